@@ -1,0 +1,896 @@
+"""
+CPU oracle for the Remhos DG remap/transport RK stage  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a dense-element numpy restatement of the reference algorithm
+(CEED/Remhos, paths below are relative to the reference checkout).  It is the
+checker for the HIP path; it is never imported by the product (`remhos_amd/`),
+only by `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg.
+
+Parity status: PINNED.  `tests/test_oracle_kat.py` reproduces the reference's own
+known-answer values (autotest/out_baseline.dat:41-69, remhos_tests.cpp:38-107) with
+this file; see DESIGN.md "Oracle".
+
+What is restated (reference file:line):
+  * problem definitions              remhos.cpp:2001-2120 (velocity), 2201-2355 (u0)
+  * mesh / remap displacement        remhos.cpp:442-584 (CFL dt 538-553, displacement 562-584)
+  * operators M, K_vol, K_face       remhos.cpp:638-727; remhos_tools.cpp:1033-1076
+                                     (convection element matrix); remhos_lo.cpp:553-570
+                                     and remhos_tools.cpp:788-858 (upwinded face data)
+  * HO  du = M^-1 K u (exact LU)     remhos_ho.cpp:84-129 (non-PA branch :90-118 semantics)
+  * LO  mass-based average           remhos_lo.cpp:247-324
+  * LO  subcell residual distrib.    remhos_lo.cpp:111-245 (host form), 1620-1802 (PA form),
+                                     remhos_tools.cpp:678-734 (Sub2Ind), 860-913
+  * bounds                           remhos_tools.cpp:432-523
+  * ClipScale FCT                    remhos_fct.cpp:449-541
+  * stage order / RK3-SSP / report   remhos.cpp:1146-1296, 1382-1428, 1596-1916
+
+MFEM itself (the finite element arithmetic) is not vendored by the reference
+(makefile:54-56, MFEM master, un-pinned); its published algorithms are restated
+here: tensor Bernstein DG basis with lexicographic dofs, Gauss-Legendre rules of
+order 2p + mo*dim - 1, Gauss-Lobatto nodal mesh of order mo, DGTraceIntegrator
+upwinding, RK3SSPSolver.  Meshes are the reference's tensor lattices
+(data/periodic-cube.mesh, cube01_hex.mesh, periodic-square.mesh, inline-quad.mesh)
+generated from their vertex coordinates.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from functools import reduce
+
+import numpy as np
+from scipy.special import erfc
+
+INF = float("inf")
+
+# --------------------------------------------------------------------------------------
+# 1-D tables
+# --------------------------------------------------------------------------------------
+
+
+def gauss_legendre_01(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return 0.5 * (x + 1.0), 0.5 * w
+
+
+def bernstein(p, t):
+    """values B[q,i] and derivatives G[q,i] of the degree-p Bernstein basis at points t."""
+    t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+    B = np.zeros((t.size, p + 1))
+    G = np.zeros((t.size, p + 1))
+    for i in range(p + 1):
+        B[:, i] = math.comb(p, i) * t**i * (1.0 - t) ** (p - i)
+    if p > 0:
+        Bm = np.zeros((t.size, p + 2))
+        for i in range(p):
+            Bm[:, i + 1] = math.comb(p - 1, i) * t**i * (1.0 - t) ** (p - 1 - i)
+        for i in range(p + 1):
+            G[:, i] = p * (Bm[:, i] - Bm[:, i + 1])
+    return B, G
+
+
+def gll_nodes(order):
+    if order == 1:
+        return np.array([0.0, 1.0])
+    if order == 2:
+        return np.array([0.0, 0.5, 1.0])
+    if order == 3:
+        a = 0.5 * (1.0 - 1.0 / math.sqrt(5.0))
+        return np.array([0.0, a, 1.0 - a, 1.0])
+    raise ValueError("mesh order 1..3 only")
+
+
+def lagrange(nodes, t):
+    t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+    n = nodes.size
+    L = np.ones((t.size, n))
+    dL = np.zeros((t.size, n))
+    for j in range(n):
+        for m in range(n):
+            if m != j:
+                L[:, j] *= (t - nodes[m]) / (nodes[j] - nodes[m])
+        for k in range(n):
+            if k == j:
+                continue
+            term = np.full(t.size, 1.0 / (nodes[j] - nodes[k]))
+            for m in range(n):
+                if m != j and m != k:
+                    term *= (t - nodes[m]) / (nodes[j] - nodes[m])
+            dL[:, j] += term
+    return L, dL
+
+
+def kron_list(mats):
+    """mats[0] acts on the x (fastest) index."""
+    return reduce(lambda acc, m: np.kron(m, acc), mats[1:], mats[0])
+
+
+# --------------------------------------------------------------------------------------
+# problem definitions (remhos.cpp:2001-2120, 2201-2355)
+# --------------------------------------------------------------------------------------
+
+
+def _to_ref(x, bb_min, bb_max):
+    center = (bb_min + bb_max) * 0.5
+    return 2.0 * (x - center) / (bb_max - bb_min)
+
+
+def velocity_function(problem, x, bb_min, bb_max):
+    """x: (..., dim) physical points -> (..., dim).  remhos.cpp:2001-2120."""
+    x = np.asarray(x, dtype=np.float64)
+    dim = x.shape[-1]
+    X = _to_ref(x, bb_min, bb_max)
+    v = np.zeros_like(x)
+    pe = problem % 20
+    if pe == 0:
+        if dim == 1:
+            v[..., 0] = 1.0
+        elif dim == 2:
+            v[..., 0] = math.sqrt(2.0 / 3.0)
+            v[..., 1] = math.sqrt(1.0 / 3.0)
+        else:
+            v[..., 0] = math.sqrt(3.0 / 6.0)
+            v[..., 1] = math.sqrt(2.0 / 6.0)
+            v[..., 2] = math.sqrt(1.0 / 6.0)
+    elif pe in (1, 2, 4):
+        w = math.pi / 2
+        v[..., 0] = -w * X[..., 1]
+        v[..., 1] = w * X[..., 0]
+    elif pe == 5:
+        v[...] = 1.0
+    elif pe in (10, 12, 13, 14, 15, 16, 17):
+        Y = X * 0.5 + 0.5
+        v[..., 0] = np.sin(math.pi * Y[..., 0]) * np.cos(math.pi * Y[..., 1])
+        v[..., 1] = -np.cos(math.pi * Y[..., 0]) * np.sin(math.pi * Y[..., 1])
+        if dim == 3:
+            c = np.cos(math.pi * Y[..., 2])
+            v[..., 0] *= c
+            v[..., 1] *= c
+            v[..., 2] = 0.0
+    else:
+        raise NotImplementedError(f"velocity for problem {problem}")
+    return v
+
+
+def _box3d(xmin, xmax, ymin, ymax, zmin, zmax, theta, ox, oy, x, y, z):
+    s = math.sin(theta * math.pi / 180)
+    c = math.cos(theta * math.pi / 180)
+    xn = c * (x - ox) - s * (y - oy) + ox
+    yn = s * (x - ox) + c * (y - oy) + oy
+    return ((xn > xmin) & (xn < xmax) & (yn > ymin) & (yn < ymax) & (z > zmin) & (z < zmax)).astype(np.float64)
+
+
+def _box2d(p1, p2, theta, origin, x, y):
+    s = math.sin(theta * math.pi / 180)
+    c = math.cos(theta * math.pi / 180)
+    ox, oy = origin
+    xn = c * (x - ox) - s * (y - oy) + ox
+    yn = s * (x - ox) + c * (y - oy) + oy
+    return ((xn > p1[0]) & (xn < p2[0]) & (yn > p1[1]) & (yn < p2[1])).astype(np.float64)
+
+
+def _cross(a, b):
+    return a + b - a * b
+
+
+def _ring(rin, rout, c, y):
+    r = np.sqrt(((y - np.asarray(c)) ** 2).sum(-1))
+    return ((r > rin) & (r < rout)).astype(np.float64)
+
+
+def u0_function(problem, x, bb_min, bb_max):
+    """x: (..., dim) -> (...).  remhos.cpp:2201-2355."""
+    x = np.asarray(x, dtype=np.float64)
+    dim = x.shape[-1]
+    X = _to_ref(x, bb_min, bb_max)
+    pe = problem % 10
+    if pe in (0, 1):
+        if dim == 1:
+            return np.exp(-40.0 * (X[..., 0] - 0.5) ** 2)
+        rx, ry, cx, cy, w = 0.45, 0.25, 0.0, -0.2, 10.0
+        if dim == 3:
+            s = 1.0 + 0.25 * np.cos(2 * math.pi * X[..., 2])
+            rx = rx * s
+            ry = ry * s
+        return (
+            erfc(w * (X[..., 0] - cx - rx))
+            * erfc(-w * (X[..., 0] - cx + rx))
+            * erfc(w * (X[..., 1] - cy - ry))
+            * erfc(-w * (X[..., 1] - cy + ry))
+        ) / 16
+    if pe == 4:
+        scale = 0.0225
+        coef = 0.5 / math.sqrt(scale)
+        X0, X1 = X[..., 0], X[..., 1]
+        slit = (X0 <= -0.05) | (X0 >= 0.05) | (X1 >= 0.7)
+        cone = coef * np.sqrt(X0**2 + (X1 + 0.5) ** 2)
+        hump = coef * np.sqrt((X0 + 0.5) ** 2 + X1**2)
+        # C precedence: cond ? 1. : (0. + cone term + hump term)
+        other = (1.0 - cone) * ((X0**2 + (X1 + 0.5) ** 2) <= 4.0 * scale) + 0.25 * (
+            1.0 + np.cos(math.pi * hump)
+        ) * (((X0 + 0.5) ** 2 + X1**2) <= 4.0 * scale)
+        cond = slit & ((X0**2 + (X1 - 0.5) ** 2) <= 4.0 * scale)
+        return np.where(cond, 1.0, other)
+    if pe == 5:
+        y = 50.0 * (x + 1.0)
+        if dim == 2:
+            rect1 = _box2d((14.0, 3.0), (17.0, 26.0), -45.0, (15.5, 11.5), y[..., 0], y[..., 1])
+            rect2 = _box2d((7.0, 10.0), (32.0, 13.0), -45.0, (15.5, 11.5), y[..., 0], y[..., 1])
+            cross = _cross(rect1, rect2)
+            ring1 = _ring(7.0, 10.0, (40.0, 40.0), y)
+            ring2 = _ring(3.0, 7.0, (40.0, 20.0), y)
+            return cross + ring1 + ring2
+        y0, y1, y2 = y[..., 0], y[..., 1], y[..., 2]
+        r1 = _box3d(7.0, 32.0, 10.0, 13.0, 10.0, 13.0, -45.0, 15.5, 11.5, y0, y1, y2)
+        r2 = _box3d(14.0, 17.0, 3.0, 26.0, 10.0, 13.0, -45.0, 15.5, 11.5, y0, y1, y2)
+        r3 = _box3d(14.0, 17.0, 10.0, 13.0, 3.0, 26.0, -45.0, 15.5, 11.5, y0, y1, y2)
+        cross = _cross(_cross(r1, r2), r3)
+        c1 = (40.0, 40.0, 40.0)
+        c2 = (40.0, 20.0, 20.0)
+        dom2 = cross + _ring(7.0, 10.0, c1, y) + _ring(3.0, 7.0, c2, y)
+        r1 = _box3d(2.0, 27.0, 30.0, 33.0, 30.0, 33.0, 0.0, 0.0, 0.0, y0, y1, y2)
+        r2 = _box3d(9.0, 12.0, 23.0, 46.0, 30.0, 33.0, 0.0, 0.0, 0.0, y0, y1, y2)
+        r3 = _box3d(9.0, 12.0, 30.0, 33.0, 23.0, 46.0, 0.0, 0.0, 0.0, y0, y1, y2)
+        cross = _cross(_cross(r1, r2), r3)
+        dom3 = cross + _ring(0.0, 7.0, c1, y) + _ring(0.0, 3.0, c2, y) + _ring(7.0, 10.0, c2, y)
+        dom1 = 1.0 - _cross(dom2, dom3)
+        return dom1 + 2.0 * dom2 + 3.0 * dom3
+    raise NotImplementedError(f"u0 for problem {problem}")
+
+
+# --------------------------------------------------------------------------------------
+# lattice meshes (coordinates of the reference's data/*.mesh files)
+# --------------------------------------------------------------------------------------
+
+MESHES = {
+    # name: (dim, coarse vertex coordinates per direction, periodic)
+    "periodic-cube": (3, [-1.0, -0.333333, 0.333333, 1.0], True),
+    "periodic-square": (2, [-1.0, -0.333333333, 0.333333333, 1.0], True),
+    "cube01_hex": (3, [0.0, 0.5, 1.0], False),
+    "inline-quad": (2, [0.0, 0.25, 0.5, 0.75, 1.0], False),
+}
+
+
+def refine_coords(c, levels):
+    c = np.asarray(c, dtype=np.float64)
+    for _ in range(levels):
+        mid = 0.5 * c[:-1] + 0.5 * c[1:]
+        out = np.empty(2 * c.size - 1)
+        out[0::2] = c
+        out[1::2] = mid
+        c = out
+    return c
+
+
+@dataclass
+class Lattice:
+    """Tensor lattice of hex/quad elements.  Element e = ex + nx*(ey + ny*ez)."""
+
+    dim: int
+    n: tuple  # elements per direction
+    periodic: bool
+    verts: list  # per direction vertex coordinates (n_d + 1)
+    mesh_order: int = 2
+
+    @property
+    def ne(self):
+        return int(np.prod(self.n))
+
+    def elem_multi(self):
+        idx = np.arange(self.ne)
+        out = []
+        for d in range(self.dim):
+            out.append(idx % self.n[d])
+            idx = idx // self.n[d]
+        return out
+
+    def elem_index(self, multi):
+        e = np.zeros_like(multi[0])
+        stride = 1
+        for d in range(self.dim):
+            e = e + multi[d] * stride
+            stride *= self.n[d]
+        return e
+
+    def shifted(self, offsets):
+        """element index shifted by integer offsets per direction; -1 outside a
+        non-periodic domain."""
+        multi = self.elem_multi()
+        ok = np.ones(self.ne, dtype=bool)
+        new = []
+        for d in range(self.dim):
+            m = multi[d] + offsets[d]
+            if self.periodic:
+                m = m % self.n[d]
+            else:
+                ok &= (m >= 0) & (m < self.n[d])
+                m = np.clip(m, 0, self.n[d] - 1)
+            new.append(m)
+        e = self.elem_index(new)
+        return np.where(ok, e, -1)
+
+    def face_neighbors(self):
+        """nbr[e, 2*d + side]"""
+        nbr = np.empty((self.ne, 2 * self.dim), dtype=np.int64)
+        for d in range(self.dim):
+            for side in (0, 1):
+                off = [0] * self.dim
+                off[d] = -1 if side == 0 else 1
+                nbr[:, 2 * d + side] = self.shifted(off)
+        return nbr
+
+    def node_coords_1d(self, d):
+        """Gauss-Lobatto mesh nodes per direction: mo*n+1 values."""
+        v = self.verts[d]
+        gl = gll_nodes(self.mesh_order)
+        mo = self.mesh_order
+        out = np.empty(mo * self.n[d] + 1)
+        for a in range(mo):
+            out[a:-1:mo] = (1.0 - gl[a]) * v[:-1] + gl[a] * v[1:]
+        out[-1] = v[-1]
+        out[0::mo] = v
+        return out
+
+    def lattice_nodes(self):
+        """all lattice nodes, shape (NN, dim), x fastest; seam copies are distinct nodes."""
+        c = [self.node_coords_1d(d) for d in range(self.dim)]
+        grids = np.meshgrid(*c, indexing="ij")  # index order (x, y, z)
+        pts = np.stack([g for g in grids], axis=-1)  # (nx, ny, nz, dim)
+        pts = np.transpose(pts, list(range(self.dim - 1, -1, -1)) + [self.dim])  # (nz, ny, nx, dim)
+        return pts.reshape(-1, self.dim)
+
+    def elem_node_ids(self):
+        """(NE, (mo+1)^dim) lattice node id of each element node, node a = ax + (mo+1)*(ay + ...)."""
+        mo = self.mesh_order
+        nn1 = [mo * self.n[d] + 1 for d in range(self.dim)]
+        multi = self.elem_multi()
+        nloc = (mo + 1) ** self.dim
+        ids = np.zeros((self.ne, nloc), dtype=np.int64)
+        for a in range(nloc):
+            rem = a
+            stride = 1
+            for d in range(self.dim):
+                ad = rem % (mo + 1)
+                rem //= mo + 1
+                ids[:, a] += (mo * multi[d] + ad) * stride
+                stride *= nn1[d]
+        return ids
+
+    def boundary_node_mask(self):
+        """lattice nodes on the domain boundary (non-periodic only)."""
+        mo = self.mesh_order
+        nn1 = [mo * self.n[d] + 1 for d in range(self.dim)]
+        idx = np.arange(int(np.prod(nn1)))
+        mask = np.zeros(idx.size, dtype=bool)
+        for d in range(self.dim):
+            m = idx % nn1[d]
+            idx = idx // nn1[d]
+            mask |= (m == 0) | (m == nn1[d] - 1)
+        return mask
+
+
+def make_lattice(name, rs, mesh_order=2):
+    dim, coarse, periodic = MESHES[name]
+    v = refine_coords(coarse, rs)
+    return Lattice(dim, tuple([v.size - 1] * dim), periodic, [v.copy() for _ in range(dim)], mesh_order)
+
+
+# --------------------------------------------------------------------------------------
+# discretisation tables
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class Tables:
+    dim: int
+    p: int
+    mo: int
+    Q: int = field(init=False)
+
+    def __post_init__(self):
+        dim, p, mo = self.dim, self.p, self.mo
+        order = 2 * p + mo * dim - 1  # MassIntegrator/ConvectionIntegrator/DGTrace rule
+        self.Q = order // 2 + 1
+        self.D = p + 1
+        self.ndof = self.D**dim
+        self.xq, self.wq = gauss_legendre_01(self.Q)
+        B, G = bernstein(p, self.xq)
+        self.B, self.G = B, G
+        gl = gll_nodes(mo)
+        L, dL = lagrange(gl, self.xq)
+        self.L, self.dL = L, dL
+        # volume matrices
+        self.Phi = kron_list([B] * dim)  # (Q^dim, ndof)
+        self.dPhi = [kron_list([G if d == c else B for d in range(dim)]) for c in range(dim)]
+        self.Psi = kron_list([L] * dim)
+        self.dPsi = [kron_list([dL if d == c else L for d in range(dim)]) for c in range(dim)]
+        self.w = kron_list([self.wq.reshape(-1, 1)] * dim).ravel()
+        # face matrices: face (c, side), quadrature over the other directions
+        e0, _ = bernstein(p, [0.0])
+        e1, _ = bernstein(p, [1.0])
+        Lf0, dLf0 = lagrange(gl, [0.0])
+        Lf1, dLf1 = lagrange(gl, [1.0])
+        self.PhiF = {}
+        self.PsiF = {}
+        self.dPsiF = {}
+        for c in range(dim):
+            for side, (bb, lf, dlf) in enumerate(((e0, Lf0, dLf0), (e1, Lf1, dLf1))):
+                self.PhiF[c, side] = kron_list([bb if d == c else B for d in range(dim)])
+                self.PsiF[c, side] = kron_list([lf if d == c else L for d in range(dim)])
+                self.dPsiF[c, side] = [
+                    kron_list([(dlf if d == c else lf) if d == c else (dL if d == cc else L) for d in range(dim)])
+                    if cc == c
+                    else kron_list([lf if d == c else (dL if d == cc else L) for d in range(dim)])
+                    for cc in range(dim)
+                ]
+        self.wF = kron_list([self.wq.reshape(-1, 1)] * (dim - 1)).ravel() if dim > 1 else np.ones(1)
+        # closed uniform points i/p (projection nodes and subcell corners)
+        cu = np.arange(p + 1) / p if p > 0 else np.array([0.5])
+        Lc, _ = lagrange(gl, cu)
+        self.PsiCU = kron_list([Lc] * dim)  # (ndof, nnodes)
+        Lm, dLm = lagrange(gl, [0.5])
+        self.PsiMid = kron_list([Lm] * dim)
+        self.dPsiMid = [kron_list([dLm if d == c else Lm for d in range(dim)]) for c in range(dim)]
+        # mirror permutation across a face normal to c: i_c -> p - i_c
+        idx = np.arange(self.ndof)
+        self.mirror = []
+        for c in range(dim):
+            ic = (idx // self.D**c) % self.D
+            self.mirror.append(idx + (p - 2 * ic) * self.D**c)
+        # multi-index of each dof
+        self.dof_multi = [(idx // self.D**c) % self.D for c in range(dim)]
+        # Sub2Ind (remhos_tools.cpp:678-734)
+        if p >= 1:
+            ns = p**dim
+            m = np.arange(ns)
+            base = np.zeros(ns, dtype=np.int64)
+            for c in range(dim):
+                base += ((m // p**c) % p) * self.D**c
+            corners = np.zeros((ns, 2**dim), dtype=np.int64)
+            for j in range(2**dim):
+                off = 0
+                for c in range(dim):
+                    off += ((j >> c) & 1) * self.D**c
+                corners[:, j] = base + off
+            self.sub2ind = corners
+
+
+def adjugate(J):
+    """J: (..., dim, dim) -> adj(J) = det(J) * inv(J), explicit cofactors."""
+    dim = J.shape[-1]
+    A = np.empty_like(J)
+    if dim == 2:
+        A[..., 0, 0] = J[..., 1, 1]
+        A[..., 0, 1] = -J[..., 0, 1]
+        A[..., 1, 0] = -J[..., 1, 0]
+        A[..., 1, 1] = J[..., 0, 0]
+        return A
+    J11, J12, J13 = J[..., 0, 0], J[..., 0, 1], J[..., 0, 2]
+    J21, J22, J23 = J[..., 1, 0], J[..., 1, 1], J[..., 1, 2]
+    J31, J32, J33 = J[..., 2, 0], J[..., 2, 1], J[..., 2, 2]
+    # remhos_lo.cpp:1168-1188
+    A[..., 0, 0] = J22 * J33 - J23 * J32
+    A[..., 0, 1] = J32 * J13 - J12 * J33
+    A[..., 0, 2] = J12 * J23 - J22 * J13
+    A[..., 1, 0] = J31 * J23 - J21 * J33
+    A[..., 1, 1] = J11 * J33 - J13 * J31
+    A[..., 1, 2] = J21 * J13 - J11 * J23
+    A[..., 2, 0] = J21 * J32 - J31 * J22
+    A[..., 2, 1] = J31 * J12 - J11 * J32
+    A[..., 2, 2] = J11 * J22 - J12 * J21
+    return A
+
+
+def det(J):
+    dim = J.shape[-1]
+    if dim == 2:
+        return J[..., 0, 0] * J[..., 1, 1] - J[..., 0, 1] * J[..., 1, 0]
+    return (
+        J[..., 0, 0] * (J[..., 1, 1] * J[..., 2, 2] - J[..., 1, 2] * J[..., 2, 1])
+        - J[..., 0, 1] * (J[..., 1, 0] * J[..., 2, 2] - J[..., 1, 2] * J[..., 2, 0])
+        + J[..., 0, 2] * (J[..., 1, 0] * J[..., 2, 1] - J[..., 1, 1] * J[..., 2, 0])
+    )
+
+
+# --------------------------------------------------------------------------------------
+# the stage operator
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class Config:
+    mesh: str = "periodic-cube"
+    rs: int = 1
+    order: int = 2
+    mesh_order: int = 2
+    problem: int = 0
+    dt: float = 0.015
+    t_final: float = 2.0
+    max_steps: int = -1
+    ho: int = 3  # 3: local inverse
+    lo: int = 4  # 4: subcell RD, 5: mass-based average
+    fct: int = 2  # 2: clip+scale
+    ho_solve: str = "exact"  # 'exact' (remhos_ho.cpp:90-118) or 'cg' (DGMassInverse semantics)
+
+
+class Remhos:
+    """Restatement of remhos() + AdvectionOperator for lattice meshes."""
+
+    def __init__(self, cfg: Config, lattice: Lattice | None = None):
+        self.cfg = cfg
+        self.lat = lattice if lattice is not None else make_lattice(cfg.mesh, cfg.rs, cfg.mesh_order)
+        lat = self.lat
+        self.dim = lat.dim
+        self.exec_mode = 0 if cfg.problem < 10 else 1  # remhos.cpp:437-440
+        self.T = Tables(lat.dim, cfg.order, lat.mesh_order)
+        self.bb_min = np.array([lat.verts[d][0] for d in range(lat.dim)])
+        self.bb_max = np.array([lat.verts[d][-1] for d in range(lat.dim)])
+        self.nbr = lat.face_neighbors()
+        self.node_ids = lat.elem_node_ids()
+        nodes = lat.lattice_nodes()
+        self.x0_nodes = nodes.copy()
+        self.X0 = nodes[self.node_ids]  # (NE, nn, dim)
+        self.dt = cfg.dt
+        if self.dt < 0.0:
+            self.dt = self._cfl_dt()
+        # remap displacement (remhos.cpp:562-584), including the "t += dt first" quirk
+        self.V = np.zeros_like(self.X0)
+        if self.exec_mode == 1:
+            x = nodes.copy()
+            v = self.vel(x)
+            t = 0.0
+            while t < cfg.t_final:
+                t += self.dt
+                x = x + min(self.dt, cfg.t_final - t) * v
+                v = self.vel(x)
+            self.V = (x - nodes)[self.node_ids]
+        # submesh for lo 4 (remhos.cpp:796-867)
+        if cfg.lo == 4:
+            self.Xs0 = np.einsum("an,enc->eac", self.T.PsiCU, self.X0)  # (NE, ndof, dim)
+            self.Vs = np.zeros_like(self.Xs0)
+            if self.exec_mode == 1:
+                self.Vs = self.vel(self.Xs0)
+                if not lat.periodic:
+                    self.Vs[self._submesh_boundary_mask()] = 0.0
+        # initial condition: nodal sampling at closed-uniform points (remhos.cpp:878-884)
+        xcu = np.einsum("an,enc->eac", self.T.PsiCU, self.X0)
+        self.u = u0_function(cfg.problem, xcu, self.bb_min, self.bb_max)
+        self.t = 0.0
+        self.update_geometry(0.0)
+        self.masses0 = self.m.copy()
+        self.mass0 = float((self.m * self.u).sum())
+
+    # ---- helpers -------------------------------------------------------------------
+    def vel(self, x):
+        return velocity_function(self.cfg.problem, x, self.bb_min, self.bb_max)
+
+    def _cfl_dt(self):
+        # remhos.cpp:538-553; GetElementSize(e) = |det J(center)|^(1/dim)
+        T = self.T
+        J = np.stack([np.einsum("qn,enc->eqc", T.dPsiMid[c], self.X0) for c in range(self.dim)], axis=-1)
+        length = np.abs(det(J[:, 0])) ** (1.0 / self.dim)
+        xc = np.einsum("qn,enc->eqc", T.PsiMid, self.X0)[:, 0]
+        v = self.vel(xc)
+        speed = np.sqrt((v * v).sum(-1) + 1e-14)
+        return float(np.min(0.25 * length / speed))
+
+    def _submesh_boundary_mask(self):
+        lat, T = self.lat, self.T
+        multi = lat.elem_multi()
+        mask = np.zeros((lat.ne, T.ndof), dtype=bool)
+        for c in range(self.dim):
+            ic = T.dof_multi[c][None, :]
+            ec = multi[c][:, None]
+            mask |= ((ec == 0) & (ic == 0)) | ((ec == lat.n[c] - 1) & (ic == T.p))
+        return mask
+
+    # ---- geometry + operators at pseudo-time t ---------------------------------------
+    def update_geometry(self, t):
+        """everything MultUnlimited re-sets-up per stage in remap (remhos.cpp:1598-1676)."""
+        T, dim = self.T, self.dim
+        X = self.X0 + t * self.V if self.exec_mode == 1 else self.X0
+        self.X = X
+        J = np.stack([np.einsum("qn,enc->eqc", T.dPsi[c], X) for c in range(dim)], axis=-1)  # (e,q,a,c)
+        self.detJ = det(J)
+        adj = adjugate(J)
+        if self.exec_mode == 1:
+            vq = np.einsum("qn,enc->eqc", T.Psi, self.V)
+            alpha = 1.0
+        else:
+            xq = np.einsum("qn,enc->eqc", T.Psi, X)
+            vq = self.vel(xq)
+            alpha = -1.0
+        # D_c = alpha w (adjJ v)_c  (remhos_lo.cpp:1168-1188)
+        self.Dq = alpha * T.w[None, :, None] * np.einsum("eqca,eqa->eqc", adj, vq)
+        self.wdet = T.w[None, :] * self.detJ
+        self.m = np.einsum("qi,eq->ei", T.Phi, self.wdet)  # lumped mass = M 1
+        # faces: upwind coefficient w_f * max(0, -+ v.n_out) per own face
+        self.sF = {}
+        for c in range(dim):
+            for side in (0, 1):
+                Jf = np.stack([np.einsum("qn,enc->eqc", T.dPsiF[c, side][cc], X) for cc in range(dim)], axis=-1)
+                adjf = adjugate(Jf)
+                sign = 1.0 if side == 1 else -1.0
+                nout = sign * adjf[:, :, c, :]  # area-weighted outward normal (e, qf, a)
+                if self.exec_mode == 1:
+                    vf = np.einsum("qn,enc->eqc", T.PsiF[c, side], self.V)
+                else:
+                    xf = np.einsum("qn,enc->eqc", T.PsiF[c, side], X)
+                    vf = self.vel(xf)
+                vn = (vf * nout).sum(-1)
+                s = np.maximum(0.0, -vn) if self.exec_mode == 0 else np.maximum(0.0, vn)
+                self.sF[c, side] = T.wF[None, :] * s
+        self._M = None
+        if self.cfg.lo == 4:
+            self._subcell_weights(t)
+
+    def mass_matrices(self):
+        if self._M is None:
+            self._M = np.einsum("qi,eq,qj->eij", self.T.Phi, self.wdet, self.T.Phi, optimize=True)
+        return self._M
+
+    def _subcell_weights(self, t):
+        """SubcellWeights(k)(m, j)  (remhos_tools.cpp:860-874, 1033-1076)."""
+        T, dim = self.T, self.dim
+        Xs = self.Xs0 + t * self.Vs if self.exec_mode == 1 else self.Xs0
+        corners = Xs[:, T.sub2ind, :]  # (NE, ns, 2^dim, dim)
+        nc = 2**dim
+        dpsi = np.zeros((nc, dim))
+        for j in range(nc):
+            for c in range(dim):
+                dpsi[j, c] = (1.0 if (j >> c) & 1 else -1.0) / 2 ** (dim - 1)
+        Js = np.einsum("emja,jc->emac", corners, dpsi)
+        adj = adjugate(Js)
+        if self.exec_mode == 1:
+            vmid = self.Vs[:, T.sub2ind, :].sum(axis=2) / nc
+            alpha = 1.0
+        else:
+            xmid = corners.sum(axis=2) / nc
+            vmid = self.vel(xmid)
+            alpha = -1.0
+        vec2 = alpha * np.einsum("emca,ema->emc", adj, vmid)
+        self.subW = np.einsum("jc,emc->emj", dpsi, vec2)  # (NE, ns, 2^dim)
+
+    # ---- solvers --------------------------------------------------------------------
+    def conv_apply(self, u):
+        """z = K_vol u (PA convection, no faces)."""
+        T = self.T
+        g = np.zeros_like(self.detJ)
+        for c in range(self.dim):
+            g += self.Dq[:, :, c] * (u @ T.dPhi[c].T)
+        return g @ T.Phi
+
+    def face_apply(self, u):
+        """DG-trace (transpose) upwind face term of K_HO."""
+        T = self.T
+        y = np.zeros_like(u)
+        for c in range(self.dim):
+            for side in (0, 1):
+                nb = self.nbr[:, 2 * c + side]
+                own = u @ T.PhiF[c, side].T
+                unb = np.where(nb[:, None] >= 0, u[np.maximum(nb, 0)], 0.0) @ T.PhiF[c, 1 - side].T
+                y += (self.sF[c, side] * (unb - own)) @ T.PhiF[c, side]
+        return y
+
+    def calc_ho(self, u):
+        """LocalInverseHOSolver::CalcHOSolution (remhos_ho.cpp:84-129)."""
+        rhs = self.conv_apply(u) + self.face_apply(u)
+        self.last_rhs = rhs
+        if self.cfg.ho_solve == "exact":
+            return np.linalg.solve(self.mass_matrices(), rhs[..., None])[..., 0]
+        return self.mass_cg(rhs)
+
+    def mass_cg(self, rhs, abs_tol=1e-8, rel_tol=0.0, max_iter=100):
+        """DGMassInverse semantics [MFEM]: Jacobi-PCG per element in the Gauss-Legendre nodal
+        basis, stop when (D^-1 r, r) <= max(rel^2 nom0, abs^2)."""
+        T = self.T
+        xg, _ = gauss_legendre_01(T.D)
+        Bg, _ = bernstein(T.p, xg)  # GL nodal value from Bernstein coeffs: u_gl = Bg u_b
+        C1 = Bg  # (D_gl, D_b)
+        C = kron_list([C1] * self.dim)  # Bernstein coeffs -> GL nodal values
+        Cinv = np.linalg.inv(C)
+        # rhs in GL basis: b_gl = Cinv^T b_b ; M_gl = Cinv^T M_b Cinv
+        PhiG = T.Phi @ Cinv  # GL basis at quadrature points
+        b = rhs @ Cinv
+        diag = np.einsum("qi,eq,qi->ei", PhiG, self.wdet, PhiG)
+        x = np.zeros_like(b)
+        r = b.copy()
+        z = r / diag
+        d = z.copy()
+        nom = (z * r).sum(-1)
+        nom0 = nom.copy()
+        tol = np.maximum(rel_tol**2 * nom0, abs_tol**2)
+        active = nom > tol
+        it = 0
+        while active.any() and it < max_iter:
+            Ad = ((d @ PhiG.T) * self.wdet) @ PhiG
+            den = (d * Ad).sum(-1)
+            a = np.where(active, nom / np.where(den != 0, den, 1.0), 0.0)
+            x += a[:, None] * d
+            r -= a[:, None] * Ad
+            z = r / diag
+            betanom = (z * r).sum(-1)
+            beta = np.where(active, betanom / np.where(nom != 0, nom, 1.0), 0.0)
+            d = z + beta[:, None] * d
+            nom = np.where(active, betanom, nom)
+            active = active & (nom > tol)
+            it += 1
+        self.cg_iters = it
+        # u_gl = C u_b  =>  u_b = Cinv u_gl; in row-vector form x_b = x_gl @ Cinv.T
+        return x @ Cinv.T
+
+    def calc_lo_massavg(self, u, du_ho, dt):
+        """MassBasedAvg::CalcLOSolution (remhos_lo.cpp:247-324)."""
+        T = self.T
+        u_new = u + dt * du_ho
+        uq = u_new @ T.Phi.T
+        mass = (self.wdet * uq).sum(-1)
+        vol = self.wdet.sum(-1)
+        ubar = mass / vol
+        return (ubar[:, None] - u) / dt
+
+    def calc_lo_rd(self, u):
+        """(PA)ResidualDistribution(Subcell)::CalcLOSolution (remhos_lo.cpp:111-245, 1620-1802)."""
+        T, cfg = self.T, self.cfg
+        eps = 1e-15
+        gamma = 1.0
+        ndof = T.ndof
+        z = self.conv_apply(u)
+        du = np.zeros_like(u)
+        # lumped upwind face fluxes (remhos_tools.cpp:876-913 with alpha = 0; remhos_lo.cpp:854-868)
+        for c in range(self.dim):
+            for side in (0, 1):
+                nb = self.nbr[:, 2 * c + side]
+                coef = self.sF[c, side] @ T.PhiF[c, side]  # (NE, ndof), zero off the face
+                unb = np.where(nb[:, None] >= 0, u[np.maximum(nb, 0)][:, T.mirror[c]], 0.0)
+                du += coef * (unb - u)
+        xe_max = u.max(-1)
+        xe_min = u.min(-1)
+        xsum = u.sum(-1)
+        rhoP = np.maximum(0.0, z).sum(-1)
+        rhoN = np.minimum(0.0, z).sum(-1)
+        sumWP = ndof * xe_max - xsum + eps
+        sumWN = ndof * xe_min - xsum - eps
+        wP = (xe_max[:, None] - u) / sumWP[:, None]
+        wN = (xe_min[:, None] - u) / sumWN[:, None]
+        if cfg.lo == 4:
+            nds = T.sub2ind.shape[1]
+            us = u[:, T.sub2ind]  # (NE, ns, nds)
+            fluct = (self.subW * us).sum(-1)
+            xmaxs = us.max(-1)
+            xmins = us.min(-1)
+            xs = us.sum(-1)
+            swP = nds * xmaxs - xs + eps
+            swN = nds * xmins - xs - eps
+            fP = np.maximum(0.0, fluct)
+            fN = np.minimum(0.0, fluct)
+            sumFP = fP.sum(-1)
+            sumFN = fN.sum(-1)
+            nwP = np.zeros_like(u)
+            nwN = np.zeros_like(u)
+            contribP = fP[:, :, None] * ((xmaxs[:, :, None] - us) / swP[:, :, None])
+            contribN = fN[:, :, None] * ((xmins[:, :, None] - us) / swN[:, :, None])
+            for m in range(T.sub2ind.shape[0]):
+                for j in range(nds):
+                    nwP[:, T.sub2ind[m, j]] += contribP[:, m, j]
+                    nwN[:, T.sub2ind[m, j]] += contribN[:, m, j]
+            aux = gamma / (rhoP + eps)
+            wP = wP * (1.0 - np.minimum(aux * sumFP, 1.0))[:, None]
+            wP = wP + np.minimum(aux, 1.0 / (sumFP + eps))[:, None] * nwP
+            aux = gamma / (rhoN - eps)
+            wN = wN * (1.0 - np.minimum(aux * sumFN, 1.0))[:, None]
+            wN = wN + np.maximum(aux, 1.0 / (sumFN - eps))[:, None] * nwN
+        return (du + wP * rhoP[:, None] + wN * rhoN[:, None]) / self.m
+
+    def compute_bounds(self, u):
+        """ComputeElementsMinMax + ComputeOverlapBounds (remhos_tools.cpp:432-523): min/max over
+        all elements that contain the dof's CG node."""
+        lat, T = self.lat, self.T
+        xe_min = u.min(-1)
+        xe_max = u.max(-1)
+        p = T.p
+        dim = self.dim
+        umin = np.full_like(u, INF)
+        umax = np.full_like(u, -INF)
+        import itertools
+
+        for off in itertools.product((-1, 0, 1), repeat=dim):
+            sh = lat.shifted(off)
+            smin = np.where(sh >= 0, xe_min[np.maximum(sh, 0)], INF)
+            smax = np.where(sh >= 0, xe_max[np.maximum(sh, 0)], -INF)
+            dmask = np.ones(T.ndof, dtype=bool)
+            for c in range(dim):
+                ic = T.dof_multi[c]
+                if off[c] == -1:
+                    dmask &= ic == 0
+                elif off[c] == 1:
+                    dmask &= ic == p
+            umin[:, dmask] = np.minimum(umin[:, dmask], smin[:, None])
+            umax[:, dmask] = np.maximum(umax[:, dmask], smax[:, None])
+        return umin, umax
+
+    @staticmethod
+    def clip_scale(u, m, du_ho, du_lo, umin, umax, dt):
+        """ClipScaleSolver::CalcFCTSolution (remhos_fct.cpp:449-541)."""
+        eps = 1.0e-15
+        u_new_lo = u + dt * du_lo
+        fmin_ = m / dt * (umin - u_new_lo)
+        fmax_ = m / dt * (umax - u_new_lo)
+        f = m * (du_ho - du_lo)
+        f = np.minimum(fmax_, np.maximum(fmin_, f))
+        sumNeg = np.minimum(f, 0.0).sum(-1)
+        sumPos = np.maximum(f, 0.0).sum(-1)
+        new_mass = sumNeg + sumPos
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f1 = np.minimum(0.0, f) - np.maximum(0.0, f) * (sumNeg / sumPos)[:, None]
+            f2 = np.maximum(0.0, f) - np.minimum(0.0, f) * (sumPos / sumNeg)[:, None]
+        f = np.where((new_mass > eps)[:, None], f1, f)
+        f = np.where((new_mass < -eps)[:, None], f2, f)
+        return du_lo + f / m
+
+    # ---- the stage = AdvectionOperator::Mult ---------------------------------------------
+    def stage(self, u, t, dt, keep=None):
+        """MultUnlimited + LimitMult (remhos.cpp:1596-1916).  dt is the full step."""
+        if self.exec_mode == 1:
+            self.update_geometry(t)
+        cfg = self.cfg
+        if cfg.fct == 0 and cfg.lo == 0:
+            return self.calc_ho(u)
+        du_ho = self.calc_ho(u)
+        if cfg.lo == 5:
+            du_lo = self.calc_lo_massavg(u, du_ho, dt)
+        else:
+            du_lo = self.calc_lo_rd(u)
+        umin, umax = self.compute_bounds(u)
+        du = self.clip_scale(u, self.m, du_ho, du_lo, umin, umax, dt)
+        if keep is not None:
+            keep.update(du_ho=du_ho, du_lo=du_lo, umin=umin, umax=umax, du=du, m=self.m.copy(), rhs=self.last_rhs)
+        return du
+
+    def step(self, dt):
+        """RK3SSPSolver::Step [MFEM], stage times t, t+dt, t+dt/2."""
+        x = self.u
+        t = self.t
+        k = self.stage(x, t, dt)
+        y = x + dt * k
+        k = self.stage(y, t + dt, dt)
+        y = y + dt * k
+        y = 0.75 * x + 0.25 * y
+        k = self.stage(y, t + dt / 2, dt)
+        y = y + dt * k
+        self.u = (1.0 / 3.0) * x + (2.0 / 3.0) * y
+        self.t = t + dt
+
+    def run(self, verbose=False):
+        """time loop remhos.cpp:1146-1296 and report :1382-1428."""
+        cfg = self.cfg
+        t_final = 1.0 if self.exec_mode == 1 else cfg.t_final
+        ti = 0
+        done = False
+        while not done:
+            dt_real = min(self.dt, t_final - self.t)
+            self.step(dt_real)
+            ti += 1
+            done = self.t >= t_final - 1e-8 * self.dt
+            if ti == cfg.max_steps:
+                done = True
+            if verbose and (done or ti % 20 == 0):
+                print(f"step {ti} t {self.t:.6f}")
+        self.steps = ti
+        return self.report()
+
+    def report(self):
+        if self.exec_mode == 1:
+            self.update_geometry(self.t)
+            masses = self.m
+        else:
+            masses = self.masses0
+        mass = float((masses * self.u).sum())
+        return {
+            "mass": mass,
+            "max": float(self.u.max()),
+            "mass0": self.mass0,
+            "mass_loss": abs(self.mass0 - mass),
+            "steps": getattr(self, "steps", 0),
+            "dt": self.dt,
+        }

@@ -1,0 +1,77 @@
+"""Pin the CPU oracle against the reference's own known-answer values.
+
+Sources (paths in the reference checkout):
+  autotest/out_baseline.dat:41-69   (-ho 3 -lo 4 -fct 2; mass and max at 10 digits)
+  remhos_tests.cpp:38-107           (-ho 3 -lo 5 -fct 2; final mass at 17 digits, AlmostEq 10 eps)
+"""
+import pytest
+
+from oracle.remhos_oracle import Config, Remhos
+
+
+def _run(**kw):
+    r = Remhos(Config(**kw))
+    return r.run()
+
+
+def _r10(x):
+    return float(f"{x:.10g}")
+
+
+AUTOTEST = [
+    # name, kwargs, Final mass u, Max value u  (autotest/out_baseline.dat)
+    ("periodic-cube transport (:66-69)", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo=4),
+     0.9607429525, 0.9334903111),
+    ("cube01_hex remap (:46-49)", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo=4),
+     0.1197299801, 0.9997499683),
+    ("periodic-square balls-jacks (:61-64)", dict(mesh="periodic-square", rs=3, order=3, problem=5, dt=0.004, t_final=0.8, lo=4),
+     0.1623263888, 0.7145371968),
+    ("inline-quad remap pacman (:41-44)", dict(mesh="inline-quad", rs=1, order=3, problem=14, dt=0.0015, t_final=0.75, lo=4),
+     0.0847954729, 0.7581364675),
+]
+
+
+@pytest.mark.parametrize("name,kw,mass,umax", AUTOTEST, ids=[a[0] for a in AUTOTEST])
+def test_autotest_baseline(name, kw, mass, umax):
+    out = _run(**kw)
+    # the reference prints 10 significant digits and the suite diffs the text
+    assert _r10(out["mass"]) == mass
+    assert _r10(out["max"]) == umax
+
+
+CTEST = [
+    ("ctest0 inline-quad rs1 o2", dict(mesh="inline-quad", rs=1, order=2, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
+     0.09711395400387984, 1e-14),
+    ("ctest1 inline-quad rs4 o3", dict(mesh="inline-quad", rs=4, order=3, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
+     0.0930984399257905, 1e-14),
+    ("ctest2 inline-quad rs4 o4", dict(mesh="inline-quad", rs=4, order=4, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
+     0.09237630484178257, 1e-14),
+    ("ctest3 cube01_hex rs1 o2", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
+     0.11972857593296446, 1e-14),
+    ("ctest5 inline-quad -pa rs4 o2", dict(mesh="inline-quad", rs=4, order=2, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
+     0.09185717760402806, 1e-14),
+    # the PA reference solves the local mass systems by CG; the oracle's exact solve agrees to 1.4e-14
+    ("ctest7 cube01_hex -pa rs3 o3", dict(mesh="cube01_hex", rs=3, order=3, problem=10, dt=-1.0, t_final=0.5, lo=5, max_steps=1),
+     0.11601536511552431, 5e-13),
+]
+
+
+@pytest.mark.parametrize("name,kw,mass,rtol", CTEST, ids=[c[0] for c in CTEST])
+def test_ctest_masses(name, kw, mass, rtol):
+    out = _run(**kw)
+    assert abs(out["mass"] - mass) <= rtol * (1.0 + abs(mass)), (out["mass"], mass)
+
+
+def test_cfl_dt_values():
+    # CFL dt of ctest #3 and #7
+    r = Remhos(Config(mesh="cube01_hex", rs=1, order=2, problem=10, dt=-1.0, t_final=0.5, lo=5))
+    assert abs(r.dt - 0.07811492852594501) < 1e-16
+    r = Remhos(Config(mesh="cube01_hex", rs=3, order=3, problem=10, dt=-1.0, t_final=0.5, lo=5))
+    assert abs(r.dt - 0.01585216144447629) < 1e-16
+
+
+def test_initial_masses():
+    r = Remhos(Config(mesh="periodic-cube", rs=1, order=2, problem=0, lo=5))
+    assert _r10(r.mass0) == 0.9607429525
+    r = Remhos(Config(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo=5))
+    assert abs(r.mass0 - 0.1197304499041930) < 1e-15
