@@ -1,0 +1,155 @@
+/*
+ * rmh.h -- C ABI of the MI355X-native Remhos hot path (HO -> LO -> bounds -> FCT RK stage).
+ *
+ * This is the drop-in boundary.  Every entry point replaces one call the reference's
+ * AdvectionOperator makes into its HOSolver / LOSolver / FCTSolver / DofInfo objects
+ * (reference file:line cited per function; paths are relative to the CEED/Remhos checkout).
+ * The C++ classes in include/remhos_amd/solvers.hpp keep the reference's virtual
+ * signatures and forward to these functions; INTEGRATION.md shows the binding a Remhos
+ * maintainer would add.
+ *
+ * Conventions
+ *   - one rmh_ctx per GPU / per MPI rank; calls on one ctx are serialised on one HIP stream;
+ *   - every vector argument of a hot-path call is a DEVICE pointer, non-owning, never aliased
+ *     with an output; layout = MFEM L2 E-vector: `ndof = (p+1)^3` contiguous doubles per
+ *     element, lexicographic with x fastest (remhos.cpp:588-590, remhos_lo.cpp:274);
+ *   - arrays handed to rmh_create() are HOST pointers and are copied;
+ *   - functions return 0 on success and a negative rmh_status otherwise (the reference aborts
+ *     through MFEM_VERIFY/MFEM_ABORT instead, e.g. remhos_ho.cpp:86, remhos_fct.cpp:465);
+ *   - there is no CPU fallback: without a HIP device rmh_create() fails with RMH_ERR_NO_DEVICE.
+ */
+#ifndef RMH_H
+#define RMH_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rmh_ctx rmh_ctx;
+
+typedef enum {
+   RMH_OK = 0,
+   RMH_ERR_INVALID = -1,     /* bad argument / unsupported order or dimension      */
+   RMH_ERR_NO_DEVICE = -2,   /* no HIP device: the product path refuses to run     */
+   RMH_ERR_HIP = -3,         /* a HIP runtime call failed (see rmh_last_error)     */
+   RMH_ERR_NOT_CONVERGED = -4, /* local mass solve hit the iteration cap           */
+   RMH_ERR_STATE = -5        /* call order violated (e.g. FCT before HO)           */
+} rmh_status;
+
+/* Mesh + space description of one rank ("SpaceLayout", stands in for the
+ * ParFiniteElementSpace / ParMesh the reference's solvers receive: remhos_ho.hpp:32,
+ * remhos_lo.hpp:31, remhos_fct.hpp:34).  Elements [0, ne_owned) are owned, elements
+ * [ne_owned, ne_owned + ne_ghost) are ghosts owned by neighbour ranks (MFEM's face-neighbour
+ * elements, plus edge/vertex neighbours for the bounds stencil). */
+typedef struct {
+   int dim;          /* 3                                                                  */
+   int order;        /* polynomial order p of the Bernstein DG space (-o, remhos.cpp:261)   */
+   int mesh_order;   /* order of the nodal mesh (-mo, remhos.cpp:222); 2                    */
+   int exec_mode;    /* 0 transport, 1 remap (remhos.cpp:437-440)                           */
+   int ne_owned;
+   int ne_ghost;
+   /* Mesh nodes as per-element copies (MFEM L2 nodal E-vector; for H1 meshes the caller
+    * expands shared nodes), [ne_owned][3 components][27 nodes], node a = ax + 3*(ay + 3*az):
+    *   x0  : start positions                                   (remhos.cpp:530-531)
+    *   vel : remap: pseudo-time mesh displacement v_gf          (remhos.cpp:562-584)
+    *         transport: advection velocity sampled at the nodes (remhos.cpp:534)          */
+   const double *x0;
+   const double *vel;
+   /* face neighbours [ne_owned][6], face f = 2*c + side (c = direction, side 0: xi_c = 0,
+    * side 1: xi_c = 1); value = element index in [0, ne_owned + ne_ghost) or -1 on the
+    * domain boundary.  The neighbour sees the face as (c, 1 - side) with identical tangential
+    * orientation (tensor-lattice meshes: SURVEY.md section 7 "Hard parts").                 */
+   const int *face_nbr;
+   /* 27-point element stencil for the overlap bounds [ne_owned][27], entry
+    * (ox+1) + 3*(oy+1) + 9*(oz+1): element sharing the corresponding vertex/edge/face,
+    * -1 if none (ComputeOverlapBounds, remhos_tools.cpp:432-495).                           */
+   const int *stencil27;
+   /* lo 4 only (may be NULL): sub-mesh node velocity at the closed-uniform points
+    * [ne_owned][3][(p+1)^3] (v_sub_gf, remhos.cpp:837-853).                                 */
+   const double *subcell_vel;
+   int device;       /* HIP device ordinal */
+} rmh_layout;
+
+/* Creation / destruction.  Replaces the construction of LocalInverseHOSolver, MassBasedAvg /
+ * PAResidualDistributionSubcell, ClipScaleSolver and DofInfo (remhos.cpp:730, 912-995,
+ * 1083-1108). */
+int  rmh_create(const rmh_layout *layout, rmh_ctx **out);
+void rmh_destroy(rmh_ctx *ctx);
+const char *rmh_last_error(void);
+const char *rmh_version(void);
+
+/* All work of ctx is enqueued on `hip_stream` (a hipStream_t; NULL = default stream). */
+int rmh_set_stream(rmh_ctx *ctx, void *hip_stream);
+
+/* Remap re-setup: AdvectionOperator::MultUnlimited moves the mesh to pseudo-time t and
+ * re-assembles M_HO, K_HO and the lumped mass (remhos.cpp:1598-1637).  Here the geometry is
+ * recomputed inside the kernels from x0 + t*vel (matrix-free), so this call only records t. */
+int rmh_setup(rmh_ctx *ctx, double t);
+
+/* Ghost data for multi-rank runs: device arrays holding the ghost elements' values of u
+ * ([ne_ghost][ndof]; ParGridFunction::ExchangeFaceNbrData, remhos_ho.cpp:122 via
+ * ParL2FaceRestriction) and ghost element extrema ([ne_ghost] each; the GroupCommunicator
+ * min/max reduction of remhos_tools.cpp:461-466).  Pointers are remembered, not copied. */
+int rmh_set_ghost_u(rmh_ctx *ctx, const double *u_ghost);
+int rmh_set_ghost_minmax(rmh_ctx *ctx, const double *xe_min_ghost, const double *xe_max_ghost);
+
+/* HOSolver::CalcHOSolution (remhos_ho.hpp:38, LocalInverseHOSolver remhos_ho.cpp:84-129):
+ * du = M^-1 (K_vol + K_face) u with an element-local, tightly converged mass solve.
+ * Also refreshes the lumped mass vector (remhos.cpp:1632) and the element extrema of u. */
+int rmh_ho_apply(rmh_ctx *ctx, const double *u, double *du);
+
+/* Lumped mass M_HO * 1 at the pseudo-time of the last rmh_setup (remhos.cpp:719-727, 1625-1632).
+ * rmh_lumped_mass returns the ctx-owned device vector written by rmh_ho_apply;
+ * rmh_compute_lumped_mass evaluates it on its own (initial / final mass, remhos.cpp:1394-1403). */
+const double *rmh_lumped_mass(rmh_ctx *ctx);
+int rmh_compute_lumped_mass(rmh_ctx *ctx, double t, double *m);
+
+/* LOSolver::CalcLOSolution:
+ *   MassBasedAvg (lo 5, remhos_lo.cpp:247-324; du_ho is what SetHOSolution hands over,
+ *   remhos_lo.hpp:102);  PAResidualDistributionSubcell (lo 4, remhos_lo.cpp:1620-1802). */
+int rmh_lo_massavg(rmh_ctx *ctx, const double *u, const double *du_ho, double dt, double *du_lo);
+int rmh_lo_rdsubcell(rmh_ctx *ctx, const double *u, double *du_lo);
+
+/* DofInfo::ComputeElementsMinMax (remhos_tools.cpp:497-523) and DofInfo::ComputeBounds ->
+ * ComputeOverlapBounds (remhos_tools.cpp:432-495).  rmh_bounds uses the element extrema of
+ * the last rmh_elem_minmax / rmh_ho_apply call plus the ghost extrema. */
+int rmh_elem_minmax(rmh_ctx *ctx, const double *u, double *xe_min, double *xe_max);
+int rmh_bounds(rmh_ctx *ctx, const double *xe_min, const double *xe_max,
+               double *u_min, double *u_max);
+
+/* FCTSolver::CalcFCTSolution, ClipScaleSolver (remhos_fct.hpp:83-86, remhos_fct.cpp:449-541). */
+int rmh_fct_clipscale(rmh_ctx *ctx, const double *u, const double *m,
+                      const double *du_ho, const double *du_lo,
+                      const double *u_min, const double *u_max, double dt, double *du);
+
+/* Fused LimitMult for -lo 5 -fct 2 (remhos.cpp:1798-1845): mass-based average, overlap bounds
+ * and clip+scale in one pass over the element, nothing but du written.  Uses the lumped mass
+ * and element extrema left by rmh_ho_apply on the same u.  If y_out != NULL the RK update
+ *   y_out = a * x_base + b * (u + dt_rk * du)      (RK3SSPSolver::Step [MFEM])
+ * is applied as well and du may be NULL. */
+int rmh_limit_fused(rmh_ctx *ctx, const double *u, const double *du_ho, double dt, double *du,
+                    const double *x_base, double a, double b, double dt_rk, double *y_out);
+
+/* Stopwatch buckets of TimingData (remhos_tools.hpp:52-64; printed by
+ * AdvectionOperator::PrintTimingData, remhos.cpp:1918-1966): seconds in
+ * t[0]=RHS (K u), t[1]=L2inv (mass solve), t[2]=LO, t[3]=FCT since the last reset, measured
+ * with HIP events on the ctx stream.  RHS and L2inv run in one kernel here, so t[0] holds the
+ * fused HO kernel and t[1] is 0. Synchronises the stream. */
+int rmh_timers(rmh_ctx *ctx, double t[4]);
+int rmh_reset_timers(rmh_ctx *ctx);
+/* enable/disable event timing (off by default: events between kernels cost launch gaps) */
+int rmh_enable_timers(rmh_ctx *ctx, int on);
+
+/* Diagnostics: max PCG iterations of the last rmh_ho_apply (synchronises). */
+int rmh_last_cg_iters(rmh_ctx *ctx, int *max_iters);
+/* Local mass solve controls (DGMassInverse::SetRelTol/SetAbsTol/SetMaxIter, remhos_ho.cpp:79-80).
+ * Default: rel_tol 1e-14, abs_tol 0, max_iter 100 -- see DESIGN.md for why this is tighter than
+ * the reference's abs 1e-8. */
+int rmh_set_mass_tol(rmh_ctx *ctx, double rel_tol, double abs_tol, int max_iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMH_H */

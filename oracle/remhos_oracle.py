@@ -677,8 +677,35 @@ class Remhos:
         rhs = self.conv_apply(u) + self.face_apply(u)
         self.last_rhs = rhs
         if self.cfg.ho_solve == "exact":
+            return self.mass_solve_exact(rhs)
+        if self.cfg.ho_solve == "bernstein_lu":
             return np.linalg.solve(self.mass_matrices(), rhs[..., None])[..., 0]
         return self.mass_cg(rhs)
+
+    def _gl_basis(self):
+        """Gauss-Legendre nodal basis of the DG space: values at the quadrature points and the
+        1-D change of basis (u_gl = C1 u_bernstein per direction)."""
+        if getattr(self, "_gl", None) is None:
+            T = self.T
+            xg, _ = gauss_legendre_01(T.D)
+            C1, _ = bernstein(T.p, xg)  # C1[k, i] = Bernstein_i(x_gl[k])
+            Ci1 = np.linalg.inv(C1)
+            Lg, _ = lagrange(xg, T.xq)  # GL Lagrange basis at the quadrature points
+            PhiG = kron_list([Lg] * self.dim)
+            Ci = kron_list([Ci1] * self.dim)
+            self._gl = (PhiG, Ci)
+        return self._gl
+
+    def mass_solve_exact(self, rhs):
+        """Exact (dense Cholesky) element-local solve of M x = rhs, the semantics of
+        remhos_ho.cpp:90-118.  The factorisation is done in the Gauss-Legendre nodal basis,
+        where M is nearly diagonal, so that the result is accurate to cond(C)*eps instead of the
+        cond(M_bernstein)*eps of an LU in the Bernstein basis (matters for p >= 4)."""
+        PhiG, Ci = self._gl_basis()
+        Mg = np.einsum("qi,eq,qj->eij", PhiG, self.wdet, PhiG, optimize=True)
+        bg = rhs @ Ci  # b_g = Ci^T b_b
+        xg = np.linalg.solve(Mg, bg[..., None])[..., 0]
+        return xg @ Ci.T  # x_b = Ci x_g
 
     def mass_cg(self, rhs, abs_tol=1e-8, rel_tol=0.0, max_iter=100):
         """DGMassInverse semantics [MFEM]: Jacobi-PCG per element in the Gauss-Legendre nodal

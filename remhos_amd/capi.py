@@ -1,0 +1,202 @@
+"""ctypes binding of the C ABI in include/rmh.h (the drop-in boundary).
+
+Only plumbing lives here: every numeric operation is a HIP kernel inside librmh.so.
+The loader fails loudly when the extension is missing -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librmh.so")
+
+# every symbol include/rmh.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = [
+    "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
+    "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_ho_apply", "rmh_lumped_mass",
+    "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
+    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
+    "rmh_last_cg_iters", "rmh_set_mass_tol",
+]
+
+
+class RmhLayout(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int),
+        ("order", C.c_int),
+        ("mesh_order", C.c_int),
+        ("exec_mode", C.c_int),
+        ("ne_owned", C.c_int),
+        ("ne_ghost", C.c_int),
+        ("x0", C.c_void_p),
+        ("vel", C.c_void_p),
+        ("face_nbr", C.c_void_p),
+        ("stencil27", C.c_void_p),
+        ("subcell_vel", C.c_void_p),
+        ("device", C.c_int),
+    ]
+
+
+class RmhError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RmhError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  remhos_amd has no CPU fallback."
+        )
+    lib = C.CDLL(path)
+    p, d, i = C.c_void_p, C.c_double, C.c_int
+    lib.rmh_create.argtypes = [C.POINTER(RmhLayout), C.POINTER(p)]
+    lib.rmh_destroy.argtypes = [p]
+    lib.rmh_destroy.restype = None
+    lib.rmh_last_error.restype = C.c_char_p
+    lib.rmh_version.restype = C.c_char_p
+    lib.rmh_set_stream.argtypes = [p, p]
+    lib.rmh_setup.argtypes = [p, d]
+    lib.rmh_set_ghost_u.argtypes = [p, p]
+    lib.rmh_set_ghost_minmax.argtypes = [p, p, p]
+    lib.rmh_ho_apply.argtypes = [p, p, p]
+    lib.rmh_lumped_mass.argtypes = [p]
+    lib.rmh_lumped_mass.restype = p
+    lib.rmh_compute_lumped_mass.argtypes = [p, d, p]
+    lib.rmh_lo_massavg.argtypes = [p, p, p, d, p]
+    lib.rmh_lo_rdsubcell.argtypes = [p, p, p]
+    lib.rmh_elem_minmax.argtypes = [p, p, p, p]
+    lib.rmh_bounds.argtypes = [p, p, p, p, p]
+    lib.rmh_fct_clipscale.argtypes = [p, p, p, p, p, p, p, d, p]
+    lib.rmh_limit_fused.argtypes = [p, p, p, d, p, p, d, d, d, p]
+    lib.rmh_timers.argtypes = [p, C.POINTER(d * 4)]
+    lib.rmh_reset_timers.argtypes = [p]
+    lib.rmh_enable_timers.argtypes = [p, i]
+    lib.rmh_last_cg_iters.argtypes = [p, C.POINTER(i)]
+    lib.rmh_set_mass_tol.argtypes = [p, d, d, i]
+    return lib
+
+
+def _ptr(x):
+    """device pointer of a torch tensor / host pointer of a numpy array / raw int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+class Context:
+    """One rmh_ctx: thin, argument-checking wrapper.  Vector arguments are torch CUDA tensors
+    (or host numpy arrays when `lib` is the g++ emulation build used by the CPU tests)."""
+
+    def __init__(self, lib, *, order, exec_mode, x0, vel, face_nbr, stencil27, ne_ghost=0,
+                 subcell_vel=None, device=0, mesh_order=2):
+        import numpy as np
+
+        self.lib = lib
+        self._keep = []
+        ne = face_nbr.shape[0]
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        vel = np.ascontiguousarray(vel, dtype=np.float64)
+        face_nbr = np.ascontiguousarray(face_nbr, dtype=np.int32)
+        stencil27 = np.ascontiguousarray(stencil27, dtype=np.int32)
+        assert x0.shape == (ne, 3, 27) and vel.shape == (ne, 3, 27)
+        assert face_nbr.shape == (ne, 6) and stencil27.shape == (ne, 27)
+        L = RmhLayout()
+        L.dim, L.order, L.mesh_order, L.exec_mode = 3, order, mesh_order, exec_mode
+        L.ne_owned, L.ne_ghost = ne, ne_ghost
+        L.x0, L.vel = x0.ctypes.data, vel.ctypes.data
+        L.face_nbr, L.stencil27 = face_nbr.ctypes.data, stencil27.ctypes.data
+        if subcell_vel is not None:
+            subcell_vel = np.ascontiguousarray(subcell_vel, dtype=np.float64)
+            assert subcell_vel.shape == (ne, 3, (order + 1) ** 3)
+            L.subcell_vel = subcell_vel.ctypes.data
+        L.device = device
+        self.ne, self.order, self.ndof = ne, order, (order + 1) ** 3
+        h = C.c_void_p()
+        self._check(lib.rmh_create(C.byref(L), C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RmhError(f"rmh error {rc}: {self.lib.rmh_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rmh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.rmh_set_stream(self.h, stream_handle))
+
+    def setup(self, t):
+        self._check(self.lib.rmh_setup(self.h, float(t)))
+
+    def set_ghost_u(self, ug):
+        self._keep_ref("ug", ug)
+        self._check(self.lib.rmh_set_ghost_u(self.h, _ptr(ug)))
+
+    def set_ghost_minmax(self, gmin, gmax):
+        self._keep_ref("gmm", (gmin, gmax))
+        self._check(self.lib.rmh_set_ghost_minmax(self.h, _ptr(gmin), _ptr(gmax)))
+
+    def _keep_ref(self, key, obj):
+        self.__dict__["_ref_" + key] = obj
+
+    def ho_apply(self, u, du):
+        self._check(self.lib.rmh_ho_apply(self.h, _ptr(u), _ptr(du)))
+
+    def lumped_mass_ptr(self):
+        return self.lib.rmh_lumped_mass(self.h)
+
+    def compute_lumped_mass(self, t, m):
+        self._check(self.lib.rmh_compute_lumped_mass(self.h, float(t), _ptr(m)))
+
+    def lo_massavg(self, u, du_ho, dt, du_lo):
+        self._check(self.lib.rmh_lo_massavg(self.h, _ptr(u), _ptr(du_ho), float(dt), _ptr(du_lo)))
+
+    def lo_rdsubcell(self, u, du_lo):
+        self._check(self.lib.rmh_lo_rdsubcell(self.h, _ptr(u), _ptr(du_lo)))
+
+    def elem_minmax(self, u, xe_min, xe_max):
+        self._check(self.lib.rmh_elem_minmax(self.h, _ptr(u), _ptr(xe_min), _ptr(xe_max)))
+
+    def bounds(self, xe_min, xe_max, u_min, u_max):
+        self._check(self.lib.rmh_bounds(self.h, _ptr(xe_min), _ptr(xe_max), _ptr(u_min), _ptr(u_max)))
+
+    def fct_clipscale(self, u, m, du_ho, du_lo, u_min, u_max, dt, du):
+        self._check(self.lib.rmh_fct_clipscale(self.h, _ptr(u), _ptr(m), _ptr(du_ho), _ptr(du_lo), _ptr(u_min),
+                                               _ptr(u_max), float(dt), _ptr(du)))
+
+    def limit_fused(self, u, du_ho, dt, du=None, x_base=None, a=0.0, b=1.0, dt_rk=0.0, y_out=None):
+        self._check(self.lib.rmh_limit_fused(self.h, _ptr(u), _ptr(du_ho), float(dt), _ptr(du), _ptr(x_base),
+                                             float(a), float(b), float(dt_rk), _ptr(y_out)))
+
+    def enable_timers(self, on=True):
+        self._check(self.lib.rmh_enable_timers(self.h, 1 if on else 0))
+
+    def reset_timers(self):
+        self._check(self.lib.rmh_reset_timers(self.h))
+
+    def timers(self):
+        t = (C.c_double * 4)()
+        self._check(self.lib.rmh_timers(self.h, C.byref(t)))
+        return list(t)
+
+    def last_cg_iters(self):
+        n = C.c_int(0)
+        self._check(self.lib.rmh_last_cg_iters(self.h, C.byref(n)))
+        return n.value
+
+    def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
+        self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))

@@ -1,0 +1,404 @@
+// C ABI of the MI355X-native Remhos hot path: context, dispatch over the polynomial order,
+// HIP-event stopwatches.  See include/rmh.h for the contract of every entry point.
+#include "../../include/rmh.h"
+#include "rmh_kernels.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rmh;
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+   g_last_error = msg;
+   return code;
+}
+
+#define RMH_HIP(call)                                                                          \
+   do {                                                                                        \
+      hipError_t err_ = (call);                                                                \
+      if (err_ != hipSuccess)                                                                  \
+      {                                                                                        \
+         return fail(RMH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err_));        \
+      }                                                                                        \
+   } while (0)
+
+struct EventPair
+{
+   hipEvent_t a, b;
+};
+} // namespace
+
+struct rmh_ctx
+{
+   int p = 0, ne = 0, ng = 0, exec_mode = 0, device = 0;
+   int ndof = 0;
+   hipStream_t stream = nullptr;
+   double t = 0.0;
+   double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
+   double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
+   int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
+   const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
+   double rel_tol = 1e-14, abs_tol = 0.0;
+   int max_iter = 100;
+   bool ho_done = false;
+   // stopwatches (TimingData, remhos_tools.hpp:52-64)
+   bool timers_on = false;
+   double tacc[4] = {0, 0, 0, 0};
+   std::vector<EventPair> pending[4];
+   std::vector<EventPair> pool;
+};
+
+namespace
+{
+
+int timer_begin(rmh_ctx *c, int bucket, EventPair &ep)
+{
+   if (!c->timers_on) { return 0; }
+   if (c->pool.empty())
+   {
+      RMH_HIP(hipEventCreate(&ep.a));
+      RMH_HIP(hipEventCreate(&ep.b));
+   }
+   else
+   {
+      ep = c->pool.back();
+      c->pool.pop_back();
+   }
+   RMH_HIP(hipEventRecord(ep.a, c->stream));
+   (void)bucket;
+   return 0;
+}
+
+int timer_end(rmh_ctx *c, int bucket, EventPair &ep)
+{
+   if (!c->timers_on) { return 0; }
+   RMH_HIP(hipEventRecord(ep.b, c->stream));
+   c->pending[bucket].push_back(ep);
+   return 0;
+}
+
+int timers_resolve(rmh_ctx *c)
+{
+   RMH_HIP(hipStreamSynchronize(c->stream));
+   for (int b = 0; b < 4; b++)
+   {
+      for (auto &ep : c->pending[b])
+      {
+         float ms = 0.f;
+         RMH_HIP(hipEventElapsedTime(&ms, ep.a, ep.b));
+         c->tacc[b] += 1e-3 * ms;
+         c->pool.push_back(ep);
+      }
+      c->pending[b].clear();
+   }
+   return 0;
+}
+
+template <typename T>
+int upload(T **dst, const T *src, size_t n)
+{
+   RMH_HIP(hipMalloc((void **)dst, n * sizeof(T)));
+   RMH_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+   return 0;
+}
+
+template <int P>
+int create_tables(rmh_ctx *c)
+{
+   std::vector<double> tab = make_tables<P>();
+   return upload(&c->d_tab, tab.data(), tab.size());
+}
+
+template <int P, int MODE>
+int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
+{
+   HoArgs a;
+   a.u = u;
+   a.u_ghost = c->u_ghost;
+   a.x0 = c->d_x0;
+   a.vel = c->d_vel;
+   a.face_nbr = c->d_nbr;
+   a.tab = c->d_tab;
+   a.du = du;
+   a.m = m;
+   a.xe_min = c->d_xe_min;
+   a.xe_max = c->d_xe_max;
+   a.cg_iters = c->d_cg;
+   a.ne_owned = c->ne;
+   a.t = t;
+   a.move = c->exec_mode == 1;
+   a.alpha = c->exec_mode == 1 ? 1.0 : -1.0;
+   a.upw = c->exec_mode == 1 ? 1.0 : -1.0;
+   a.rel2 = c->rel_tol * c->rel_tol;
+   a.abs2 = c->abs_tol * c->abs_tol;
+   a.max_iter = c->max_iter;
+   hipLaunchKernelGGL((ho_kernel<P, MODE>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, a);
+   RMH_HIP(hipGetLastError());
+   return 0;
+}
+
+#define RMH_DISPATCH(c, expr)                                                                  \
+   switch ((c)->p)                                                                             \
+   {                                                                                           \
+      case 1: { constexpr int P = 1; expr; break; }                                            \
+      case 2: { constexpr int P = 2; expr; break; }                                            \
+      case 3: { constexpr int P = 3; expr; break; }                                            \
+      case 4: { constexpr int P = 4; expr; break; }                                            \
+      case 5: { constexpr int P = 5; expr; break; }                                            \
+      case 6: { constexpr int P = 6; expr; break; }                                            \
+      default: return fail(RMH_ERR_INVALID, "unsupported order");                              \
+   }
+
+} // namespace
+
+extern "C" {
+
+const char *rmh_last_error(void) { return g_last_error.c_str(); }
+const char *rmh_version(void) { return "remhos_amd 0.1 (gfx950)"; }
+
+int rmh_create(const rmh_layout *L, rmh_ctx **out)
+{
+   if (!L || !out) { return fail(RMH_ERR_INVALID, "null argument"); }
+   *out = nullptr;
+   if (L->dim != 3) { return fail(RMH_ERR_INVALID, "only dim = 3 is implemented on the device"); }
+   if (L->order < 1 || L->order > 6) { return fail(RMH_ERR_INVALID, "order must be in 1..6"); }
+   if (L->mesh_order != 2) { return fail(RMH_ERR_INVALID, "mesh_order must be 2"); }
+   if (L->ne_owned <= 0 || L->ne_ghost < 0) { return fail(RMH_ERR_INVALID, "bad element counts"); }
+   if (!L->x0 || !L->vel || !L->face_nbr || !L->stencil27) { return fail(RMH_ERR_INVALID, "null mesh array"); }
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+   {
+      return fail(RMH_ERR_NO_DEVICE, "no HIP device: the remhos_amd hot path has no CPU fallback");
+   }
+   if (L->device < 0 || L->device >= ndev) { return fail(RMH_ERR_INVALID, "bad device ordinal"); }
+   RMH_HIP(hipSetDevice(L->device));
+   rmh_ctx *c = new rmh_ctx;
+   c->p = L->order;
+   c->ne = L->ne_owned;
+   c->ng = L->ne_ghost;
+   c->exec_mode = L->exec_mode;
+   c->device = L->device;
+   c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
+   const size_t ne = c->ne;
+   int rc = 0;
+   if ((rc = upload(&c->d_x0, L->x0, ne * 81))) { delete c; return rc; }
+   if ((rc = upload(&c->d_vel, L->vel, ne * 81))) { delete c; return rc; }
+   if ((rc = upload(&c->d_nbr, L->face_nbr, ne * 6))) { delete c; return rc; }
+   if ((rc = upload(&c->d_st27, L->stencil27, ne * 27))) { delete c; return rc; }
+   if (L->subcell_vel)
+   {
+      if ((rc = upload(&c->d_subvel, L->subcell_vel, ne * 3 * c->ndof))) { delete c; return rc; }
+   }
+   RMH_DISPATCH(c, rc = create_tables<P>(c));
+   if (rc) { delete c; return rc; }
+   RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_cg, sizeof(int)));
+   RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
+   *out = c;
+   return RMH_OK;
+}
+
+void rmh_destroy(rmh_ctx *c)
+{
+   if (!c) { return; }
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_m, c->d_xe_min, c->d_xe_max, c->d_nbr, c->d_st27, c->d_cg};
+   for (void *b : bufs) { (void)hipFree(b); }
+   for (int b = 0; b < 4; b++)
+   {
+      for (auto &ep : c->pending[b]) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+   }
+   for (auto &ep : c->pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+   delete c;
+}
+
+int rmh_set_stream(rmh_ctx *c, void *s)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->stream = (hipStream_t)s;
+   return RMH_OK;
+}
+
+int rmh_setup(rmh_ctx *c, double t)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->t = t;
+   c->ho_done = false;
+   return RMH_OK;
+}
+
+int rmh_set_ghost_u(rmh_ctx *c, const double *ug)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->u_ghost = ug;
+   return RMH_OK;
+}
+
+int rmh_set_ghost_minmax(rmh_ctx *c, const double *gmin, const double *gmax)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->gh_min = gmin;
+   c->gh_max = gmax;
+   return RMH_OK;
+}
+
+int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
+{
+   if (!c || !u || !du) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
+   EventPair ep;
+   int rc = timer_begin(c, 0, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, rc = (launch_ho<P, 0>(c, u, du, c->d_m, c->t)));
+   if (rc) { return rc; }
+   rc = timer_end(c, 0, ep);
+   c->ho_done = true;
+   return rc;
+}
+
+const double *rmh_lumped_mass(rmh_ctx *c) { return c ? c->d_m : nullptr; }
+
+int rmh_compute_lumped_mass(rmh_ctx *c, double t, double *m)
+{
+   if (!c || !m) { return fail(RMH_ERR_INVALID, "null argument"); }
+   int rc = 0;
+   RMH_DISPATCH(c, rc = (launch_ho<P, 1>(c, nullptr, nullptr, m, t)));
+   return rc;
+}
+
+int rmh_lo_massavg(rmh_ctx *c, const double *u, const double *du_ho, double dt, double *du_lo)
+{
+   if (!c || !u || !du_ho || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_lo_massavg needs the lumped mass of rmh_ho_apply"); }
+   EventPair ep;
+   int rc = timer_begin(c, 2, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((lo_massavg_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
+                                      du_ho, (const double *)c->d_m, dt, du_lo));
+   RMH_HIP(hipGetLastError());
+   return timer_end(c, 2, ep);
+}
+
+int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
+{
+   (void)c; (void)u; (void)du_lo;
+   return fail(RMH_ERR_INVALID, "rmh_lo_rdsubcell: subcell residual distribution is not implemented yet");
+}
+
+int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)
+{
+   if (!c || !u || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
+                                      xe_min, xe_max));
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u_min, double *u_max)
+{
+   if (!c || !xe_min || !xe_max || !u_min || !u_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
+                                      (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, u_min,
+                                      u_max));
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_fct_clipscale(rmh_ctx *c, const double *u, const double *m, const double *du_ho, const double *du_lo,
+                      const double *u_min, const double *u_max, double dt, double *du)
+{
+   if (!c || !u || !m || !du_ho || !du_lo || !u_min || !u_max || !du)
+   {
+      return fail(RMH_ERR_INVALID, "null argument");
+   }
+   EventPair ep;
+   int rc = timer_begin(c, 3, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((fct_clipscale_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u, m,
+                                      du_ho, du_lo, u_min, u_max, dt, du));
+   RMH_HIP(hipGetLastError());
+   return timer_end(c, 3, ep);
+}
+
+int rmh_limit_fused(rmh_ctx *c, const double *u, const double *du_ho, double dt, double *du, const double *x_base,
+                    double a, double b, double dt_rk, double *y_out)
+{
+   if (!c || !u || !du_ho || (!du && !y_out)) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_limit_fused must follow rmh_ho_apply on the same u"); }
+   if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
+   LimitArgs la;
+   la.u = u;
+   la.du_ho = du_ho;
+   la.m = c->d_m;
+   la.stencil27 = c->d_st27;
+   la.xe_min = c->d_xe_min;
+   la.xe_max = c->d_xe_max;
+   la.gh_min = c->gh_min;
+   la.gh_max = c->gh_max;
+   la.ne_owned = c->ne;
+   la.dt = dt;
+   la.du = du;
+   la.x_base = x_base;
+   la.a = a;
+   la.b = b;
+   la.dt_rk = dt_rk;
+   la.y_out = y_out;
+   EventPair ep;
+   int rc = timer_begin(c, 3, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, la));
+   RMH_HIP(hipGetLastError());
+   return timer_end(c, 3, ep);
+}
+
+int rmh_enable_timers(rmh_ctx *c, int on)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->timers_on = on != 0;
+   return RMH_OK;
+}
+
+int rmh_reset_timers(rmh_ctx *c)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   int rc = timers_resolve(c);
+   for (int b = 0; b < 4; b++) { c->tacc[b] = 0.0; }
+   return rc;
+}
+
+int rmh_timers(rmh_ctx *c, double t[4])
+{
+   if (!c || !t) { return fail(RMH_ERR_INVALID, "null argument"); }
+   int rc = timers_resolve(c);
+   for (int b = 0; b < 4; b++) { t[b] = c->tacc[b]; }
+   return rc;
+}
+
+int rmh_last_cg_iters(rmh_ctx *c, int *max_iters)
+{
+   if (!c || !max_iters) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_HIP(hipStreamSynchronize(c->stream));
+   RMH_HIP(hipMemcpy(max_iters, c->d_cg, sizeof(int), hipMemcpyDeviceToHost));
+   RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
+   return RMH_OK;
+}
+
+int rmh_set_mass_tol(rmh_ctx *c, double rel_tol, double abs_tol, int max_iter)
+{
+   if (!c || rel_tol < 0 || abs_tol < 0 || max_iter < 1) { return fail(RMH_ERR_INVALID, "bad tolerance"); }
+   c->rel_tol = rel_tol;
+   c->abs_tol = abs_tol;
+   c->max_iter = max_iter;
+   return RMH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,189 @@
+// Host-side 1-D basis / quadrature tables for the hot path.
+//
+// MFEM supplies these to the reference through DofToQuad / IntRules;
+// here they are generated directly:
+//   * Gauss-Legendre rule with Q = p + 3 points on [0,1]  (order 2p + mo*dim - 1 with mo = 2,
+//     dim = 3: MassIntegrator / ConvectionIntegrator / DGTraceIntegrator rules);
+//   * Bernstein basis of degree p (DG_FECollection(order, dim, BasisType::Positive),
+//     remhos.cpp:588-590) and its derivative at those points;
+//   * quadratic Lagrange basis on {0, 1/2, 1} (Gauss-Lobatto mesh nodes of order 2,
+//     remhos.cpp:513-527);
+//   * the Gauss-Legendre nodal basis used by the element-local mass solve
+//     (DGMassInverse(fes, BasisType::GaussLegendre), remhos_ho.cpp:79) and the 1-D change of
+//     basis Bernstein <-> Gauss-Legendre nodal.
+#pragma once
+#include <cmath>
+#include <vector>
+
+namespace rmh
+{
+
+// table layout shared by host and device code (offsets in doubles)
+template <int P>
+struct TabLayout
+{
+   static constexpr int D = P + 1, Q = P + 3;
+   static constexpr int oB = 0;             // B[q*D+i]   Bernstein values
+   static constexpr int oG = oB + Q * D;    // G[q*D+i]   Bernstein derivatives
+   static constexpr int oL = oG + Q * D;    // L[q*3+a]   mesh Lagrange values
+   static constexpr int odL = oL + Q * 3;   // dL[q*3+a]  mesh Lagrange derivatives
+   static constexpr int oW = odL + Q * 3;   // w[q]       quadrature weights
+   static constexpr int oBg = oW + Q;       // Bg[q*D+k]  GL nodal basis at quadrature points
+   static constexpr int oBg2 = oBg + Q * D; // Bg2 = Bg^2 (Jacobi diagonal)
+   static constexpr int oCi = oBg2 + Q * D; // Ci[i*D+k]  inverse of C[k][i] = Bernstein_i(gl node k)
+   static constexpr int N = oCi + D * D;
+};
+
+inline void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
+{
+   x.assign(n, 0.0);
+   w.assign(n, 0.0);
+   for (int i = 0; i < n; i++)
+   {
+      // Newton iteration on P_n, start from the Chebyshev guess
+      double z = std::cos(M_PI * (i + 0.75) / (n + 0.5));
+      double pp = 0.0;
+      for (int it = 0; it < 100; it++)
+      {
+         double p1 = 1.0, p2 = 0.0;
+         for (int j = 0; j < n; j++)
+         {
+            const double p3 = p2;
+            p2 = p1;
+            p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0);
+         }
+         pp = n * (z * p1 - p2) / (z * z - 1.0);
+         const double dz = p1 / pp;
+         z -= dz;
+         if (std::fabs(dz) < 1e-16) { break; }
+      }
+      // ascending order on [0,1]
+      x[n - 1 - i] = 0.5 * (1.0 + z);
+      w[n - 1 - i] = 1.0 / ((1.0 - z * z) * pp * pp);
+   }
+}
+
+inline double binom(int n, int k)
+{
+   double r = 1.0;
+   for (int i = 1; i <= k; i++) { r = r * (n - k + i) / i; }
+   return r;
+}
+
+inline double bernstein(int p, int i, double t)
+{
+   if (i < 0 || i > p) { return 0.0; }
+   return binom(p, i) * std::pow(t, i) * std::pow(1.0 - t, p - i);
+}
+
+inline double dbernstein(int p, int i, double t)
+{
+   if (p == 0) { return 0.0; }
+   return p * (bernstein(p - 1, i - 1, t) - bernstein(p - 1, i, t));
+}
+
+inline void lagrange(const std::vector<double> &nodes, double t, std::vector<double> &L,
+                     std::vector<double> &dL)
+{
+   const int n = (int)nodes.size();
+   L.assign(n, 1.0);
+   dL.assign(n, 0.0);
+   for (int j = 0; j < n; j++)
+   {
+      for (int m = 0; m < n; m++)
+      {
+         if (m != j) { L[j] *= (t - nodes[m]) / (nodes[j] - nodes[m]); }
+      }
+      for (int k = 0; k < n; k++)
+      {
+         if (k == j) { continue; }
+         double term = 1.0 / (nodes[j] - nodes[k]);
+         for (int m = 0; m < n; m++)
+         {
+            if (m != j && m != k) { term *= (t - nodes[m]) / (nodes[j] - nodes[m]); }
+         }
+         dL[j] += term;
+      }
+   }
+}
+
+// dense inverse by Gauss-Jordan with partial pivoting (tiny D x D matrices)
+inline void invert(int n, std::vector<double> &a)
+{
+   std::vector<double> inv(n * n, 0.0);
+   for (int i = 0; i < n; i++) { inv[i * n + i] = 1.0; }
+   for (int c = 0; c < n; c++)
+   {
+      int piv = c;
+      for (int r = c + 1; r < n; r++)
+      {
+         if (std::fabs(a[r * n + c]) > std::fabs(a[piv * n + c])) { piv = r; }
+      }
+      for (int k = 0; k < n; k++)
+      {
+         std::swap(a[c * n + k], a[piv * n + k]);
+         std::swap(inv[c * n + k], inv[piv * n + k]);
+      }
+      const double d = 1.0 / a[c * n + c];
+      for (int k = 0; k < n; k++) { a[c * n + k] *= d; inv[c * n + k] *= d; }
+      for (int r = 0; r < n; r++)
+      {
+         if (r == c) { continue; }
+         const double f = a[r * n + c];
+         for (int k = 0; k < n; k++)
+         {
+            a[r * n + k] -= f * a[c * n + k];
+            inv[r * n + k] -= f * inv[c * n + k];
+         }
+      }
+   }
+   a = inv;
+}
+
+template <int P>
+inline std::vector<double> make_tables()
+{
+   using T = TabLayout<P>;
+   constexpr int D = T::D, Q = T::Q;
+   std::vector<double> tab(T::N, 0.0);
+   std::vector<double> xq, wq, xg, wg;
+   gauss_legendre_01(Q, xq, wq);
+   gauss_legendre_01(D, xg, wg);
+   const std::vector<double> mesh_nodes = {0.0, 0.5, 1.0};
+   std::vector<double> L, dL;
+   for (int q = 0; q < Q; q++)
+   {
+      for (int i = 0; i < D; i++)
+      {
+         tab[T::oB + q * D + i] = bernstein(P, i, xq[q]);
+         tab[T::oG + q * D + i] = dbernstein(P, i, xq[q]);
+      }
+      lagrange(mesh_nodes, xq[q], L, dL);
+      for (int a = 0; a < 3; a++)
+      {
+         tab[T::oL + q * 3 + a] = L[a];
+         tab[T::odL + q * 3 + a] = dL[a];
+      }
+      tab[T::oW + q] = wq[q];
+      lagrange(xg, xq[q], L, dL);
+      for (int k = 0; k < D; k++)
+      {
+         tab[T::oBg + q * D + k] = L[k];
+         tab[T::oBg2 + q * D + k] = L[k] * L[k];
+      }
+   }
+   // C[k][i] = Bernstein_i(x_gl[k]);  Ci = C^-1 stored as Ci[i*D+k]
+   std::vector<double> C(D * D);
+   for (int k = 0; k < D; k++)
+   {
+      for (int i = 0; i < D; i++) { C[k * D + i] = bernstein(P, i, xg[k]); }
+   }
+   invert(D, C);
+   for (int i = 0; i < D; i++)
+   {
+      for (int k = 0; k < D; k++) { tab[T::oCi + i * D + k] = C[i * D + k]; }
+   }
+   return tab;
+}
+
+} // namespace rmh

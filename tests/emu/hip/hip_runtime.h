@@ -1,0 +1,108 @@
+// TEST INFRASTRUCTURE ONLY -- a minimal host emulation of the HIP constructs used by
+// remhos_amd/csrc so that the kernel sources can be compiled with g++ and run under
+// sanitizers / against the oracle on a machine without a GPU (tests/test_emu_cpu.py).
+// The product never includes this file: hipcc resolves <hip/hip_runtime.h> to ROCm's header.
+// A workgroup is emulated by blockDim.x OS threads that meet at a std::barrier for
+// __syncthreads(); workgroups run one after another.
+#pragma once
+#include <algorithm>
+#include <barrier>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3
+{
+   unsigned x, y, z;
+   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+typedef void *hipStream_t;
+typedef struct { double t; } *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+
+namespace hipemu
+{
+inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+inline std::barrier<> *g_barrier = nullptr;
+inline unsigned long long g_xchg[1024];
+} // namespace hipemu
+
+#define threadIdx (hipemu::t_threadIdx)
+#define blockIdx (hipemu::t_blockIdx)
+#define blockDim (hipemu::t_blockDim)
+#define gridDim (hipemu::t_gridDim)
+
+inline void __syncthreads() { hipemu::g_barrier->arrive_and_wait(); }
+
+inline double __shfl_xor(double v, int off)
+{
+   const unsigned t = threadIdx.x;
+   std::memcpy(&hipemu::g_xchg[t], &v, 8);
+   __syncthreads();
+   double r;
+   std::memcpy(&r, &hipemu::g_xchg[t ^ (unsigned)off], 8);
+   __syncthreads();
+   return r;
+}
+
+inline int atomicMax(int *p, int v)
+{
+   // workgroups run sequentially and only one thread per workgroup calls this in the kernels
+   const int old = *p;
+   *p = std::max(old, v);
+   return old;
+}
+
+inline const char *hipGetErrorString(hipError_t) { return "hip emulation error"; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+inline hipError_t hipFree(void *p) { std::free(p); return 0; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new std::remove_pointer_t<hipEvent_t>; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+
+template <typename K, typename... Args>
+inline void hipemu_launch(K kernel, dim3 grid, dim3 block, Args... args)
+{
+   std::barrier<> bar(block.x);
+   hipemu::g_barrier = &bar;
+   std::vector<std::thread> pool;
+   for (unsigned t = 0; t < block.x; t++)
+   {
+      pool.emplace_back([=, &bar]()
+      {
+         hipemu::t_blockDim = block;
+         hipemu::t_gridDim = grid;
+         hipemu::t_threadIdx = dim3(t, 0, 0);
+         for (unsigned b = 0; b < grid.x; b++)
+         {
+            hipemu::t_blockIdx = dim3(b, 0, 0);
+            kernel(args...);
+            bar.arrive_and_wait();
+         }
+      });
+   }
+   for (auto &th : pool) { th.join(); }
+   hipemu::g_barrier = nullptr;
+}
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+   hipemu_launch(kernel, grid, block, __VA_ARGS__)

@@ -1,0 +1,22 @@
+"""Shared test helpers: turn an oracle case into the arrays rmh_create() takes."""
+import numpy as np
+
+
+def layout_from_oracle(r):
+    """r: oracle.remhos_oracle.Remhos (3-D).  Returns x0, vel, face_nbr, stencil27 in the
+    C-ABI layouts of include/rmh.h."""
+    lat = r.lat
+    assert lat.dim == 3
+    x0 = np.ascontiguousarray(r.X0.transpose(0, 2, 1))
+    v = r.V if r.exec_mode == 1 else r.vel(r.X0)
+    vel = np.ascontiguousarray(v.transpose(0, 2, 1))
+    nbr = r.nbr.astype(np.int32)
+    st = np.stack(
+        [lat.shifted((ox, oy, oz)) for oz in (-1, 0, 1) for oy in (-1, 0, 1) for ox in (-1, 0, 1)], axis=1
+    ).astype(np.int32)
+    return x0, vel, nbr, st
+
+
+def perturbed(u):
+    """make the field generic (keeps it deterministic: no RNG)"""
+    return u + 0.01 * np.sin(np.arange(u.size, dtype=np.float64).reshape(u.shape))

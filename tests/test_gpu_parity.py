@@ -1,0 +1,141 @@
+"""GPU parity: every C-ABI entry point against the oracle on the same inputs.
+
+Tolerances (FP64): the HIP path and the oracle evaluate the same polynomials with different
+summation orders, and the oracle's dense LU solve of the Bernstein mass matrix carries
+cond(M)*eps ~ 1e-12 at p = 3 (more at p = 6), so vectors are compared at REL relative to the
+vector's max norm; bounds (pure min/max) must be bit-exact.
+"""
+import numpy as np
+import pytest
+
+from oracle.remhos_oracle import Config, Remhos
+from tests.helpers import layout_from_oracle, perturbed
+
+pytestmark = pytest.mark.gpu
+
+REL = {1: 1e-12, 2: 1e-12, 3: 1e-11, 4: 1e-11, 5: 1e-10, 6: 1e-9}
+
+CASES = [
+    # mesh, rs, order, problem, t
+    ("cube01_hex", 1, 1, 10, 0.3),
+    ("cube01_hex", 1, 2, 10, 0.3),
+    ("cube01_hex", 1, 3, 10, 0.5),
+    ("cube01_hex", 2, 3, 10, 1.0),
+    ("periodic-cube", 1, 3, 10, 0.4),
+    ("periodic-cube", 1, 2, 0, 0.0),
+    ("periodic-cube", 0, 3, 0, 0.0),
+    ("cube01_hex", 1, 4, 10, 0.3),
+    ("cube01_hex", 0, 5, 10, 0.3),
+    ("cube01_hex", 0, 6, 10, 0.3),
+    ("periodic-cube", 0, 6, 10, 0.7),
+]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    from remhos_amd.capi import load_library
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch, load_library()
+
+
+def _relerr(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,t", CASES, ids=[f"{c[0]}-rs{c[1]}-o{c[2]}-p{c[3]}" for c in CASES])
+def test_stage_parity(gpu, mesh, rs, p, prob, t):
+    torch, lib = gpu
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    u_h = perturbed(r.u)
+    keep = {}
+    r.stage(u_h, t, cfg.dt, keep)
+
+    dev = torch.device("cuda:0")
+    u = torch.from_numpy(u_h).to(dev)
+    new = lambda: torch.empty_like(u)
+    du_ho, du_lo, du, du2, m, umin, umax = (new() for _ in range(7))
+    xmn = torch.empty(r.lat.ne, dtype=torch.float64, device=dev)
+    xmx = torch.empty_like(xmn)
+
+    ctx.setup(t)
+    ctx.ho_apply(u, du_ho)
+    ctx.compute_lumped_mass(t, m)
+    ctx.lo_massavg(u, du_ho, cfg.dt, du_lo)
+    ctx.elem_minmax(u, xmn, xmx)
+    ctx.bounds(xmn, xmx, umin, umax)
+    ctx.fct_clipscale(u, m, du_ho, du_lo, umin, umax, cfg.dt, du)
+    ctx.limit_fused(u, du_ho, cfg.dt, du=du2)
+    torch.cuda.synchronize()
+    iters = ctx.last_cg_iters()
+    assert 0 < iters < 100
+    print(f"cg iters {iters}", {k: _relerr(v.cpu().numpy(), keep[n]) for k, v, n in (("m", m, "m"), ("du_ho", du_ho, "du_ho"), ("du", du, "du"))})
+
+    tol = REL[p]
+    assert _relerr(m.cpu().numpy(), keep["m"]) < 1e-13
+    assert _relerr(du_ho.cpu().numpy(), keep["du_ho"]) < tol
+    assert _relerr(du_lo.cpu().numpy(), keep["du_lo"]) < tol
+    # bounds are pure min/max of the same doubles: bit-exact
+    assert np.array_equal(umin.cpu().numpy(), keep["umin"])
+    assert np.array_equal(umax.cpu().numpy(), keep["umax"])
+    assert _relerr(du.cpu().numpy(), keep["du"]) < tol
+    assert _relerr(du2.cpu().numpy(), keep["du"]) < tol
+    # the fused and the granular limiter paths agree with each other to round-off
+    assert _relerr(du2.cpu().numpy(), du.cpu().numpy()) < 1e-12
+    # lumped mass left behind by the HO kernel == standalone evaluation
+    import ctypes
+
+    mptr = ctx.lumped_mass_ptr()
+    m2 = torch.empty_like(m)
+    assert mptr
+    ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(
+        ctypes.c_void_p(m2.data_ptr()), ctypes.c_void_p(mptr), ctypes.c_size_t(m.numel() * 8), 3
+    )
+    torch.cuda.synchronize()
+    assert torch.equal(m2, m)
+    ctx.close()
+
+
+def test_rk_update_fused(gpu):
+    """y_out = a*x + b*(u + dt_rk*du) epilogue of rmh_limit_fused (RK3SSPSolver::Step)."""
+    torch, lib = gpu
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh="cube01_hex", rs=1, order=3, problem=10, dt=0.01, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=3, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    dev = torch.device("cuda:0")
+    u = torch.from_numpy(perturbed(r.u)).to(dev)
+    xb = torch.from_numpy(r.u.copy()).to(dev)
+    du_ho, du, y = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    ctx.setup(0.25)
+    ctx.ho_apply(u, du_ho)
+    ctx.limit_fused(u, du_ho, cfg.dt, du=du, x_base=xb, a=0.75, b=0.25, dt_rk=cfg.dt, y_out=y)
+    torch.cuda.synchronize()
+    ref = 0.75 * xb + 0.25 * (u + cfg.dt * du)
+    assert float((y - ref).abs().max()) < 1e-15
+    ctx.close()
+
+
+def test_errors_are_reported(gpu):
+    torch, lib = gpu
+    from remhos_amd.capi import Context, RmhError
+
+    cfg = Config(mesh="cube01_hex", rs=0, order=2, problem=10, dt=0.01, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    with pytest.raises(RmhError):
+        Context(lib, order=9, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    ctx = Context(lib, order=2, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    u = torch.zeros(r.u.shape, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(RmhError):  # limiter before HO: call order violated
+        ctx.limit_fused(u, u, 0.1, du=torch.empty_like(u))
+    ctx.close()
