@@ -1,0 +1,246 @@
+// C++ host side of the MI355X-native Remhos hot path.
+//
+// The abstract classes HOSolver / LOSolver / FCTSolver keep the reference's virtual signatures
+// (remhos_ho.hpp:29-42, remhos_lo.hpp:28-44, remhos_fct.hpp:31-90) so that the concrete
+// classes below can be handed to an AdvectionOperator exactly like the reference's
+// LocalInverseHOSolver / MassBasedAvg / PAResidualDistributionSubcell / ClipScaleSolver
+// (remhos.cpp:912-925, 927-995, 1083-1113).  They own nothing numeric: every Calc* call
+// forwards to the C ABI in include/rmh.h, i.e. to a HIP kernel.
+//
+// Stand-ins for the MFEM types that appear in those signatures:
+//   Vector              device-resident vector (mfem::Vector with a valid device pointer)
+//   ParGridFunction     = Vector (DG L-vector == E-vector, remhos_lo.cpp:274)
+//   SpaceLayout         what the solvers need from ParFiniteElementSpace: sizes + the rmh_ctx
+// Errors abort like MFEM_VERIFY / MFEM_ABORT do (remhos_ho.cpp:86, remhos_fct.cpp:465).
+#pragma once
+#include "../rmh.h"
+
+#include <cstddef>
+
+namespace remhos
+{
+
+typedef double real_t;
+
+[[noreturn]] void rmh_abort(const char *msg, const char *file, int line);
+#define RMH_VERIFY(cond, msg)                                   \
+   do {                                                         \
+      if (!(cond)) { ::remhos::rmh_abort(msg, __FILE__, __LINE__); } \
+   } while (0)
+
+// Device vector.  Read()/Write()/ReadWrite() return DEVICE pointers (mfem::Vector::Read() with a
+// device configured, remhos.cpp:1679-1680); there is no implicit host mirror.
+class Vector
+{
+   double *data = nullptr;
+   int size = 0;
+   bool own = false;
+
+public:
+   Vector() {}
+   explicit Vector(int n);
+   Vector(double *device_ptr, int n) : data(device_ptr), size(n), own(false) {}
+   Vector(const Vector &o);
+   Vector &operator=(const Vector &o);
+   Vector &operator=(double value);
+   ~Vector();
+   void SetSize(int n);
+   int Size() const { return size; }
+   const double *Read() const { return data; }
+   double *Write() { return data; }
+   double *ReadWrite() { return data; }
+   void CopyFromHost(const double *h);
+   void CopyToHost(double *h) const;
+};
+typedef Vector ParGridFunction;
+
+// y = a*x + b*y' helpers used by the RK solver (device axpys)
+void add(const Vector &x, double a, const Vector &y, Vector &z);           // z = x + a y
+void add(double a, const Vector &x, double b, const Vector &y, Vector &z); // z = a x + b y
+
+class SpaceLayout
+{
+   rmh_ctx *ctx;
+   int ne, ndof;
+   long long global_vsize;
+
+public:
+   SpaceLayout(rmh_ctx *c, int ne_, int ndof_, long long gvs) : ctx(c), ne(ne_), ndof(ndof_), global_vsize(gvs) {}
+   rmh_ctx *Ctx() const { return ctx; }
+   int GetNE() const { return ne; }
+   int GetNDofs() const { return ndof; }
+   int GetVSize() const { return ne * ndof; }
+   long long GlobalVSize() const { return global_vsize; }
+};
+typedef SpaceLayout ParFiniteElementSpace;
+
+// remhos_tools.hpp:52-64.  The stopwatches are HIP-event buckets inside the rmh_ctx; Update()
+// pulls the accumulated seconds.
+struct TimingData
+{
+   double sw_rhs = 0, sw_L2inv = 0, sw_LO = 0, sw_FCT = 0;
+   void Update(rmh_ctx *ctx);
+};
+
+// High-Order Solver (remhos_ho.hpp:29-42)
+class HOSolver
+{
+protected:
+   ParFiniteElementSpace &pfes;
+
+public:
+   HOSolver(ParFiniteElementSpace &space) : pfes(space) {}
+   virtual ~HOSolver() {}
+   virtual void CalcHOSolution(const Vector &u, Vector &du) const = 0;
+   TimingData *timer = nullptr;
+};
+
+// remhos_ho.hpp:56-68, PA branch remhos_ho.cpp:119-128
+class LocalInverseHOSolver : public HOSolver
+{
+public:
+   LocalInverseHOSolver(ParFiniteElementSpace &space) : HOSolver(space) {}
+   void CalcHOSolution(const Vector &u, Vector &du) const override;
+};
+
+// Low-Order Solver (remhos_lo.hpp:28-44)
+class LOSolver
+{
+protected:
+   ParFiniteElementSpace &pfes;
+   real_t dt = -1.0; // usually not known at creation, updated later.
+
+public:
+   LOSolver(ParFiniteElementSpace &space) : pfes(space) {}
+   virtual ~LOSolver() {}
+   virtual void UpdateTimeStep(real_t dt_new) { dt = dt_new; }
+   virtual void CalcLOSolution(const Vector &u, Vector &du) const = 0;
+   TimingData *timer = nullptr;
+};
+
+// remhos_lo.hpp:87-109
+class MassBasedAvg : public LOSolver
+{
+protected:
+   HOSolver &ho_solver;
+   // Temporary HO solution, used only in the next call to CalcLOSolution().
+   mutable const Vector *du_HO = nullptr;
+
+public:
+   MassBasedAvg(ParFiniteElementSpace &space, HOSolver &hos) : LOSolver(space), ho_solver(hos) {}
+   void SetHOSolution(Vector &du) { du_HO = &du; }
+   void CalcLOSolution(const Vector &u, Vector &du) const override;
+};
+
+// remhos_lo.hpp:142-171
+class PAResidualDistributionSubcell : public LOSolver
+{
+public:
+   PAResidualDistributionSubcell(ParFiniteElementSpace &space) : LOSolver(space) {}
+   void CalcLOSolution(const Vector &u, Vector &du) const override;
+};
+
+// Monotone, High-order, Conservative Solver (remhos_fct.hpp:31-90)
+class FCTSolver
+{
+protected:
+   ParFiniteElementSpace &pfes;
+   real_t dt;
+
+public:
+   FCTSolver(ParFiniteElementSpace &space, real_t dt_) : pfes(space), dt(dt_) {}
+   virtual ~FCTSolver() {}
+   virtual void UpdateTimeStep(real_t dt_new) { dt = dt_new; }
+   // Calculate du that satisfies the following:
+   // bounds preservation: u_min_i <= u_i + dt du_i <= u_max_i,
+   // conservation:        sum m_i (u_i + dt du_ho_i) = sum m_i (u_i + dt du_i).
+   virtual void CalcFCTSolution(const ParGridFunction &u, const Vector &m, const Vector &du_ho,
+                                const Vector &du_lo, const Vector &u_min, const Vector &u_max,
+                                Vector &du) const = 0;
+   TimingData *timer = nullptr;
+   bool verify_bounds = false;
+};
+
+// remhos_fct.hpp:137-155
+class ClipScaleSolver : public FCTSolver
+{
+public:
+   ClipScaleSolver(ParFiniteElementSpace &space, real_t dt_) : FCTSolver(space, dt_) {}
+   void CalcFCTSolution(const ParGridFunction &u, const Vector &m, const Vector &du_ho, const Vector &du_lo,
+                        const Vector &u_min, const Vector &u_max, Vector &du) const override;
+};
+
+// Local bounds (remhos_tools.hpp:114-189): element extrema and overlap bounds
+class DofInfo
+{
+   ParFiniteElementSpace &pfes;
+
+public:
+   Vector xe_min, xe_max, xi_min, xi_max;
+   DofInfo(ParFiniteElementSpace &space);
+   void ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_max) const;
+   void ComputeBounds(const Vector &el_min, const Vector &el_max, Vector &dof_min, Vector &dof_max) const;
+};
+
+// remhos_solvers.hpp:25-63
+class LimitedTimeDependentOperator
+{
+protected:
+   real_t dt = 0.0, t = 0.0;
+   int height;
+
+public:
+   LimitedTimeDependentOperator(int n) : height(n) {}
+   virtual ~LimitedTimeDependentOperator() {}
+   int Height() const { return height; }
+   virtual void SetDt(real_t dt_) { dt = dt_; }
+   real_t GetDt() const { return dt; }
+   void SetTime(real_t t_) { t = t_; }
+   real_t GetTime() const { return t; }
+   virtual void MultUnlimited(const Vector &x, Vector &y) const = 0;
+   virtual void LimitMult(const Vector &x, Vector &y) const = 0;
+   virtual void Mult(const Vector &x, Vector &y) const
+   {
+      MultUnlimited(x, y);
+      LimitMult(x, y);
+   }
+};
+
+// The stage operator (remhos.cpp:115-198, 1596-1739, 1798-1916), single field u.
+class AdvectionOperator : public LimitedTimeDependentOperator
+{
+   ParFiniteElementSpace &pfes;
+   DofInfo &dofs;
+   HOSolver *ho_solver;
+   LOSolver *lo_solver;
+   FCTSolver *fct_solver;
+   mutable Vector lumpedM, du_HO, du_LO;
+   mutable TimingData timer;
+   const bool fused; // LimitMult through rmh_limit_fused (no du_LO / bounds vectors)
+
+public:
+   AdvectionOperator(ParFiniteElementSpace &space, DofInfo &dofs_, HOSolver *hos, LOSolver *los, FCTSolver *fct,
+                     bool fused_limiter);
+   void SetDt(real_t dt_) override
+   {
+      LimitedTimeDependentOperator::SetDt(dt_);
+      if (lo_solver) { lo_solver->UpdateTimeStep(dt_); }
+      if (fct_solver) { fct_solver->UpdateTimeStep(dt_); }
+   }
+   void MultUnlimited(const Vector &x, Vector &y) const override;
+   void LimitMult(const Vector &x, Vector &y) const override;
+   TimingData &Timer() const { return timer; }
+};
+
+// mfem::RK3SSPSolver (remhos.cpp:490; stage times t, t+dt, t+dt/2: SURVEY A.6)
+class RK3SSPSolver
+{
+   LimitedTimeDependentOperator *f = nullptr;
+   Vector y, k;
+
+public:
+   void Init(LimitedTimeDependentOperator &op);
+   void Step(Vector &x, real_t &t, real_t &dt);
+};
+
+} // namespace remhos

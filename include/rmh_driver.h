@@ -1,0 +1,77 @@
+/*
+ * rmh_driver.h -- C ABI of the host-side harness around the hot path: case setup on the
+ * reference's lattice meshes (what remhos() does before its time loop, remhos.cpp:442-584,
+ * 878-884) with a box partition standing in for ParMesh (remhos.cpp:459-463), and a
+ * single-GPU restatement of the time loop (remhos.cpp:1146-1330) + final report
+ * (remhos.cpp:1340-1436) driving the HOSolver / LOSolver / FCTSolver classes of
+ * include/remhos_amd/solvers.hpp.
+ *
+ * The rmhd_case_* functions are pure host code (also built into librmh_host.so for the CPU
+ * tests); rmhd_run needs the GPU.
+ */
+#ifndef RMH_DRIVER_H
+#define RMH_DRIVER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+   char mesh[32];     /* -m : "periodic-cube" | "cube01_hex" (data/ lattice meshes)             */
+   int rs;            /* -rs                                                                  */
+   int order;         /* -o                                                                   */
+   int problem;       /* -p  (0 translation transport, 10 Taylor-Green remap, ...)            */
+   double dt;         /* -dt (< 0: CFL rule remhos.cpp:538-553)                               */
+   double t_final;    /* -tf                                                                  */
+   int max_steps;     /* -ms (< 0: none)                                                      */
+   int lo_type;       /* -lo : 4 subcell RD, 5 mass-based average                             */
+   int fused;         /* 1: LimitMult through rmh_limit_fused, 0: the reference's call sequence */
+   int px, py, pz;    /* box partition of the element lattice                                 */
+   int rank;          /* which block this process owns                                        */
+} rmhd_config;
+
+typedef struct {
+   int order, exec_mode, ndof, ne_owned, ne_ghost, n_peers;
+   long long ne_global;
+   int n[3], lo[3], nl[3];
+   double dt;
+   double bb_min[3], bb_max[3];
+} rmhd_case_info;
+
+typedef struct rmhd_case rmhd_case;
+
+/* returns NULL on error (message in rmhd_last_error) */
+rmhd_case *rmhd_case_create(const rmhd_config *cfg);
+void rmhd_case_destroy(rmhd_case *c);
+const char *rmhd_last_error(void);
+int rmhd_case_get_info(const rmhd_case *c, rmhd_case_info *info);
+const double *rmhd_case_x0(const rmhd_case *c);          /* [ne_owned][3][27] */
+const double *rmhd_case_vel(const rmhd_case *c);         /* [ne_owned][3][27] */
+const double *rmhd_case_u0(const rmhd_case *c);          /* [ne_owned][ndof]  */
+const double *rmhd_case_subcell_vel(const rmhd_case *c); /* [ne_owned][3][ndof] or NULL */
+const int *rmhd_case_face_nbr(const rmhd_case *c);       /* [ne_owned][6]  */
+const int *rmhd_case_stencil27(const rmhd_case *c);      /* [ne_owned][27] */
+const long long *rmhd_case_owned_gid(const rmhd_case *c);
+const long long *rmhd_case_ghost_gid(const rmhd_case *c);
+/* k-th neighbour rank of the halo exchange: owned elements it needs / ghost slots it fills */
+int rmhd_case_peer(const rmhd_case *c, int k, int *rank, int *nsend, const int **send_elems,
+                   int *nrecv, const int **recv_slots);
+
+typedef struct {
+   double final_mass, max_value, mass0, mass_loss; /* remhos.cpp:1423-1428 */
+   double dt, t_end;
+   int steps, stages;
+   long long global_dofs;
+   double t_rhs, t_inv, t_lo, t_fct, t_total; /* TimingData buckets, remhos.cpp:1928-1933 */
+   double fom_rhs, fom_inv, fom_lo, fom_fct, fom; /* remhos.cpp:1947-1951 (fom omits INV) */
+   double wall, fom_wall;                     /* whole stage loop, everything included    */
+   int cg_iters_max;
+} rmhd_result;
+
+/* remhos() on one GPU (px = py = pz = 1): setup, RK3-SSP loop, report.  0 on success. */
+int rmhd_run(const rmhd_config *cfg, rmhd_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

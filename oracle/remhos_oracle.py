@@ -530,6 +530,7 @@ class Remhos:
         nodes = lat.lattice_nodes()
         self.x0_nodes = nodes.copy()
         self.X0 = nodes[self.node_ids]  # (NE, nn, dim)
+        self.refine_steps = 0  # tests of single stages at high order set this to 2
         self.dt = cfg.dt
         if self.dt < 0.0:
             self.dt = self._cfl_dt()
@@ -703,9 +704,25 @@ class Remhos:
         cond(M_bernstein)*eps of an LU in the Bernstein basis (matters for p >= 4)."""
         PhiG, Ci = self._gl_basis()
         Mg = np.einsum("qi,eq,qj->eij", PhiG, self.wdet, PhiG, optimize=True)
-        bg = rhs @ Ci  # b_g = Ci^T b_b
-        xg = np.linalg.solve(Mg, bg[..., None])[..., 0]
-        return xg @ Ci.T  # x_b = Ci x_g
+
+        def solve(b):
+            bg = b @ Ci  # b_g = Ci^T b_b
+            xg = np.linalg.solve(Mg, bg[..., None])[..., 0]
+            return xg @ Ci.T  # x_b = Ci x_g
+
+        x = solve(rhs)
+        if self.refine_steps > 0:
+            # iterative refinement with the residual in extended precision: removes the
+            # cond(C)^dim * eps error of the basis change, so that the oracle is accurate to
+            # FP64 round-off in the Bernstein coefficients at every order
+            ld = np.longdouble
+            Phi_l, w_l, b_l = self.T.Phi.astype(ld), self.wdet.astype(ld), rhs.astype(ld)
+            x_l = x.astype(ld)
+            for _ in range(self.refine_steps):
+                r = b_l - ((x_l @ Phi_l.T) * w_l) @ Phi_l
+                x_l = x_l + solve(r.astype(np.float64)).astype(ld)
+            x = x_l.astype(np.float64)
+        return x
 
     def mass_cg(self, rhs, abs_tol=1e-8, rel_tol=0.0, max_iter=100):
         """DGMassInverse semantics [MFEM]: Jacobi-PCG per element in the Gauss-Legendre nodal

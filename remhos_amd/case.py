@@ -1,0 +1,126 @@
+"""ctypes view of the host-side case builder (include/rmh_driver.h): mesh lattice, box
+partition, halo lists, initial condition -- all computed by the C++ host code
+(remhos_amd/csrc/rmh_host.cpp); this file only exposes the arrays as numpy views."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "librmh_host.so")
+
+DRIVER_SYMBOLS = [
+    "rmhd_case_create", "rmhd_case_destroy", "rmhd_last_error", "rmhd_case_get_info", "rmhd_case_x0",
+    "rmhd_case_vel", "rmhd_case_u0", "rmhd_case_subcell_vel", "rmhd_case_face_nbr", "rmhd_case_stencil27",
+    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_run",
+]
+
+
+class RmhdConfig(C.Structure):
+    _fields_ = [
+        ("mesh", C.c_char * 32), ("rs", C.c_int), ("order", C.c_int), ("problem", C.c_int),
+        ("dt", C.c_double), ("t_final", C.c_double), ("max_steps", C.c_int), ("lo_type", C.c_int),
+        ("fused", C.c_int), ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int), ("rank", C.c_int),
+    ]
+
+
+class RmhdCaseInfo(C.Structure):
+    _fields_ = [
+        ("order", C.c_int), ("exec_mode", C.c_int), ("ndof", C.c_int), ("ne_owned", C.c_int),
+        ("ne_ghost", C.c_int), ("n_peers", C.c_int), ("ne_global", C.c_longlong),
+        ("n", C.c_int * 3), ("lo", C.c_int * 3), ("nl", C.c_int * 3), ("dt", C.c_double),
+        ("bb_min", C.c_double * 3), ("bb_max", C.c_double * 3),
+    ]
+
+
+class RmhdResult(C.Structure):
+    _fields_ = [
+        ("final_mass", C.c_double), ("max_value", C.c_double), ("mass0", C.c_double), ("mass_loss", C.c_double),
+        ("dt", C.c_double), ("t_end", C.c_double), ("steps", C.c_int), ("stages", C.c_int),
+        ("global_dofs", C.c_longlong),
+        ("t_rhs", C.c_double), ("t_inv", C.c_double), ("t_lo", C.c_double), ("t_fct", C.c_double), ("t_total", C.c_double),
+        ("fom_rhs", C.c_double), ("fom_inv", C.c_double), ("fom_lo", C.c_double), ("fom_fct", C.c_double), ("fom", C.c_double),
+        ("wall", C.c_double), ("fom_wall", C.c_double), ("cg_iters_max", C.c_int),
+    ]
+
+
+def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=-1, lo_type=5,
+                fused=1, part=(1, 1, 1), rank=0) -> RmhdConfig:
+    c = RmhdConfig()
+    c.mesh = mesh.encode()
+    c.rs, c.order, c.problem = rs, order, problem
+    c.dt, c.t_final, c.max_steps, c.lo_type, c.fused = dt, t_final, max_steps, lo_type, fused
+    c.px, c.py, c.pz = part
+    c.rank = rank
+    return c
+
+
+def bind_driver(lib: C.CDLL) -> C.CDLL:
+    p = C.c_void_p
+    lib.rmhd_case_create.argtypes = [C.POINTER(RmhdConfig)]
+    lib.rmhd_case_create.restype = p
+    lib.rmhd_case_destroy.argtypes = [p]
+    lib.rmhd_case_destroy.restype = None
+    lib.rmhd_last_error.restype = C.c_char_p
+    lib.rmhd_case_get_info.argtypes = [p, C.POINTER(RmhdCaseInfo)]
+    for name in ("x0", "vel", "u0", "subcell_vel", "face_nbr", "stencil27", "owned_gid", "ghost_gid"):
+        f = getattr(lib, "rmhd_case_" + name)
+        f.argtypes = [p]
+        f.restype = p
+    lib.rmhd_case_peer.argtypes = [p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(p),
+                                   C.POINTER(C.c_int), C.POINTER(p)]
+    if hasattr(lib, "rmhd_run"):
+        lib.rmhd_run.argtypes = [C.POINTER(RmhdConfig), C.POINTER(RmhdResult)]
+    return lib
+
+
+def load_host_library(path: str | None = None) -> C.CDLL:
+    path = path or HOST_LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` to build it")
+    return bind_driver(C.CDLL(path))
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if not ptr or n == 0:
+        return np.zeros(shape, dtype=dtype)
+    ct = {np.float64: C.c_double, np.int32: C.c_int, np.int64: C.c_longlong}[dtype]
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
+    return arr.reshape(shape).copy()
+
+
+class Case:
+    """Host arrays of one rank's block of a Remhos case."""
+
+    def __init__(self, lib: C.CDLL, cfg: RmhdConfig):
+        h = lib.rmhd_case_create(C.byref(cfg))
+        if not h:
+            raise RuntimeError("rmhd_case_create: " + lib.rmhd_last_error().decode())
+        info = RmhdCaseInfo()
+        lib.rmhd_case_get_info(h, C.byref(info))
+        self.cfg = cfg
+        self.order, self.exec_mode, self.ndof = info.order, info.exec_mode, info.ndof
+        self.ne_owned, self.ne_ghost, self.ne_global = info.ne_owned, info.ne_ghost, info.ne_global
+        self.n, self.lo, self.nl = list(info.n), list(info.lo), list(info.nl)
+        self.dt = info.dt
+        self.bb_min, self.bb_max = list(info.bb_min), list(info.bb_max)
+        ne, nd = self.ne_owned, self.ndof
+        self.x0 = _view(lib.rmhd_case_x0(h), (ne, 3, 27), np.float64)
+        self.vel = _view(lib.rmhd_case_vel(h), (ne, 3, 27), np.float64)
+        self.u0 = _view(lib.rmhd_case_u0(h), (ne, nd), np.float64)
+        sv = lib.rmhd_case_subcell_vel(h)
+        self.subcell_vel = _view(sv, (ne, 3, nd), np.float64) if sv else None
+        self.face_nbr = _view(lib.rmhd_case_face_nbr(h), (ne, 6), np.int32)
+        self.stencil27 = _view(lib.rmhd_case_stencil27(h), (ne, 27), np.int32)
+        self.owned_gid = _view(lib.rmhd_case_owned_gid(h), (ne,), np.int64)
+        self.ghost_gid = _view(lib.rmhd_case_ghost_gid(h), (self.ne_ghost,), np.int64)
+        self.peers = []
+        for k in range(info.n_peers):
+            rank, ns, nr = C.c_int(), C.c_int(), C.c_int()
+            ps, pr = C.c_void_p(), C.c_void_p()
+            lib.rmhd_case_peer(h, k, C.byref(rank), C.byref(ns), C.byref(ps), C.byref(nr), C.byref(pr))
+            self.peers.append((rank.value, _view(ps.value, (ns.value,), np.int32), _view(pr.value, (nr.value,), np.int32)))
+        lib.rmhd_case_destroy(h)

@@ -58,6 +58,8 @@ struct rmh_ctx
 namespace
 {
 
+int timers_resolve(rmh_ctx *c);
+
 int timer_begin(rmh_ctx *c, int bucket, EventPair &ep)
 {
    if (!c->timers_on) { return 0; }
@@ -81,6 +83,7 @@ int timer_end(rmh_ctx *c, int bucket, EventPair &ep)
    if (!c->timers_on) { return 0; }
    RMH_HIP(hipEventRecord(ep.b, c->stream));
    c->pending[bucket].push_back(ep);
+   if (c->pending[bucket].size() >= 4096) { return timers_resolve(c); }
    return 0;
 }
 

@@ -1,0 +1,104 @@
+// C ABI of the host-side case builder (include/rmh_driver.h, rmhd_case_*).  No GPU code.
+#include "../../include/rmh_driver.h"
+#include "rmh_host.hpp"
+
+#include <cstring>
+#include <string>
+
+struct rmhd_case
+{
+   remhos::CaseData d;
+};
+
+namespace remhos
+{
+thread_local std::string g_driver_error;
+
+CaseConfig to_config(const rmhd_config &c)
+{
+   CaseConfig k;
+   k.mesh = std::string(c.mesh, strnlen(c.mesh, sizeof(c.mesh)));
+   k.rs = c.rs;
+   k.order = c.order;
+   k.problem = c.problem;
+   k.dt = c.dt;
+   k.t_final = c.t_final;
+   k.max_steps = c.max_steps;
+   k.lo_type = c.lo_type;
+   k.px = c.px > 0 ? c.px : 1;
+   k.py = c.py > 0 ? c.py : 1;
+   k.pz = c.pz > 0 ? c.pz : 1;
+   k.rank = c.rank;
+   return k;
+}
+} // namespace remhos
+
+extern "C" {
+
+const char *rmhd_last_error(void) { return remhos::g_driver_error.c_str(); }
+
+rmhd_case *rmhd_case_create(const rmhd_config *cfg)
+{
+   if (!cfg) { remhos::g_driver_error = "null config"; return nullptr; }
+   rmhd_case *c = new rmhd_case;
+   const std::string err = remhos::build_case(remhos::to_config(*cfg), c->d);
+   if (!err.empty())
+   {
+      remhos::g_driver_error = err;
+      delete c;
+      return nullptr;
+   }
+   return c;
+}
+
+void rmhd_case_destroy(rmhd_case *c) { delete c; }
+
+int rmhd_case_get_info(const rmhd_case *c, rmhd_case_info *info)
+{
+   if (!c || !info) { return -1; }
+   const remhos::CaseData &d = c->d;
+   info->order = d.order;
+   info->exec_mode = d.exec_mode;
+   info->ndof = d.ndof;
+   info->ne_owned = d.ne_owned;
+   info->ne_ghost = d.ne_ghost;
+   info->n_peers = (int)d.peers.size();
+   info->ne_global = d.ne_global;
+   for (int k = 0; k < 3; k++)
+   {
+      info->n[k] = d.n[k];
+      info->lo[k] = d.lo[k];
+      info->nl[k] = d.nl[k];
+      info->bb_min[k] = d.bb_min[k];
+      info->bb_max[k] = d.bb_max[k];
+   }
+   info->dt = d.dt;
+   return 0;
+}
+
+const double *rmhd_case_x0(const rmhd_case *c) { return c->d.x0.data(); }
+const double *rmhd_case_vel(const rmhd_case *c) { return c->d.vel.data(); }
+const double *rmhd_case_u0(const rmhd_case *c) { return c->d.u0.data(); }
+const double *rmhd_case_subcell_vel(const rmhd_case *c)
+{
+   return c->d.subcell_vel.empty() ? nullptr : c->d.subcell_vel.data();
+}
+const int *rmhd_case_face_nbr(const rmhd_case *c) { return c->d.face_nbr.data(); }
+const int *rmhd_case_stencil27(const rmhd_case *c) { return c->d.stencil27.data(); }
+const long long *rmhd_case_owned_gid(const rmhd_case *c) { return c->d.owned_gid.data(); }
+const long long *rmhd_case_ghost_gid(const rmhd_case *c) { return c->d.ghost_gid.data(); }
+
+int rmhd_case_peer(const rmhd_case *c, int k, int *rank, int *nsend, const int **send_elems, int *nrecv,
+                   const int **recv_slots)
+{
+   if (!c || k < 0 || k >= (int)c->d.peers.size()) { return -1; }
+   const remhos::Peer &p = c->d.peers[k];
+   *rank = p.rank;
+   *nsend = (int)p.send_elems.size();
+   *send_elems = p.send_elems.data();
+   *nrecv = (int)p.recv_slots.size();
+   *recv_slots = p.recv_slots.data();
+   return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,352 @@
+// Host classes of include/remhos_amd/solvers.hpp and the single-GPU time loop rmhd_run().
+#include "../../include/remhos_amd/solvers.hpp"
+#include "../../include/rmh_driver.h"
+#include "rmh_host.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace remhos
+{
+
+extern thread_local std::string g_driver_error;
+CaseConfig to_config(const rmhd_config &c);
+
+void rmh_abort(const char *msg, const char *file, int line)
+{
+   std::fprintf(stderr, "\nremhos_amd abort: %s\n ... in %s:%d\n ... last rmh error: %s\n", msg, file, line,
+                rmh_last_error());
+   std::abort();
+}
+
+#define RMH_CALL(expr) RMH_VERIFY((expr) == 0, #expr)
+#define HIP_CALL(expr) RMH_VERIFY((expr) == hipSuccess, #expr)
+
+// ---- Vector ------------------------------------------------------------------------------
+Vector::Vector(int n) { SetSize(n); }
+Vector::Vector(const Vector &o)
+{
+   SetSize(o.size);
+   if (size) { HIP_CALL(hipMemcpyAsync(data, o.data, sizeof(double) * size, hipMemcpyDeviceToDevice, nullptr)); }
+}
+Vector &Vector::operator=(const Vector &o)
+{
+   if (this == &o) { return *this; }
+   if (size != o.size) { SetSize(o.size); }
+   if (size) { HIP_CALL(hipMemcpyAsync(data, o.data, sizeof(double) * size, hipMemcpyDeviceToDevice, nullptr)); }
+   return *this;
+}
+Vector::~Vector()
+{
+   if (own && data) { (void)hipFree(data); }
+}
+void Vector::SetSize(int n)
+{
+   if (own && data) { (void)hipFree(data); }
+   data = nullptr;
+   size = n;
+   own = true;
+   if (n > 0) { HIP_CALL(hipMalloc((void **)&data, sizeof(double) * n)); }
+}
+void Vector::CopyFromHost(const double *h)
+{
+   HIP_CALL(hipMemcpy(data, h, sizeof(double) * size, hipMemcpyHostToDevice));
+}
+void Vector::CopyToHost(double *h) const
+{
+   HIP_CALL(hipMemcpy(h, data, sizeof(double) * size, hipMemcpyDeviceToHost));
+}
+
+__global__ void fill_kernel(double *z, double v, int n)
+{
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { z[i] = v; }
+}
+__global__ void axpby_kernel(double a, const double *x, double b, const double *y, double *z, int n)
+{
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+   {
+      z[i] = a * x[i] + b * y[i];
+   }
+}
+static int grid_for(int n) { return std::max(1, std::min(2048, (n + 255) / 256)); }
+
+Vector &Vector::operator=(double value)
+{
+   if (size) { hipLaunchKernelGGL(fill_kernel, dim3(grid_for(size)), dim3(256), 0, nullptr, data, value, size); }
+   return *this;
+}
+void add(const Vector &x, double a, const Vector &y, Vector &z)
+{
+   const int n = x.Size();
+   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, 1.0, x.Read(), a, y.Read(), z.Write(),
+                      n);
+}
+void add(double a, const Vector &x, double b, const Vector &y, Vector &z)
+{
+   const int n = x.Size();
+   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, a, x.Read(), b, y.Read(), z.Write(), n);
+}
+
+void TimingData::Update(rmh_ctx *ctx)
+{
+   double t[4];
+   RMH_CALL(rmh_timers(ctx, t));
+   sw_rhs = t[0];
+   sw_L2inv = t[1];
+   sw_LO = t[2];
+   sw_FCT = t[3];
+}
+
+// ---- solvers: forward to the C ABI ------------------------------------------------------------
+void LocalInverseHOSolver::CalcHOSolution(const Vector &u, Vector &du) const
+{
+   RMH_VERIFY(timer, "Timer not set."); // remhos_ho.cpp:86
+   RMH_CALL(rmh_ho_apply(pfes.Ctx(), u.Read(), du.Write()));
+}
+
+void MassBasedAvg::CalcLOSolution(const Vector &u, Vector &du) const
+{
+   // remhos_lo.cpp:247-324
+   if (du_HO)
+   {
+      RMH_CALL(rmh_lo_massavg(pfes.Ctx(), u.Read(), du_HO->Read(), dt, du.Write()));
+      du_HO = nullptr;
+   }
+   else
+   {
+      Vector du_HO_tmp(u.Size());
+      ho_solver.CalcHOSolution(u, du_HO_tmp);
+      RMH_CALL(rmh_lo_massavg(pfes.Ctx(), u.Read(), du_HO_tmp.Read(), dt, du.Write()));
+   }
+}
+
+void PAResidualDistributionSubcell::CalcLOSolution(const Vector &u, Vector &du) const
+{
+   RMH_CALL(rmh_lo_rdsubcell(pfes.Ctx(), u.Read(), du.Write()));
+}
+
+void ClipScaleSolver::CalcFCTSolution(const ParGridFunction &u, const Vector &m, const Vector &du_ho,
+                                      const Vector &du_lo, const Vector &u_min, const Vector &u_max,
+                                      Vector &du) const
+{
+   RMH_CALL(rmh_fct_clipscale(pfes.Ctx(), u.Read(), m.Read(), du_ho.Read(), du_lo.Read(), u_min.Read(), u_max.Read(),
+                              dt, du.Write()));
+}
+
+DofInfo::DofInfo(ParFiniteElementSpace &space)
+   : pfes(space), xe_min(space.GetNE()), xe_max(space.GetNE()), xi_min(space.GetVSize()), xi_max(space.GetVSize())
+{
+}
+void DofInfo::ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_max) const
+{
+   RMH_CALL(rmh_elem_minmax(pfes.Ctx(), u.Read(), u_min.Write(), u_max.Write()));
+}
+void DofInfo::ComputeBounds(const Vector &el_min, const Vector &el_max, Vector &dof_min, Vector &dof_max) const
+{
+   RMH_CALL(rmh_bounds(pfes.Ctx(), el_min.Read(), el_max.Read(), dof_min.Write(), dof_max.Write()));
+}
+
+// ---- AdvectionOperator (remhos.cpp:1596-1739, 1798-1916) -----------------------------------------
+AdvectionOperator::AdvectionOperator(ParFiniteElementSpace &space, DofInfo &dofs_, HOSolver *hos, LOSolver *los,
+                                     FCTSolver *fct, bool fused_limiter)
+   : LimitedTimeDependentOperator(space.GetVSize()), pfes(space), dofs(dofs_), ho_solver(hos), lo_solver(los),
+     fct_solver(fct), lumpedM(rmh_lumped_mass(space.Ctx()) ? const_cast<double *>(rmh_lumped_mass(space.Ctx())) : nullptr,
+                              space.GetVSize()),
+     du_HO(space.GetVSize()), du_LO(fused_limiter ? 0 : space.GetVSize()), fused(fused_limiter)
+{
+   if (ho_solver) { ho_solver->timer = &timer; }
+   if (lo_solver) { lo_solver->timer = &timer; }
+   if (fct_solver) { fct_solver->timer = &timer; }
+}
+
+void AdvectionOperator::MultUnlimited(const Vector &X, Vector &Y) const
+{
+   // remap: move the mesh to the stage time and re-set-up M_HO, K_HO, lumpedM
+   // (remhos.cpp:1598-1637) -- matrix-free here: the kernels evaluate x0 + t*v themselves
+   RMH_CALL(rmh_setup(pfes.Ctx(), GetTime()));
+   RMH_VERIFY(ho_solver && lo_solver && fct_solver, "FCT requires HO and LO solvers."); // remhos.cpp:1690
+   ho_solver->CalcHOSolution(X, Y);
+   // Limiting is deferred to LimitMult()
+}
+
+void AdvectionOperator::LimitMult(const Vector &X, Vector &Y) const
+{
+   const Vector &u = X;
+   Vector &d_u = Y;
+   if (fused)
+   {
+      // d_u holds du_HO on entry; the fused kernel reads du_HO and writes d_u element by element
+      RMH_CALL(rmh_limit_fused(pfes.Ctx(), u.Read(), d_u.Read(), dt, d_u.Write(), nullptr, 0.0, 1.0, 0.0, nullptr));
+      return;
+   }
+   // the reference's sequence, remhos.cpp:1812-1831 (the x_gf face-neighbour exchange at
+   // :1812-1813 is dead weight for ClipScale and is skipped)
+   du_HO = d_u; // Vector du_HO(d_u)
+   auto mba = dynamic_cast<MassBasedAvg *>(lo_solver);
+   if (mba) { mba->SetHOSolution(du_HO); }
+   lo_solver->CalcLOSolution(u, du_LO);
+   dofs.ComputeElementsMinMax(u, dofs.xe_min, dofs.xe_max);
+   dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
+   fct_solver->CalcFCTSolution(u, lumpedM, du_HO, du_LO, dofs.xi_min, dofs.xi_max, d_u);
+}
+
+// ---- RK3 SSP [MFEM RK3SSPSolver::Step] -------------------------------------------------------------
+void RK3SSPSolver::Init(LimitedTimeDependentOperator &op)
+{
+   f = &op;
+   y.SetSize(op.Height());
+   k.SetSize(op.Height());
+}
+void RK3SSPSolver::Step(Vector &x, real_t &t, real_t &dt)
+{
+   // x0 = x, t0 = t, k0 = dt*f(t0, x0)
+   f->SetTime(t);
+   f->Mult(x, k);
+   // x1 = x + k0, t1 = t + dt, k1 = dt*f(t1, x1)
+   add(x, dt, k, y);
+   f->SetTime(t + dt);
+   f->Mult(y, k);
+   // x2 = 3/4*x + 1/4*(x1 + k1), t2 = t + 1/2*dt, k2 = dt*f(t2, x2)
+   add(y, dt, k, y);
+   add(3. / 4, x, 1. / 4, y, y);
+   f->SetTime(t + dt / 2);
+   f->Mult(y, k);
+   // x3 = 1/3*x + 2/3*(x2 + k2), t3 = t + dt
+   add(y, dt, k, y);
+   add(1. / 3, x, 2. / 3, y, x);
+   t += dt;
+}
+
+} // namespace remhos
+
+using namespace remhos;
+
+extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
+{
+   if (!cfg || !res) { g_driver_error = "null argument"; return -1; }
+   CaseConfig cc = to_config(*cfg);
+   if (cc.px * cc.py * cc.pz != 1)
+   {
+      g_driver_error = "rmhd_run drives one GPU; multi-GPU runs go through remhos_amd.stepper (torch.distributed)";
+      return -1;
+   }
+   CaseData cd;
+   const std::string err = build_case(cc, cd);
+   if (!err.empty()) { g_driver_error = err; return -1; }
+
+   rmh_layout L;
+   L.dim = 3;
+   L.order = cd.order;
+   L.mesh_order = 2;
+   L.exec_mode = cd.exec_mode;
+   L.ne_owned = cd.ne_owned;
+   L.ne_ghost = 0;
+   L.x0 = cd.x0.data();
+   L.vel = cd.vel.data();
+   L.face_nbr = cd.face_nbr.data();
+   L.stencil27 = cd.stencil27.data();
+   L.subcell_vel = cd.subcell_vel.empty() ? nullptr : cd.subcell_vel.data();
+   L.device = 0;
+   rmh_ctx *ctx = nullptr;
+   if (rmh_create(&L, &ctx) != 0) { g_driver_error = rmh_last_error(); return -1; }
+   rmh_enable_timers(ctx, 1);
+
+   const int vsize = cd.ne_owned * cd.ndof;
+   int rc = 0;
+   {
+      ParFiniteElementSpace pfes(ctx, cd.ne_owned, cd.ndof, (long long)cd.ne_global * cd.ndof);
+      DofInfo dofs(pfes);
+      HOSolver *ho_solver = new LocalInverseHOSolver(pfes);
+      LOSolver *lo_solver = nullptr;
+      if (cc.lo_type == 5) { lo_solver = new MassBasedAvg(pfes, *ho_solver); }
+      else { lo_solver = new PAResidualDistributionSubcell(pfes); }
+      double dt = cd.dt;
+      FCTSolver *fct_solver = new ClipScaleSolver(pfes, dt);
+      const bool fused = cfg->fused && cc.lo_type == 5;
+      AdvectionOperator adv(pfes, dofs, ho_solver, lo_solver, fct_solver, fused);
+
+      Vector u(vsize);
+      u.CopyFromHost(cd.u0.data());
+      std::vector<double> h_u(vsize), h_m(vsize);
+      // initial mass (remhos.cpp:1073-1076)
+      Vector masses(vsize);
+      RMH_CALL(rmh_compute_lumped_mass(ctx, 0.0, masses.Write()));
+      masses.CopyToHost(h_m.data());
+      double mass0 = 0.0;
+      for (int i = 0; i < vsize; i++) { mass0 += h_m[i] * cd.u0[i]; }
+
+      RK3SSPSolver ode_solver;
+      double t = 0.0;
+      adv.SetTime(t);
+      ode_solver.Init(adv);
+      // For remap, the pseudo-time always evolves from 0 to 1 (remhos.cpp:1128-1134)
+      const double t_final = cd.exec_mode == 1 ? 1.0 : cc.t_final;
+      bool done = false;
+      int ti = 0;
+      HIP_CALL(hipDeviceSynchronize());
+      const auto w0 = std::chrono::steady_clock::now();
+      while (!done)
+      {
+         double dt_real = std::min(dt, t_final - t);
+         adv.SetDt(dt_real);
+         ode_solver.Step(u, t, dt_real);
+         ti++;
+         done = (t >= t_final - 1.e-8 * dt);
+         if (ti == cc.max_steps) { done = true; }
+      }
+      HIP_CALL(hipDeviceSynchronize());
+      const auto w1 = std::chrono::steady_clock::now();
+
+      // final mass: remap uses the lumped mass at the final position (remhos.cpp:1382-1413)
+      if (cd.exec_mode == 1)
+      {
+         RMH_CALL(rmh_compute_lumped_mass(ctx, t, masses.Write()));
+         masses.CopyToHost(h_m.data());
+      }
+      u.CopyToHost(h_u.data());
+      double mass = 0.0, umax = -INFINITY;
+      for (int i = 0; i < vsize; i++)
+      {
+         mass += h_m[i] * h_u[i];
+         umax = std::fmax(umax, h_u[i]);
+      }
+      adv.Timer().Update(ctx);
+      const TimingData &T = adv.Timer();
+      res->final_mass = mass;
+      res->max_value = umax;
+      res->mass0 = mass0;
+      res->mass_loss = std::fabs(mass0 - mass);
+      res->dt = dt;
+      res->t_end = t;
+      res->steps = ti;
+      res->stages = 3 * ti;
+      res->global_dofs = pfes.GlobalVSize();
+      res->t_rhs = T.sw_rhs;
+      res->t_inv = T.sw_L2inv;
+      res->t_lo = T.sw_LO;
+      res->t_fct = T.sw_FCT;
+      res->t_total = T.sw_rhs + T.sw_LO + T.sw_FCT; // remhos.cpp:1933 (omits INV)
+      const double dofs_steps = 1e-6 * (double)res->global_dofs * res->stages;
+      res->fom_rhs = T.sw_rhs > 0 ? dofs_steps / T.sw_rhs : 0;
+      res->fom_inv = T.sw_L2inv > 0 ? dofs_steps / T.sw_L2inv : 0;
+      res->fom_lo = T.sw_LO > 0 ? dofs_steps / T.sw_LO : 0;
+      res->fom_fct = T.sw_FCT > 0 ? dofs_steps / T.sw_FCT : 0;
+      res->fom = res->t_total > 0 ? dofs_steps / res->t_total : 0;
+      res->wall = std::chrono::duration<double>(w1 - w0).count();
+      res->fom_wall = dofs_steps / res->wall;
+      int it = 0;
+      rmh_last_cg_iters(ctx, &it);
+      res->cg_iters_max = it;
+      delete fct_solver;
+      delete lo_solver;
+      delete ho_solver;
+   }
+   rmh_destroy(ctx);
+   return rc;
+}

@@ -1,0 +1,494 @@
+// Host-side case setup (see rmh_host.hpp).  Plain C++17, no GPU code.
+#include "rmh_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <cstring>
+#include <map>
+#include <thread>
+
+namespace remhos
+{
+
+namespace
+{
+
+struct MeshDef
+{
+   std::vector<double> coarse; // vertex coordinates per direction of the data/*.mesh lattice
+   bool periodic;
+};
+
+// data/periodic-cube.mesh:114-328 (6-decimal coordinates are part of the
+// reference's answers), data/cube01_hex.mesh:64-144
+bool lookup_mesh(const std::string &name, MeshDef &m)
+{
+   if (name == "periodic-cube") { m = {{-1.0, -0.333333, 0.333333, 1.0}, true}; return true; }
+   if (name == "cube01_hex") { m = {{0.0, 0.5, 1.0}, false}; return true; }
+   return false;
+}
+
+std::vector<double> refine(std::vector<double> c, int levels)
+{
+   for (int l = 0; l < levels; l++)
+   {
+      std::vector<double> o(2 * c.size() - 1);
+      for (size_t i = 0; i < c.size(); i++) { o[2 * i] = c[i]; }
+      for (size_t i = 0; i + 1 < c.size(); i++) { o[2 * i + 1] = 0.5 * c[i] + 0.5 * c[i + 1]; }
+      c.swap(o);
+   }
+   return c;
+}
+
+// Q2 Lagrange basis on {0, 1/2, 1}
+inline void lag2(double t, double L[3])
+{
+   L[0] = 2.0 * (t - 0.5) * (t - 1.0);
+   L[1] = -4.0 * t * (t - 1.0);
+   L[2] = 2.0 * t * (t - 0.5);
+}
+
+void parallel_for(long long n, const std::function<void(long long, long long)> &body)
+{
+   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+   if (n < 4096) { nt = 1; }
+   std::vector<std::thread> pool;
+   const long long chunk = (n + nt - 1) / nt;
+   for (unsigned t = 0; t < nt; t++)
+   {
+      const long long a = t * chunk, b = std::min(n, a + chunk);
+      if (a >= b) { break; }
+      pool.emplace_back([=, &body]() { body(a, b); });
+   }
+   for (auto &th : pool) { th.join(); }
+}
+
+inline double box3D(double xmin, double xmax, double ymin, double ymax, double zmin, double zmax, double theta,
+                    double ox, double oy, double x, double y, double z)
+{
+   const double s = std::sin(theta * M_PI / 180), c = std::cos(theta * M_PI / 180);
+   const double xn = c * (x - ox) - s * (y - oy) + ox;
+   const double yn = s * (x - ox) + c * (y - oy) + oy;
+   return (xn > xmin && xn < xmax && yn > ymin && yn < ymax && z > zmin && z < zmax) ? 1.0 : 0.0;
+}
+inline double get_cross(double r1, double r2) { return r1 + r2 - r1 * r2; }
+inline double ring(double rin, double rout, const double c[3], const double y[3])
+{
+   double r = 0.0;
+   for (int i = 0; i < 3; i++) { r += (y[i] - c[i]) * (y[i] - c[i]); }
+   r = std::sqrt(r);
+   return (r > rin && r < rout) ? 1.0 : 0.0;
+}
+
+} // namespace
+
+// remhos.cpp:2001-2120 (dim = 3)
+void velocity_function(int problem, const double *bb_min, const double *bb_max, const double x[3], double v[3])
+{
+   double X[3];
+   for (int i = 0; i < 3; i++)
+   {
+      const double center = (bb_min[i] + bb_max[i]) * 0.5;
+      X[i] = 2 * (x[i] - center) / (bb_max[i] - bb_min[i]);
+   }
+   v[0] = v[1] = v[2] = 0.0;
+   switch (problem % 20)
+   {
+      case 0:
+         v[0] = std::sqrt(3. / 6.); v[1] = std::sqrt(2. / 6.); v[2] = std::sqrt(1. / 6.);
+         break;
+      case 1:
+      case 2:
+      case 4:
+      {
+         const double w = M_PI / 2;
+         v[0] = -w * X[1]; v[1] = w * X[0]; v[2] = 0.0;
+         break;
+      }
+      case 5:
+         v[0] = 1.0; v[1] = 1.0; v[2] = 1.0;
+         break;
+      case 10:
+      case 12:
+      case 13:
+      case 14:
+      case 15:
+      case 16:
+      case 17:
+      {
+         // Taylor-Green deformation; map [-1,1] to [0,1]
+         for (int d = 0; d < 3; d++) { X[d] = X[d] * 0.5 + 0.5; }
+         v[0] = std::sin(M_PI * X[0]) * std::cos(M_PI * X[1]);
+         v[1] = -std::cos(M_PI * X[0]) * std::sin(M_PI * X[1]);
+         v[0] *= std::cos(M_PI * X[2]);
+         v[1] *= std::cos(M_PI * X[2]);
+         v[2] = 0.0;
+         break;
+      }
+      default: break;
+   }
+}
+
+// remhos.cpp:2201-2355 (dim = 3)
+double u0_function(int problem, const double *bb_min, const double *bb_max, const double x[3])
+{
+   double X[3];
+   for (int i = 0; i < 3; i++)
+   {
+      const double center = (bb_min[i] + bb_max[i]) * 0.5;
+      X[i] = 2 * (x[i] - center) / (bb_max[i] - bb_min[i]);
+   }
+   switch (problem % 10)
+   {
+      case 0:
+      case 1:
+      {
+         double rx = 0.45, ry = 0.25;
+         const double cx = 0., cy = -0.2, w = 10.;
+         const double s = (1. + 0.25 * std::cos(2 * M_PI * X[2]));
+         rx *= s;
+         ry *= s;
+         return (std::erfc(w * (X[0] - cx - rx)) * std::erfc(-w * (X[0] - cx + rx)) *
+                 std::erfc(w * (X[1] - cy - ry)) * std::erfc(-w * (X[1] - cy + ry))) / 16;
+      }
+      case 4:
+      {
+         const double scale = 0.0225;
+         const double coef = (0.5 / std::sqrt(scale));
+         const bool slit = (X[0] <= -0.05) || (X[0] >= 0.05) || (X[1] >= 0.7);
+         const double cone = coef * std::sqrt(std::pow(X[0], 2.) + std::pow(X[1] + 0.5, 2.));
+         const double hump = coef * std::sqrt(std::pow(X[0] + 0.5, 2.) + std::pow(X[1], 2.));
+         return (slit && ((std::pow(X[0], 2.) + std::pow(X[1] - .5, 2.)) <= 4. * scale))
+                   ? 1.
+                   : 0. + (1. - cone) * (std::pow(X[0], 2.) + std::pow(X[1] + .5, 2.) <= 4. * scale) +
+                        .25 * (1. + std::cos(M_PI * hump)) *
+                           ((std::pow(X[0] + .5, 2.) + std::pow(X[1], 2.)) <= 4. * scale);
+      }
+      case 5:
+      {
+         double y[3];
+         for (int i = 0; i < 3; i++) { y[i] = 50. * (x[i] + 1.); }
+         double rect1 = box3D(7., 32., 10., 13., 10., 13., -45., 15.5, 11.5, y[0], y[1], y[2]);
+         double rect2 = box3D(14., 17., 3., 26., 10., 13., -45., 15.5, 11.5, y[0], y[1], y[2]);
+         double rect3 = box3D(14., 17., 10., 13., 3., 26., -45., 15.5, 11.5, y[0], y[1], y[2]);
+         double cross = get_cross(get_cross(rect1, rect2), rect3);
+         const double c1[3] = {40., 40., 40.}, c2[3] = {40., 20., 20.};
+         const double dom2 = cross + ring(7., 10., c1, y) + ring(3., 7., c2, y);
+         rect1 = box3D(2., 27., 30., 33., 30., 33., 0., 0., 0., y[0], y[1], y[2]);
+         rect2 = box3D(9., 12., 23., 46., 30., 33., 0., 0., 0., y[0], y[1], y[2]);
+         rect3 = box3D(9., 12., 30., 33., 23., 46., 0., 0., 0., y[0], y[1], y[2]);
+         cross = get_cross(get_cross(rect1, rect2), rect3);
+         const double dom3 = cross + ring(0., 7., c1, y) + ring(0., 3., c2, y) + ring(7., 10., c2, y);
+         const double dom1 = 1. - get_cross(dom2, dom3);
+         return dom1 + 2. * dom2 + 3. * dom3;
+      }
+      default: return 0.0;
+   }
+}
+
+std::string build_case(const CaseConfig &cfg, CaseData &out)
+{
+   MeshDef md;
+   if (!lookup_mesh(cfg.mesh, md)) { return "unknown lattice mesh '" + cfg.mesh + "' (periodic-cube, cube01_hex)"; }
+   if (cfg.order < 1 || cfg.order > 6) { return "order must be in 1..6"; }
+   if (cfg.px < 1 || cfg.py < 1 || cfg.pz < 1) { return "bad partition"; }
+   const int nranks = cfg.px * cfg.py * cfg.pz;
+   if (cfg.rank < 0 || cfg.rank >= nranks) { return "bad rank"; }
+   if (cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 4 or 5"; }
+
+   const std::vector<double> verts = refine(md.coarse, cfg.rs);
+   const int N = (int)verts.size() - 1;
+   const int P[3] = {cfg.px, cfg.py, cfg.pz};
+   for (int d = 0; d < 3; d++)
+   {
+      if (P[d] > N) { return "more partition blocks than elements in a direction"; }
+   }
+   out = CaseData();
+   out.order = cfg.order;
+   out.exec_mode = cfg.problem < 10 ? 0 : 1; // remhos.cpp:437-440
+   const int D = cfg.order + 1, p = cfg.order;
+   out.ndof = D * D * D;
+   out.periodic = md.periodic;
+   out.ne_global = (long long)N * N * N;
+   for (int d = 0; d < 3; d++)
+   {
+      out.n[d] = N;
+      out.bb_min[d] = verts.front();
+      out.bb_max[d] = verts.back();
+   }
+   const int r3[3] = {cfg.rank % cfg.px, (cfg.rank / cfg.px) % cfg.py, cfg.rank / (cfg.px * cfg.py)};
+   auto chunk_lo = [&](int d, int r) { return (int)(((long long)r * N) / P[d]); };
+   for (int d = 0; d < 3; d++)
+   {
+      out.lo[d] = chunk_lo(d, r3[d]);
+      out.nl[d] = chunk_lo(d, r3[d] + 1) - out.lo[d];
+   }
+   auto owner_1d = [&](int d, int g)
+   {
+      // inverse of chunk_lo
+      int r = (int)(((long long)(g + 1) * P[d] - 1) / N);
+      while (chunk_lo(d, r) > g) { r--; }
+      while (chunk_lo(d, r + 1) <= g) { r++; }
+      return r;
+   };
+   const int nlx = out.nl[0], nly = out.nl[1], nlz = out.nl[2];
+   out.ne_owned = nlx * nly * nlz;
+   const int ne = out.ne_owned;
+   const double *bmin = out.bb_min, *bmax = out.bb_max;
+   const int problem = cfg.problem;
+
+   // mesh nodes per direction (Gauss-Lobatto order 2 = vertices and midpoints)
+   std::vector<double> nodes1d(2 * N + 1);
+   for (int i = 0; i <= N; i++) { nodes1d[2 * i] = verts[i]; }
+   for (int i = 0; i < N; i++) { nodes1d[2 * i + 1] = 0.5 * verts[i] + 0.5 * verts[i + 1]; }
+
+   // ---- time step (remhos.cpp:538-553): 0.25 * h_e / |v(center)|, min over ALL elements ------------
+   double dt = cfg.dt;
+   if (dt < 0.0)
+   {
+      dt = INFINITY;
+      for (int ez = 0; ez < N; ez++)
+      {
+         for (int ey = 0; ey < N; ey++)
+         {
+            for (int ex = 0; ex < N; ex++)
+            {
+               // J(center) of the Q2 lattice element: differences of the mid-face nodes
+               const double hx = nodes1d[2 * ex + 2] - nodes1d[2 * ex];
+               const double hy = nodes1d[2 * ey + 2] - nodes1d[2 * ey];
+               const double hz = nodes1d[2 * ez + 2] - nodes1d[2 * ez];
+               const double length = std::pow(std::fabs(hx * hy * hz), 1. / 3.);
+               const double xc[3] = {nodes1d[2 * ex + 1], nodes1d[2 * ey + 1], nodes1d[2 * ez + 1]};
+               double v[3];
+               velocity_function(problem, bmin, bmax, xc, v);
+               const double speed = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + 1e-14);
+               dt = std::fmin(dt, 0.25 * length / speed);
+            }
+         }
+      }
+   }
+   out.dt = dt;
+
+   // ---- local lattice nodes: positions and remap displacement (remhos.cpp:562-584) ----------------
+   const int nnx = 2 * nlx + 1, nny = 2 * nly + 1, nnz = 2 * nlz + 1;
+   const long long nn = (long long)nnx * nny * nnz;
+   std::vector<double> xn(3 * nn), vn(3 * nn);
+   const bool remap = out.exec_mode == 1;
+   const double t_final = cfg.t_final;
+   parallel_for(nn, [&](long long a, long long b)
+   {
+      for (long long k = a; k < b; k++)
+      {
+         const int ix = (int)(k % nnx), iy = (int)((k / nnx) % nny), iz = (int)(k / ((long long)nnx * nny));
+         const double x0[3] = {nodes1d[2 * out.lo[0] + ix], nodes1d[2 * out.lo[1] + iy], nodes1d[2 * out.lo[2] + iz]};
+         double x[3] = {x0[0], x0[1], x0[2]}, v[3];
+         velocity_function(problem, bmin, bmax, x, v);
+         if (remap)
+         {
+            // note the reference's order: t advances BEFORE min(dt, t_final - t) is taken
+            double t = 0.0;
+            while (t < t_final)
+            {
+               t += dt;
+               const double h = std::min(dt, t_final - t);
+               for (int c = 0; c < 3; c++) { x[c] = x[c] + h * v[c]; }
+               velocity_function(problem, bmin, bmax, x, v);
+            }
+            for (int c = 0; c < 3; c++) { v[c] = x[c] - x0[c]; }
+         }
+         for (int c = 0; c < 3; c++)
+         {
+            xn[3 * k + c] = x0[c];
+            vn[3 * k + c] = v[c];
+         }
+      }
+   });
+
+   // ---- per-element copies (L2 nodal E-vector), initial condition, subcell velocity --------------
+   out.x0.resize((size_t)ne * 81);
+   out.vel.resize((size_t)ne * 81);
+   out.u0.resize((size_t)ne * out.ndof);
+   const bool lo4 = cfg.lo_type == 4;
+   if (lo4) { out.subcell_vel.assign((size_t)ne * 3 * out.ndof, 0.0); }
+   out.owned_gid.resize(ne);
+   std::vector<double> Lcu(3 * D); // Q2 Lagrange at the closed-uniform points i/p
+   for (int i = 0; i < D; i++) { lag2((double)i / p, &Lcu[3 * i]); }
+   parallel_for(ne, [&](long long a, long long b)
+   {
+      for (long long e = a; e < b; e++)
+      {
+         const int lx = (int)(e % nlx), ly = (int)((e / nlx) % nly), lz = (int)(e / ((long long)nlx * nly));
+         out.owned_gid[e] = (long long)(out.lo[0] + lx) + (long long)N * ((out.lo[1] + ly) + (long long)N * (out.lo[2] + lz));
+         double *ex0 = &out.x0[(size_t)e * 81], *ev = &out.vel[(size_t)e * 81];
+         for (int az = 0; az < 3; az++)
+         {
+            for (int ay = 0; ay < 3; ay++)
+            {
+               for (int ax = 0; ax < 3; ax++)
+               {
+                  const long long k = (2 * lx + ax) + (long long)nnx * ((2 * ly + ay) + (long long)nny * (2 * lz + az));
+                  const int a3 = ax + 3 * (ay + 3 * az);
+                  for (int c = 0; c < 3; c++)
+                  {
+                     ex0[c * 27 + a3] = xn[3 * k + c];
+                     ev[c * 27 + a3] = vn[3 * k + c];
+                  }
+               }
+            }
+         }
+         // u_i = u0(x(xi_i)) at the closed-uniform points (remhos.cpp:878-884)
+         for (int iz = 0; iz < D; iz++)
+         {
+            for (int iy = 0; iy < D; iy++)
+            {
+               for (int ix = 0; ix < D; ix++)
+               {
+                  double x[3] = {0, 0, 0};
+                  for (int az = 0; az < 3; az++)
+                  {
+                     for (int ay = 0; ay < 3; ay++)
+                     {
+                        for (int ax = 0; ax < 3; ax++)
+                        {
+                           const double w = Lcu[3 * ix + ax] * Lcu[3 * iy + ay] * Lcu[3 * iz + az];
+                           const int a3 = ax + 3 * (ay + 3 * az);
+                           for (int c = 0; c < 3; c++) { x[c] += w * ex0[c * 27 + a3]; }
+                        }
+                     }
+                  }
+                  const int i = ix + D * (iy + D * iz);
+                  out.u0[(size_t)e * out.ndof + i] = u0_function(problem, bmin, bmax, x);
+                  if (lo4 && remap)
+                  {
+                     // v_sub_gf: instantaneous velocity at the sub-mesh nodes, zero on the
+                     // domain boundary of non-periodic meshes (remhos.cpp:837-853)
+                     double v[3];
+                     velocity_function(problem, bmin, bmax, x, v);
+                     bool bdr = false;
+                     if (!md.periodic)
+                     {
+                        const int g[3] = {out.lo[0] + lx, out.lo[1] + ly, out.lo[2] + lz};
+                        const int id[3] = {ix, iy, iz};
+                        for (int c = 0; c < 3; c++)
+                        {
+                           bdr = bdr || (g[c] == 0 && id[c] == 0) || (g[c] == N - 1 && id[c] == p);
+                        }
+                     }
+                     for (int c = 0; c < 3; c++)
+                     {
+                        out.subcell_vel[((size_t)e * 3 + c) * out.ndof + i] = bdr ? 0.0 : v[c];
+                     }
+                  }
+               }
+            }
+         }
+      }
+   });
+
+   // ---- topology: 27-stencil with ghosts, face neighbours, halo lists ------------------------------
+   out.stencil27.assign((size_t)ne * 27, -1);
+   out.face_nbr.assign((size_t)ne * 6, -1);
+   std::map<std::pair<int, long long>, int> ghost_slot; // (owner, gid) -> slot, ordered
+   std::map<int, std::vector<long long>> send_sets;       // peer -> gids of owned elements it needs
+   auto wrap = [&](int g, bool &ok)
+   {
+      if (g >= 0 && g < N) { return g; }
+      if (!md.periodic) { ok = false; return 0; }
+      return (g % N + N) % N;
+   };
+   // pass 1: collect ghosts and send sets (only elements near the box surface have remote neighbours)
+   for (int lz = 0; lz < nlz; lz++)
+   {
+      for (int ly = 0; ly < nly; ly++)
+      {
+         for (int lx = 0; lx < nlx; lx++)
+         {
+            const bool surf = lx == 0 || ly == 0 || lz == 0 || lx == nlx - 1 || ly == nly - 1 || lz == nlz - 1;
+            if (!surf) { continue; }
+            const long long mygid = out.owned_gid[lx + (long long)nlx * (ly + (long long)nly * lz)];
+            for (int s = 0; s < 27; s++)
+            {
+               const int o[3] = {s % 3 - 1, (s / 3) % 3 - 1, s / 9 - 1};
+               bool ok = true;
+               const int g[3] = {wrap(out.lo[0] + lx + o[0], ok), wrap(out.lo[1] + ly + o[1], ok),
+                                 wrap(out.lo[2] + lz + o[2], ok)};
+               if (!ok) { continue; }
+               const int owner = owner_1d(0, g[0]) + cfg.px * (owner_1d(1, g[1]) + cfg.py * owner_1d(2, g[2]));
+               if (owner == cfg.rank) { continue; }
+               const long long gid = g[0] + (long long)N * (g[1] + (long long)N * g[2]);
+               ghost_slot[{owner, gid}] = 0;
+               send_sets[owner].push_back(mygid);
+            }
+         }
+      }
+   }
+   int slot = 0;
+   out.ghost_gid.clear();
+   for (auto &kv : ghost_slot)
+   {
+      kv.second = slot++;
+      out.ghost_gid.push_back(kv.first.second);
+   }
+   out.ne_ghost = slot;
+   auto local_of_gid = [&](long long gid)
+   {
+      const int gx = (int)(gid % N), gy = (int)((gid / N) % N), gz = (int)(gid / ((long long)N * N));
+      return (gx - out.lo[0]) + nlx * ((gy - out.lo[1]) + nly * (gz - out.lo[2]));
+   };
+   std::map<int, Peer> peers;
+   for (auto &kv : ghost_slot)
+   {
+      Peer &pr = peers[kv.first.first];
+      pr.rank = kv.first.first;
+      pr.recv_slots.push_back(kv.second);
+   }
+   for (auto &kv : send_sets)
+   {
+      std::vector<long long> &g = kv.second;
+      std::sort(g.begin(), g.end());
+      g.erase(std::unique(g.begin(), g.end()), g.end());
+      Peer &pr = peers[kv.first];
+      pr.rank = kv.first;
+      for (long long gid : g) { pr.send_elems.push_back(local_of_gid(gid)); }
+   }
+   for (auto &kv : peers) { out.peers.push_back(kv.second); }
+   // pass 2: fill the tables
+   for (int lz = 0; lz < nlz; lz++)
+   {
+      for (int ly = 0; ly < nly; ly++)
+      {
+         for (int lx = 0; lx < nlx; lx++)
+         {
+            const int e = lx + nlx * (ly + nly * lz);
+            for (int s = 0; s < 27; s++)
+            {
+               const int o[3] = {s % 3 - 1, (s / 3) % 3 - 1, s / 9 - 1};
+               bool ok = true;
+               const int g[3] = {wrap(out.lo[0] + lx + o[0], ok), wrap(out.lo[1] + ly + o[1], ok),
+                                 wrap(out.lo[2] + lz + o[2], ok)};
+               if (!ok) { continue; }
+               int idx;
+               const int l[3] = {g[0] - out.lo[0], g[1] - out.lo[1], g[2] - out.lo[2]};
+               if (l[0] >= 0 && l[0] < nlx && l[1] >= 0 && l[1] < nly && l[2] >= 0 && l[2] < nlz)
+               {
+                  idx = l[0] + nlx * (l[1] + nly * l[2]);
+               }
+               else
+               {
+                  const int owner = owner_1d(0, g[0]) + cfg.px * (owner_1d(1, g[1]) + cfg.py * owner_1d(2, g[2]));
+                  const long long gid = g[0] + (long long)N * (g[1] + (long long)N * g[2]);
+                  idx = ne + ghost_slot.at({owner, gid});
+               }
+               out.stencil27[(size_t)e * 27 + s] = idx;
+            }
+            // face neighbours are the six axis entries of the stencil
+            const int fs[6] = {12, 14, 10, 16, 4, 22};
+            for (int f = 0; f < 6; f++) { out.face_nbr[(size_t)e * 6 + f] = out.stencil27[(size_t)e * 27 + fs[f]]; }
+         }
+      }
+   }
+   return "";
+}
+
+} // namespace remhos

@@ -1,0 +1,62 @@
+// Host-side setup of a Remhos case on a tensor-lattice mesh: what remhos() does between
+// option parsing and the time loop (remhos.cpp:442-584, 878-884), re-stated without MFEM for
+// the reference's benchmark meshes, plus the box partition that stands
+// in for ParMesh(comm, mesh, partitioning) (remhos.cpp:459-463).
+#pragma once
+#include <string>
+#include <vector>
+
+namespace remhos
+{
+
+struct CaseConfig
+{
+   std::string mesh = "periodic-cube"; // -m   (name of a data/*.mesh lattice)
+   int rs = 1;                         // -rs
+   int order = 3;                      // -o
+   int problem = 10;                   // -p
+   double dt = -1.0;                   // -dt  (< 0: CFL rule, remhos.cpp:538-553)
+   double t_final = 0.5;               // -tf
+   int max_steps = -1;                 // -ms
+   int lo_type = 5;                    // -lo  (4 or 5)
+   int px = 1, py = 1, pz = 1;         // box partition of the element lattice
+   int rank = 0;
+};
+
+// neighbour rank in the halo exchange: which owned elements it needs, which ghost slots it fills
+struct Peer
+{
+   int rank;
+   std::vector<int> send_elems; // local indices of owned elements, ascending global id
+   std::vector<int> recv_slots; // ghost slot indices (0-based within the ghost block), ascending global id
+};
+
+struct CaseData
+{
+   int order = 0, exec_mode = 0, ndof = 0;
+   int ne_owned = 0, ne_ghost = 0;
+   long long ne_global = 0;
+   int n[3] = {0, 0, 0};   // global elements per direction
+   int lo[3] = {0, 0, 0};  // first owned element per direction
+   int nl[3] = {0, 0, 0};  // owned elements per direction
+   bool periodic = false;
+   double bb_min[3], bb_max[3];
+   double dt = 0.0;
+   std::vector<double> x0;          // [ne_owned][3][27]
+   std::vector<double> vel;         // [ne_owned][3][27]
+   std::vector<double> u0;          // [ne_owned][ndof]
+   std::vector<double> subcell_vel; // [ne_owned][3][ndof] (lo 4 only)
+   std::vector<int> face_nbr;       // [ne_owned][6]
+   std::vector<int> stencil27;      // [ne_owned][27]
+   std::vector<long long> owned_gid, ghost_gid;
+   std::vector<Peer> peers;
+};
+
+// problem definitions (remhos.cpp:2001-2120, 2201-2355)
+void velocity_function(int problem, const double *bb_min, const double *bb_max, const double x[3], double v[3]);
+double u0_function(int problem, const double *bb_min, const double *bb_max, const double x[3]);
+
+// returns an empty string on success, an error message otherwise
+std::string build_case(const CaseConfig &cfg, CaseData &out);
+
+} // namespace remhos

@@ -1,0 +1,133 @@
+"""RK3-SSP stage loop of one rank through the C ABI, with the halo exchange of multi-rank runs.
+
+Everything numeric is a HIP kernel behind include/rmh.h; torch supplies device buffers, the
+stream and torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
+tests).  Stage sequence = AdvectionOperator::Mult (remhos.cpp:1596-1916) inside
+RK3SSPSolver::Step [MFEM]; per stage ONE neighbour exchange carries, for every element a
+neighbour rank needs, its ndof values of u (ParGridFunction::ExchangeFaceNbrData,
+remhos_ho.cpp:122) plus its min/max (the GroupCommunicator min/max of remhos_tools.cpp:461-466).
+"""
+from __future__ import annotations
+
+import torch
+
+from .capi import Context
+
+
+class Stepper:
+    def __init__(self, lib, case, device="cuda:0", dist=None, fused=True):
+        self.case = case
+        self.dev = torch.device(device)
+        self.dist = dist if (dist is not None and case.peers) else None
+        self.fused = fused
+        dev_index = self.dev.index or 0
+        self.ctx = Context(lib, order=case.order, exec_mode=case.exec_mode, x0=case.x0, vel=case.vel,
+                           face_nbr=case.face_nbr, stencil27=case.stencil27, ne_ghost=case.ne_ghost,
+                           subcell_vel=case.subcell_vel, device=dev_index if self.dev.type == "cuda" else 0)
+        if self.dev.type == "cuda":
+            self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        ne, nd, ng = case.ne_owned, case.ndof, case.ne_ghost
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.x = torch.from_numpy(case.u0).to(self.dev).contiguous()
+        self.y = torch.empty_like(self.x)
+        self.k = torch.empty_like(self.x)
+        if not fused:
+            self.du_lo = torch.empty_like(self.x)
+            self.umin = torch.empty_like(self.x)
+            self.umax = torch.empty_like(self.x)
+            self.xe_min = torch.empty(ne, **f64)
+            self.xe_max = torch.empty(ne, **f64)
+            self.m = torch.empty_like(self.x)
+        self.t = 0.0
+        self.dt = case.dt
+        # ghost storage and exchange plan
+        self.ug = torch.zeros(max(ng, 1), nd, **f64)
+        self.gmin = torch.zeros(max(ng, 1), **f64)
+        self.gmax = torch.zeros(max(ng, 1), **f64)
+        if ng:
+            self.ctx.set_ghost_u(self.ug)
+            self.ctx.set_ghost_minmax(self.gmin, self.gmax)
+        self.plan = []
+        for rank, send, recv in case.peers:
+            s = torch.from_numpy(send.astype("int64")).to(self.dev)
+            r = torch.from_numpy(recv.astype("int64")).to(self.dev)
+            sb = torch.empty(len(send), nd + 2, **f64)
+            rb = torch.empty(len(recv), nd + 2, **f64)
+            self.plan.append((rank, s, r, sb, rb))
+
+    # -- halo exchange: neighbour all-to-all of packed [u | min | max] rows ---------------------
+    def exchange(self, u):
+        if not self.plan:
+            return
+        nd = self.case.ndof
+        ops = []
+        for rank, s, r, sb, rb in self.plan:
+            rows = u.index_select(0, s)
+            sb[:, :nd] = rows
+            sb[:, nd] = rows.amin(dim=1)
+            sb[:, nd + 1] = rows.amax(dim=1)
+        if self.dist is None:
+            raise RuntimeError("this rank has neighbour ranks but no torch.distributed group was given")
+        for rank, s, r, sb, rb in self.plan:
+            ops.append(self.dist.P2POp(self.dist.isend, sb, rank))
+            ops.append(self.dist.P2POp(self.dist.irecv, rb, rank))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        for rank, s, r, sb, rb in self.plan:
+            self.ug.index_copy_(0, r, rb[:, :nd])
+            self.gmin.index_copy_(0, r, rb[:, nd])
+            self.gmax.index_copy_(0, r, rb[:, nd + 1])
+
+    # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
+    def stage(self, u, t, dt, x_base, a, b, out):
+        c = self.ctx
+        self.exchange(u)
+        c.setup(t)
+        c.ho_apply(u, self.k)
+        if self.fused:
+            c.limit_fused(u, self.k, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
+            return
+        # the reference's call sequence (remhos.cpp:1815-1831)
+        c.compute_lumped_mass(t, self.m)
+        c.lo_massavg(u, self.k, dt, self.du_lo)
+        c.elem_minmax(u, self.xe_min, self.xe_max)
+        c.bounds(self.xe_min, self.xe_max, self.umin, self.umax)
+        du = torch.empty_like(u)
+        c.fct_clipscale(u, self.m, self.k, self.du_lo, self.umin, self.umax, dt, du)
+        y = u + dt * du
+        if x_base is None:
+            out.copy_(b * y)
+        else:
+            out.copy_(a * x_base + b * y)
+
+    def step(self, dt):
+        """RK3SSPSolver::Step: stage times t, t+dt, t+dt/2."""
+        x, y, t = self.x, self.y, self.t
+        self.stage(x, t, dt, None, 0.0, 1.0, y)
+        self.stage(y, t + dt, dt, x, 0.75, 0.25, y)
+        self.stage(y, t + dt / 2, dt, x, 1.0 / 3.0, 2.0 / 3.0, x)
+        self.t = t + dt
+
+    def run(self, max_steps=-1, t_final=None):
+        """time loop of remhos.cpp:1146-1296"""
+        if t_final is None:
+            t_final = 1.0 if self.case.exec_mode == 1 else self.case.cfg.t_final
+        ti, done = 0, False
+        while not done:
+            dt_real = min(self.dt, t_final - self.t)
+            self.step(dt_real)
+            ti += 1
+            done = self.t >= t_final - 1e-8 * self.dt
+            if ti == max_steps:
+                done = True
+        return ti
+
+    def local_mass_and_max(self, t=None):
+        """sum_i m_i u_i with the lumped mass at pseudo-time t, and max u (remhos.cpp:1382-1414)."""
+        m = torch.empty_like(self.x)
+        tt = self.t if t is None else t
+        self.ctx.compute_lumped_mass(tt if self.case.exec_mode == 1 else 0.0, m)
+        return float((m * self.x).sum()), float(self.x.max())
+
+    def close(self):
+        self.ctx.close()

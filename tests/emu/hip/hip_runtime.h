@@ -69,6 +69,8 @@ inline const char *hipGetErrorString(hipError_t) { return "hip emulation error";
 inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
 inline hipError_t hipFree(void *p) { std::free(p); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }

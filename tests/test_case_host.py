@@ -1,0 +1,79 @@
+"""Host logic (C++ case builder, box partition, halo lists) against the oracle's lattice."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle.remhos_oracle import Config, Remhos
+from remhos_amd.case import Case, load_host_library, make_config
+from tests.helpers import layout_from_oracle
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return load_host_library()
+
+
+CASES = [
+    ("cube01_hex", 1, 2, 10, -1.0, 0.5),
+    ("periodic-cube", 1, 3, 10, -1.0, 0.5),
+    ("periodic-cube", 1, 2, 0, 0.015, 2.0),
+]
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,dt,tf", CASES)
+def test_case_matches_oracle(lib, mesh, rs, p, prob, dt, tf):
+    r = Remhos(Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=dt, t_final=tf, lo=4))
+    x0, vel, nbr, st = layout_from_oracle(r)
+    c = Case(lib, make_config(mesh, rs, p, prob, dt, tf, lo_type=4))
+    assert c.dt == r.dt
+    assert np.array_equal(c.x0, x0)
+    assert np.abs(c.vel - vel).max() < 1e-15
+    assert np.abs(c.u0 - r.u).max() < 1e-15
+    assert np.array_equal(c.face_nbr, nbr)
+    assert np.array_equal(c.stencil27, st)
+    if r.exec_mode == 1:
+        assert np.abs(c.subcell_vel - r.Vs.transpose(0, 2, 1)).max() < 1e-15
+
+
+@pytest.mark.parametrize("mesh,rs,part", [("periodic-cube", 1, (2, 1, 1)), ("periodic-cube", 1, (2, 2, 2)),
+                                          ("cube01_hex", 2, (2, 2, 1)), ("cube01_hex", 1, (3, 1, 2))])
+def test_partition_is_consistent(lib, mesh, rs, part):
+    """Union of the blocks = the global lattice; stencils agree through global ids; send and
+    receive lists of neighbouring ranks match element for element."""
+    nr = part[0] * part[1] * part[2]
+    g = Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5))
+    cases = [Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5, part=part, rank=k)) for k in range(nr)]
+    assert sum(c.ne_owned for c in cases) == g.ne_owned
+    all_gid = np.concatenate([c.owned_gid for c in cases])
+    assert np.array_equal(np.sort(all_gid), np.arange(g.ne_owned))
+    for c in cases:
+        assert c.dt == g.dt
+        gid_of_local = np.concatenate([c.owned_gid, c.ghost_gid])
+        # geometry and initial data are the rows of the global case
+        assert np.array_equal(c.x0, g.x0[c.owned_gid])
+        assert np.array_equal(c.vel, g.vel[c.owned_gid])
+        assert np.array_equal(c.u0, g.u0[c.owned_gid])
+        # stencil in global numbering equals the global stencil
+        st = np.where(c.stencil27 >= 0, gid_of_local[np.maximum(c.stencil27, 0)], -1)
+        assert np.array_equal(st, g.stencil27[c.owned_gid])
+        fn = np.where(c.face_nbr >= 0, gid_of_local[np.maximum(c.face_nbr, 0)], -1)
+        assert np.array_equal(fn, g.face_nbr[c.owned_gid])
+        # every ghost is filled by exactly one peer
+        filled = np.concatenate([r for _, _, r in c.peers]) if c.peers else np.zeros(0, np.int32)
+        assert np.array_equal(np.sort(filled), np.arange(c.ne_ghost))
+    for a, b in itertools.permutations(range(nr), 2):
+        pa = {rk: (s, r) for rk, s, r in cases[a].peers}
+        pb = {rk: (s, r) for rk, s, r in cases[b].peers}
+        if b in pa:
+            assert a in pb
+            send_gid = cases[a].owned_gid[pa[b][0]]
+            recv_gid = cases[b].ghost_gid[pb[a][1]]
+            assert np.array_equal(send_gid, recv_gid)
+
+
+def test_bad_config_is_reported(lib):
+    with pytest.raises(RuntimeError, match="unknown lattice mesh"):
+        Case(lib, make_config("star-q2", 1, 2, 10))
+    with pytest.raises(RuntimeError, match="order"):
+        Case(lib, make_config("cube01_hex", 1, 9, 10))

@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: world_size-2 (and 4) gloo runs of the box-partitioned stepper must
+reproduce the single-rank result -- same partition / halo-list / exchange code the GPU path uses
+with the nccl (RCCL) backend.  The reference's suite checks the same rank-count invariance
+(autotest/test.sh with mpirun -np N against one baseline)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(tmp_path, mesh, rs, p, prob, steps, part):
+    world = part[0] * part[1] * part[2]
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mesh, str(rs), str(p),
+             str(prob), str(steps)] + [str(k) for k in part], env=env))
+    for pr in procs:
+        assert pr.wait(timeout=900) == 0
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    gid = np.concatenate([d["gid"] for d in parts])
+    u = np.concatenate([d["u"] for d in parts])
+    order = np.argsort(gid)
+    return u[order], float(parts[0]["mass"][0]), float(parts[0]["umax"][0])
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,part", [("cube01_hex", 1, 1, 10, (2, 1, 1)), ("periodic-cube", 0, 2, 10, (1, 2, 1)),
+                                                 ("cube01_hex", 1, 1, 10, (2, 2, 1))])
+def test_rank_count_invariance(tmp_path, mesh, rs, p, prob, part):
+    from oracle.remhos_oracle import Config, Remhos
+
+    steps = 1
+    d1 = tmp_path / "n1"
+    dn = tmp_path / "nn"
+    d1.mkdir()
+    dn.mkdir()
+    u1, mass1, max1 = _run(d1, mesh, rs, p, prob, steps, (1, 1, 1))
+    un, massn, maxn = _run(dn, mesh, rs, p, prob, steps, part)
+    # identical arithmetic per element: the partition may not change a single bit of the field
+    assert np.array_equal(u1, un)
+    assert max1 == maxn
+    assert abs(mass1 - massn) < 1e-15  # different summation order of the all-reduce
+    # and both equal the oracle
+    r = Remhos(Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=-1.0, t_final=0.5, lo=5, max_steps=steps))
+    out = r.run()
+    assert np.abs(un - r.u).max() < 1e-13
+    assert abs(massn - out["mass"]) < 1e-14

