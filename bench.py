@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the Remhos RK stage hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one RK3-SSP time step = 3 RK stages, each stage = HO (PA convection + upwind faces +
+local mass solve) -> LO (mass-based average) -> overlap bounds -> ClipScale FCT -> RK update on
+the whole mesh.  Metric (BASELINE.json): MDOFs x RK-stage / s = 1e-6 * global dofs * 3K / T,
+T = max over ranks of the wall time of K steps (everything included: halo exchange, mass solve,
+bounds, RK update), inputs resident in HBM.
+
+Workload (config.workload): BASELINE.json configs[1] -- 3D periodic-cube remap (problem 10,
+Taylor-Green mesh motion, erfc bump), p = 3, -pa -ho 3 -lo 5 -fct 2 (the combination the reference
+itself allows on a device, remhos.cpp:391-397), refined to --rs levels (default 5: 884 736 hex,
+56.6 M dofs).  For N > 1 the SAME global mesh is box-partitioned over the ranks (strong scaling);
+each stage does one RCCL neighbour exchange of ghost-element values.
+
+The same JSON line carries `roofline` for the dominant kernel (ho_kernel, duration from HIP events
+on the kernel's own stream inside the timed region) and `cpu_baseline` (the oracle timed on the
+host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+PART = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+
+
+def ho_alg_bytes_per_element(p):
+    """Algorithmic HBM bytes of the HO kernel per element (phase 1,
+    matrix-free variant): read u D^3, neighbour traces 6 D^2, Q2 nodes of x0 and v 2*81;
+    write du_HO D^3."""
+    D = p + 1
+    return 8 * (2 * D**3 + 6 * D**2 + 162)
+
+
+def stage_alg_bytes_per_dof(p):
+    """SURVEY.md 8(d) matrix-free model for the whole stage: 8*(8 D^3 + 6 D^2 + 162 + 6 p^3)/D^3."""
+    D = p + 1
+    return 8.0 * (8 * D**3 + 6 * D**2 + 162 + 6 * p**3) / D**3
+
+
+def cpu_baseline(order, budget_s=20.0):
+    """Time the CPU oracle (numpy restatement of the reference algorithm, oracle/) on a bounded
+    sample of the same workload: periodic-cube remap, same order, refined once (216 hex)."""
+    import numpy as np
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    from oracle.remhos_oracle import Config, Remhos
+
+    def run():
+        r = Remhos(Config(mesh="periodic-cube", rs=1, order=order, problem=10, dt=-1.0, t_final=0.5, lo=5))
+        ndofs = r.u.size
+        r.step(r.dt)  # warm-up (first-touch, einsum paths)
+        stages, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and r.t < 1.0 - r.dt:
+            r.step(r.dt)
+            stages += 3
+        el = time.perf_counter() - t0
+        return ndofs, stages, el
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            ndofs, stages, el = run()
+    else:
+        ndofs, stages, el = run()
+    return {
+        "value": 1e-6 * ndofs * stages / el,
+        "unit": "MDOFs*RK-stage/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/remhos_oracle.py (numpy, 1 thread): periodic-cube -rs 1 -o {order} -p 10 -lo 5 -fct 2, "
+                  f"{ndofs} dofs, {stages} RK stages in {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rs", type=int, default=5)
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--mesh", default="periodic-cube")
+    ap.add_argument("--problem", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="reference call sequence instead of the fused limiter")
+    args = ap.parse_args()
+
+    import torch
+
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import Case, bind_driver, make_config
+    from remhos_amd.stepper import Stepper
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus not in PART:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the remhos_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    lib = bind_driver(load_library())
+    cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, part=PART[args.gpus], rank=rank)
+    t0 = time.perf_counter()
+    case = Case(lib, cfg)
+    st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused)
+    setup_s = time.perf_counter() - t0
+    global_dofs = case.ne_global * case.ndof
+    dt = case.dt
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st.step(dt)
+    st.ctx.last_cg_iters()  # reset
+    st.ctx.enable_timers(True)
+    st.ctx.reset_timers()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.step(dt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tim = st.ctx.timers()
+    st.ctx.enable_timers(False)
+    cg_iters = st.ctx.last_cg_iters()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    stages = 3 * args.steps
+    value = 1e-6 * global_dofs * stages / elapsed
+    # sanity of the state after the run: mass conservation and bounds (not timed)
+    mass, umax = st.local_mass_and_max()
+    if dist is not None:
+        red = torch.tensor([mass], dtype=torch.float64, device=dev)
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        mass = float(red[0])
+
+    if rank == 0:
+        ho_avg_s = tim[0] / stages
+        ho_bytes = ho_alg_bytes_per_element(args.order) * case.ne_owned
+        achieved = ho_bytes / ho_avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{args.mesh}-rs{args.rs}-o{args.order}-n{args.gpus}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MDOFs*RK-stage/s, 3D hex remap",
+            "value": value,
+            "unit": "MDOFs*RK-stage/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.mesh} -rs {args.rs} -o {args.order} -p {args.problem} remap, -pa -ho 3 -lo 5 -fct 2, RK3-SSP "
+                            f"(BASELINE configs[1]); {case.ne_global} hex, {global_dofs} dofs",
+                "global_dofs": global_dofs,
+                "elements": case.ne_global,
+                "partition": "x".join(str(k) for k in PART[args.gpus]),
+                "limiter": "reference call sequence" if args.unfused else "fused (LO avg + bounds + ClipScale + RK update)",
+                "dt": dt,
+                "mass_cg_max_iters": cg_iters,
+                "final_mass": mass,
+                "max_value": umax,
+                "setup_s": setup_s,
+            },
+            "roofline": {
+                "kernel": f"ho_kernel<{args.order},0>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": 1e3 * ho_avg_s,
+                "alg_bytes_per_launch": ho_bytes,
+                "note": "FP64-VALU-bound at p=3 in matrix-free form (geometry recomputed per stage); see DESIGN.md",
+            },
+            "buckets_s": {"ho_rhs_plus_inv": tim[0], "lo": tim[2], "fct_fused_limiter": tim[3]},
+            "stage_roofline": {
+                "alg_bytes_per_dof": stage_alg_bytes_per_dof(args.order),
+                "achieved_GBs": value * 1e6 * stage_alg_bytes_per_dof(args.order) / 1e9,
+                "frac_of_hbm_peak": value * 1e6 * stage_alg_bytes_per_dof(args.order) / 1e9 / (HBM_PEAK_GBS * args.gpus),
+            },
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.order)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    st.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""Whole runs on the GPU through the product path (C++ case builder + C ABI kernels + stepper /
+C++ driver) against the REFERENCE's own known-answer values and against the oracle.
+
+Reference values: remhos_tests.cpp:63-68 (ctest #3), :81-86 (ctest #7); tolerance of the
+reference's own check is 10 eps relative to 1+|x| (remhos_tests.cpp:13-23); ctest #7 was produced
+with the reference's CG mass solve (abs-tol 1e-8), which an exact solve matches to 1.4e-14.
+BASELINE.json target: final mass within 1e-12 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+
+    assert torch.cuda.is_available()
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+
+    return bind_driver(load_library())
+
+
+KAT = [
+    # name, config kwargs, reference final mass, relative tolerance
+    ("ctest3", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=-1.0, t_final=0.5, max_steps=5), 0.11972857593296446, 1e-13),
+    ("ctest7", dict(mesh="cube01_hex", rs=3, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=1), 0.11601536511552431, 1e-12),
+]
+
+
+@pytest.mark.parametrize("name,kw,mass_ref,rtol", KAT, ids=[k[0] for k in KAT])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_reference_final_mass(lib, name, kw, mass_ref, rtol, fused):
+    from remhos_amd.case import RmhdResult, make_config
+
+    cfg = make_config(fused=fused, **kw)
+    res = RmhdResult()
+    assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, lib.rmhd_last_error()
+    assert res.steps == kw["max_steps"]
+    assert abs(res.final_mass - mass_ref) <= rtol * abs(mass_ref), (res.final_mass, mass_ref)
+    assert 0 < res.cg_iters_max < 100
+    assert res.fom_wall > 0
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,steps", [("periodic-cube", 1, 3, 10, 4), ("cube01_hex", 2, 2, 10, 3),
+                                                  ("periodic-cube", 1, 2, 0, 6), ("cube01_hex", 1, 4, 10, 2)])
+def test_run_vs_oracle(lib, mesh, rs, p, prob, steps):
+    """final mass, max and the field itself after several RK3 steps: GPU path vs CPU oracle.
+    Tolerances: mass 1e-12 relative (BASELINE target), field 1e-10 in max norm (the error of
+    each local mass solve is cond-limited, see tests/test_gpu_parity.py)."""
+    import torch
+
+    from oracle.remhos_oracle import Config, Remhos
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    dt, tf = (-1.0, 0.5) if prob >= 10 else (0.01, 0.5)
+    r = Remhos(Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=dt, t_final=tf, lo=5, max_steps=steps))
+    out = r.run()
+    st = Stepper(lib, Case(lib, make_config(mesh, rs, p, prob, dt, tf)), device="cuda:0", fused=True)
+    n = st.run(max_steps=steps)
+    torch.cuda.synchronize()
+    assert n == out["steps"]
+    mass, umax = st.local_mass_and_max()
+    assert abs(mass - out["mass"]) <= 1e-12 * abs(out["mass"])
+    assert abs(umax - out["max"]) <= 1e-10
+    err = np.abs(st.x.cpu().numpy() - r.u)
+    assert err.max() < 1e-10
+    # L1 / L2 / Linf of u_GPU - u_CPU, lumped-mass weighted (SURVEY 8(d) error norms)
+    l1 = float((r.m * err).sum())
+    l2 = float(np.sqrt((r.m * err**2).sum()))
+    assert l1 < 1e-11 and l2 < 1e-11
+    st.close()
