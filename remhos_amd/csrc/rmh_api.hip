@@ -2,8 +2,10 @@
 // HIP-event stopwatches.  See include/rmh.h for the contract of every entry point.
 #include "../../include/rmh.h"
 #include "rmh_kernels.hpp"
+#include "rmh_ho2.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,6 +50,7 @@ struct rmh_ctx
    double rel_tol = 1e-14, abs_tol = 0.0;
    int max_iter = 100;
    bool ho_done = false;
+   int ho_variant = 2; // 2: batched kernel (rmh_ho2.hpp), 1: one element per workgroup (rmh_kernels.hpp)
    // stopwatches (TimingData, remhos_tools.hpp:52-64)
    bool timers_on = false;
    double tacc[4] = {0, 0, 0, 0};
@@ -142,7 +145,15 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.rel2 = c->rel_tol * c->rel_tol;
    a.abs2 = c->abs_tol * c->abs_tol;
    a.max_iter = c->max_iter;
-   hipLaunchKernelGGL((ho_kernel<P, MODE>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, a);
+   if (MODE == 0 && c->ho_variant == 2)
+   {
+      constexpr int NB = K2Cfg<P>::NB;
+      hipLaunchKernelGGL((ho_kernel2<P>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+   }
+   else
+   {
+      hipLaunchKernelGGL((ho_kernel<P, MODE>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, a);
+   }
    RMH_HIP(hipGetLastError());
    return 0;
 }
@@ -189,6 +200,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->exec_mode = L->exec_mode;
    c->device = L->device;
    c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
+   if (const char *v = std::getenv("RMH_HO_KERNEL")) { c->ho_variant = std::atoi(v) == 1 ? 1 : 2; }
    const size_t ne = c->ne;
    int rc = 0;
    if ((rc = upload(&c->d_x0, L->x0, ne * 81))) { delete c; return rc; }

@@ -1,0 +1,705 @@
+// HO kernel, second generation: element batching.
+//
+// Same mathematics as ho_kernel (rmh_kernels.hpp) -- du = M^-1 (K_vol + K_face) u, lumped mass,
+// element extrema -- but organised for wave64 occupancy of the "column" phases:
+//
+//   * a workgroup of 256 threads (4 wavefronts) works on NB = floor(256 / Q^2) elements at once
+//     (p = 3: Q = 6, 36 quadrature columns per element, NB = 7 -> 252 of 256 lanes busy; the
+//     one-element-per-wavefront kernel keeps 36 of 64 busy);
+//   * thread roles per phase:  column (eb, qx, qy)  |  face row (eb, face, q1)  |  dof (eb, i)
+//     | flat task loops over small intermediates;
+//   * the 1-D basis tables are read from global memory with compile-time indices, i.e. through
+//     the scalar cache into SGPRs and used as scalar FMA operands; only lane-dependent rows sit
+//     in VGPRs.  LDS holds element data only;
+//   * faces are sum-factorised (one thread per face row of quadrature points, geometry from the
+//     9 face nodes) instead of evaluated point by point;
+//   * the right-hand side is tested directly with the Gauss-Legendre nodal basis (the basis of
+//     the local mass solve), so no forward change of basis is needed; PCG vectors live in
+//     registers of the dof threads, only the search direction goes through LDS.
+//
+// Reference semantics: LocalInverseHOSolver::CalcHOSolution PA branch (remhos_ho.cpp:119-128),
+// K_HO = ConvectionIntegrator + transposed DGTraceIntegrator (remhos.cpp:646-678), DGMassInverse
+// (remhos_ho.cpp:79-80), lumped mass M_HO*1 (remhos.cpp:1632).
+#pragma once
+#include "rmh_kernels.hpp"
+
+namespace rmh
+{
+
+template <int P>
+struct K2Cfg : TabLayout<P>
+{
+   using T = TabLayout<P>;
+   static constexpr int D = T::D, Q = T::Q;
+   static constexpr int D2 = D * D, D3 = D * D * D, Q2 = Q * Q;
+   static constexpr int NT = 256;
+   static constexpr int NB = NT / Q2;                 // elements per workgroup
+   static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
+   // per-element LDS regions (doubles)
+   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+   static constexpr int S2 = D2 + 1;                      // padded row stride of U1 / R2 (bank conflicts)
+   static constexpr int R0 = cmax(9 * Q * 9, 3 * Q2 * D); // T1 -> R3
+   static constexpr int R1 = 3 * Q * S2;                  // U1 -> R2
+   static constexpr int RF = 6 * Q * D;                  // face rows tested along q2
+   static constexpr int EL = 162 + D3 + 6 * D2 + R0 + R1 + RF + 2 * D3;
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2;
+   static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
+};
+
+// sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r]
+// (the element total, broadcast back to the dof threads)
+template <int P>
+__device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[K2Cfg<P>::DR], double *s_acc)
+{
+   using C = K2Cfg<P>;
+   const int tid = threadIdx.x;
+   __syncthreads();
+   if (tid < C::NB) { s_acc[tid] = 0.0; }
+   __syncthreads();
+#pragma unroll
+   for (int r = 0; r < C::DR; r++)
+   {
+      const int t = tid + r * C::NT;
+      const int eb = t / C::D3;
+      double x = (t < C::NB * C::D3) ? v[r] : 0.0;
+      if (C::WAVE_ALIGNED)
+      {
+#pragma unroll
+         for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); }
+         if ((tid & 63) == 0 && t < C::NB * C::D3) { s_acc[eb] = x; }
+      }
+      else
+      {
+         if (t < C::NB * C::D3) { atomicAdd(&s_acc[eb], x); }
+      }
+   }
+   __syncthreads();
+#pragma unroll
+   for (int r = 0; r < C::DR; r++)
+   {
+      const int t = tid + r * C::NT;
+      out[r] = (t < C::NB * C::D3) ? s_acc[t / C::D3] : 0.0;
+   }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
+{
+   using C = K2Cfg<P>;
+   constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NB = C::NB, DR = C::DR;
+   constexpr int S2 = C::S2;
+   __shared__ double lds[C::LDS_DOUBLES];
+   // per-element regions
+   double *sXV = lds;                  // [NB][162]   X(t) nodes (81) then V nodes (81)
+   double *su = sXV + NB * 162;        // [NB][D3]
+   double *sNb = su + NB * D3;         // [NB][6*D2]
+   double *sR0 = sNb + NB * 6 * D2;    // [NB][R0]    T1, later R3
+   double *sR1 = sR0 + NB * C::R0;     // [NB][R1]    U1, later R2
+   double *sFq = sR1 + NB * C::R1;     // [NB][6*Q*D] face values tested along q2
+   double *sA = sFq + NB * C::RF;      // [NB][D3]    ping
+   double *sB = sA + NB * D3;          // [NB][D3]    pong
+   double *s_acc = sB + NB * D3;       // [NB]
+   int *s_flag = (int *)(s_acc + 4 * NB);
+   double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
+
+   const int tid = threadIdx.x;
+   const int e0 = blockIdx.x * NB;
+   const double *__restrict__ gt = a.tab; // uniform: compile-time indices become scalar loads
+   constexpr int oB = C::oB, oG = C::oG, oL = C::oL, odL = C::odL, oW = C::oW, oBg = C::oBg, oBg2 = C::oBg2,
+                 oCi = C::oCi;
+
+   // ---- phase A: loads ----------------------------------------------------------------------
+   for (int i = tid; i < C::N2; i += NT) { stab[i] = a.tab[i]; }
+   for (int k = tid; k < NB * 81; k += NT)
+   {
+      const int eb = k / 81, i = k % 81;
+      const int e = min(e0 + eb, a.ne_owned - 1);
+      const double x0 = a.x0[(size_t)e * 81 + i];
+      const double v = a.vel[(size_t)e * 81 + i];
+      sXV[eb * 162 + 81 + i] = v;
+      sXV[eb * 162 + i] = a.move ? x0 + a.t * v : x0;
+   }
+   for (int k = tid; k < NB * D3; k += NT)
+   {
+      const int eb = k / D3, i = k % D3;
+      const int e = min(e0 + eb, a.ne_owned - 1);
+      su[k] = a.u[(size_t)e * D3 + i];
+   }
+   for (int k = tid; k < NB * 6 * D2; k += NT)
+   {
+      const int eb = k / (6 * D2), r6 = k % (6 * D2);
+      const int f = r6 / D2, r = r6 % D2;
+      const int i1 = r % D, i2 = r / D;
+      const int c = f >> 1, side = f & 1;
+      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+      const int strc = (c == 0) ? 1 : (c == 1 ? D : D2);
+      const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
+      const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
+      const int e = min(e0 + eb, a.ne_owned - 1);
+      const int nb = a.face_nbr[(size_t)e * 6 + f];
+      double val = 0.0;
+      if (nb >= 0)
+      {
+         const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * D3;
+         val = un[(side ? 0 : P) * strc + i1 * str1 + i2 * str2];
+      }
+      sNb[k] = val;
+   }
+   __syncthreads();
+
+   // ---- phase B: x-contractions of the geometry and of u; face rows -------------------------------
+   // T1[eb][(arr*Q + qx)*9 + n2], arr = 3*comp + kind, kind 0: L.X, 1: dL.X, 2: L.V
+   // pencil tasks (eb, comp, n2): 3 node values in, Q values out per kind; basis entries are
+   // compile-time indexed (scalar operands)
+   for (int k = tid; k < NB * 27; k += NT)
+   {
+      const int eb = k / 27, r = k % 27;
+      const int comp = r / 9, n2 = r % 9;
+      const double *X = sXV + eb * 162 + comp * 27 + 3 * n2;
+      const double x0 = X[0], x1 = X[1], x2 = X[2];
+      const double v0 = X[81], v1 = X[82], v2 = X[83];
+      double *dst = sR0 + eb * C::R0 + (comp * 3) * Q * 9 + n2;
+#pragma unroll
+      for (int q = 0; q < Q; q++)
+      {
+         const double l0 = gt[oL + q * 3], l1 = gt[oL + q * 3 + 1], l2 = gt[oL + q * 3 + 2];
+         const double d0 = gt[odL + q * 3], d1 = gt[odL + q * 3 + 1], d2 = gt[odL + q * 3 + 2];
+         dst[(0 * Q + q) * 9] = l0 * x0 + l1 * x1 + l2 * x2;
+         dst[(1 * Q + q) * 9] = d0 * x0 + d1 * x1 + d2 * x2;
+         dst[(2 * Q + q) * 9] = l0 * v0 + l1 * v1 + l2 * v2;
+      }
+   }
+   // U1[eb][(kind*Q + qx)*S2 + i2], kind 0: B.u, 1: G.u; pencil tasks (eb, i2)
+   for (int k = tid; k < NB * D2; k += NT)
+   {
+      const int eb = k / D2, i2 = k % D2;
+      const double *src = su + eb * D3 + D * i2;
+      double uu[D];
+#pragma unroll
+      for (int ix = 0; ix < D; ix++) { uu[ix] = src[ix]; }
+      double *dst = sR1 + eb * C::R1 + i2;
+#pragma unroll
+      for (int q = 0; q < Q; q++)
+      {
+         double ub = 0.0, ug = 0.0;
+#pragma unroll
+         for (int ix = 0; ix < D; ix++)
+         {
+            ub += gt[oB + q * D + ix] * uu[ix];
+            ug += gt[oG + q * D + ix] * uu[ix];
+         }
+         dst[(0 * Q + q) * S2] = ub;
+         dst[(1 * Q + q) * S2] = ug;
+      }
+   }
+   // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
+   //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
+   // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
+   for (int fr = tid; fr < NB * 6 * Q; fr += NT)
+   {
+      const int eb = fr / (6 * Q), r = fr % (6 * Q);
+      const int f = r / Q, q1 = r % Q;
+      const int c = f >> 1, side = f & 1;
+      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+      const int nc = (c == 0) ? 1 : (c == 1 ? 3 : 9);
+      const int n1 = (c1 == 0) ? 1 : (c1 == 1 ? 3 : 9);
+      const int n2s = (c2 == 0) ? 1 : (c2 == 1 ? 3 : 9);
+      const double *X = sXV + eb * 162 + (side ? 2 * nc : 0);
+      const double *V = X + 81;
+      double L1[3], dL1[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { L1[k] = stab[oL + q1 * 3 + k]; dL1[k] = stab[odL + q1 * 3 + k]; }
+      // contraction along a1 for the three node rows a2
+      double xd[3][3], xl[3][3], vl[3][3]; // [comp][a2]
+#pragma unroll
+      for (int comp = 0; comp < 3; comp++)
+      {
+#pragma unroll
+         for (int a2 = 0; a2 < 3; a2++)
+         {
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int a1 = 0; a1 < 3; a1++)
+            {
+               const double x = X[comp * 27 + a1 * n1 + a2 * n2s];
+               s0 += dL1[a1] * x;
+               s1 += L1[a1] * x;
+               s2 += L1[a1] * V[comp * 27 + a1 * n1 + a2 * n2s];
+            }
+            xd[comp][a2] = s0; xl[comp][a2] = s1; vl[comp][a2] = s2;
+         }
+      }
+      // traces: contraction of (u_nbr - u_own) along i1
+      const int dc = (c == 0) ? 1 : (c == 1 ? D : D2);
+      const int d1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
+      const int d2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
+      const double *uo = su + eb * D3 + (side ? P * dc : 0);
+      const double *un = sNb + eb * 6 * D2 + f * D2;
+      double jr[D];
+#pragma unroll
+      for (int i2 = 0; i2 < D; i2++)
+      {
+         double acc = 0.0;
+#pragma unroll
+         for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * (un[i1 + D * i2] - uo[i1 * d1 + i2 * d2]); }
+         jr[i2] = acc;
+      }
+      const double w1 = stab[oW + q1];
+      double tq[D];
+#pragma unroll
+      for (int k2 = 0; k2 < D; k2++) { tq[k2] = 0.0; }
+#pragma unroll
+      for (int q2 = 0; q2 < Q; q2++)
+      {
+         double t1[3], t2[3], vf[3];
+#pragma unroll
+         for (int comp = 0; comp < 3; comp++)
+         {
+            double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; a2++)
+            {
+               const double L2 = gt[oL + q2 * 3 + a2], dL2 = gt[odL + q2 * 3 + a2];
+               s0 += L2 * xd[comp][a2];
+               s1 += dL2 * xl[comp][a2];
+               s2 += L2 * vl[comp][a2];
+            }
+            t1[comp] = s0; t2[comp] = s1; vf[comp] = s2;
+         }
+         const double nx = t1[1] * t2[2] - t1[2] * t2[1];
+         const double ny = t1[2] * t2[0] - t1[0] * t2[2];
+         const double nz = t1[0] * t2[1] - t1[1] * t2[0];
+         double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
+         if (!side) { vn = -vn; }
+         double jump = 0.0;
+#pragma unroll
+         for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
+         const double val = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2] * jump;
+#pragma unroll
+         for (int k2 = 0; k2 < D; k2++) { tq[k2] += gt[oBg + q2 * D + k2] * val; }
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < D; k2++) { sFq[eb * C::RF + (f * Q + q1) * D + k2] = tq[k2]; }
+   }
+   __syncthreads();
+
+   // ---- phase C: column threads: geometry, grad u, z-leg of the test contractions -------------------
+   const bool col = tid < NB * Q2;
+   const int ceb = col ? tid / Q2 : 0, cc = tid % Q2;
+   const int qx = cc % Q, qy = cc / Q;
+   double wd[Q];
+   double Bgy[D]; // GL basis row of this thread's qy (mass apply)
+   double r0[D], r1[D], r2[D];
+#pragma unroll
+   for (int iz = 0; iz < D; iz++) { r0[iz] = 0; r1[iz] = 0; r2[iz] = 0; Bgy[iz] = 0; }
+#pragma unroll
+   for (int qz = 0; qz < Q; qz++) { wd[qz] = 0; }
+   if (col)
+   {
+      double Ly[3], dLy[3], By[D], Gy[D];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { Ly[k] = stab[oL + qy * 3 + k]; dLy[k] = stab[odL + qy * 3 + k]; }
+#pragma unroll
+      for (int k = 0; k < D; k++)
+      {
+         By[k] = stab[oB + qy * D + k];
+         Gy[k] = stab[oG + qy * D + k];
+         Bgy[k] = stab[oBg + qy * D + k];
+      }
+      const double *T1 = sR0 + ceb * C::R0;
+      double A[3][4][3];
+#pragma unroll
+      for (int comp = 0; comp < 3; comp++)
+      {
+#pragma unroll
+         for (int az = 0; az < 3; az++)
+         {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int ay = 0; ay < 3; ay++)
+            {
+               const int n2 = ay + 3 * az;
+               const double xl = T1[((comp * 3 + 0) * Q + qx) * 9 + n2];
+               const double xd = T1[((comp * 3 + 1) * Q + qx) * 9 + n2];
+               const double vl = T1[((comp * 3 + 2) * Q + qx) * 9 + n2];
+               a0 += Ly[ay] * xd;
+               a1 += dLy[ay] * xl;
+               a2 += Ly[ay] * xl;
+               a3 += Ly[ay] * vl;
+            }
+            A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2; A[comp][3][az] = a3;
+         }
+      }
+      const double *U1 = sR1 + ceb * C::R1;
+      double UB[D], UG[D], UU[D];
+#pragma unroll
+      for (int iz = 0; iz < D; iz++)
+      {
+         double b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+         for (int iy = 0; iy < D; iy++)
+         {
+            const double ub = U1[(0 * Q + qx) * S2 + iy + D * iz];
+            const double ug = U1[(1 * Q + qx) * S2 + iy + D * iz];
+            b0 += By[iy] * ug;
+            b1 += Gy[iy] * ub;
+            b2 += By[iy] * ub;
+         }
+         UB[iz] = b0; UG[iz] = b1; UU[iz] = b2;
+      }
+      const double wxy = stab[oW + qx] * stab[oW + qy];
+#pragma unroll
+      for (int qz = 0; qz < Q; qz++)
+      {
+         double J[3][3], v[3];
+#pragma unroll
+         for (int comp = 0; comp < 3; comp++)
+         {
+            double j0 = 0, j1 = 0, j2 = 0, vv = 0;
+#pragma unroll
+            for (int az = 0; az < 3; az++)
+            {
+               const double Lz = gt[oL + qz * 3 + az], dLz = gt[odL + qz * 3 + az];
+               j0 += Lz * A[comp][0][az];
+               j1 += Lz * A[comp][1][az];
+               j2 += dLz * A[comp][2][az];
+               vv += Lz * A[comp][3][az];
+            }
+            J[comp][0] = j0; J[comp][1] = j1; J[comp][2] = j2; v[comp] = vv;
+         }
+         // adj(J), rows as in remhos_lo.cpp:1168-1180
+         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
+         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
+         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
+         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
+         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+         const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
+         const double w3 = wxy * gt[oW + qz];
+         const double aw = a.alpha * w3;
+         const double D0 = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
+         const double D1 = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
+         const double D2q = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
+         const double wdq = w3 * detJ;
+         wd[qz] = wdq;
+         double gx = 0, gy = 0, gz = 0;
+#pragma unroll
+         for (int iz = 0; iz < D; iz++)
+         {
+            const double Bz = gt[oB + qz * D + iz], Gz = gt[oG + qz * D + iz];
+            gx += Bz * UB[iz];
+            gy += Bz * UG[iz];
+            gz += Gz * UU[iz];
+         }
+         const double g = D0 * gx + D1 * gy + D2q * gz;
+         // test along z: r0: GL nodal basis x (D.grad u); r1: Bernstein x w detJ (lumped mass);
+         //               r2: GL basis squared x w detJ (Jacobi diagonal)
+#pragma unroll
+         for (int iz = 0; iz < D; iz++)
+         {
+            r0[iz] += gt[oBg + qz * D + iz] * g;
+            r1[iz] += gt[oB + qz * D + iz] * wdq;
+            r2[iz] += gt[oBg2 + qz * D + iz] * wdq;
+         }
+      }
+   }
+   __syncthreads(); // R3 overlays T1: every column thread is done with T1
+   if (col)
+   {
+      double *R3 = sR0 + ceb * C::R0;
+#pragma unroll
+      for (int iz = 0; iz < D; iz++)
+      {
+         R3[(0 * Q2 + cc) * D + iz] = r0[iz];
+         R3[(1 * Q2 + cc) * D + iz] = r1[iz];
+         R3[(2 * Q2 + cc) * D + iz] = r2[iz];
+      }
+   }
+   __syncthreads();
+
+   // ---- phase F: y-leg of the three test contractions (R2 overlays U1) ---------------------------------
+   for (int k = tid; k < NB * Q * D; k += NT)
+   {
+      const int eb = k / (Q * D), rem = k % (Q * D);
+      const int q = rem / D, iz = rem % D;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+      {
+         const double *R3 = sR0 + eb * C::R0 + (r * Q2 + q) * D + iz;
+         double in[Q];
+#pragma unroll
+         for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
+         double *dst = sR1 + eb * C::R1 + (r * Q + q) * S2 + D * iz; // [r][qx][iy + D*iz]
+#pragma unroll
+         for (int iy = 0; iy < D; iy++)
+         {
+            double acc = 0.0;
+#pragma unroll
+            for (int jy = 0; jy < Q; jy++)
+            {
+               const double w = (r == 0) ? gt[oBg + jy * D + iy] : (r == 1 ? gt[oB + jy * D + iy] : gt[oBg2 + jy * D + iy]);
+               acc += w * in[jy];
+            }
+            dst[iy] = acc;
+         }
+      }
+   }
+   __syncthreads();
+
+   // ---- phase G: dof threads: x-leg, face contributions ------------------------------------------------
+   double rg[DR], mm[DR], dg[DR];
+   double cBg[DR][Q]; // column ix of the GL basis table of each dof of this thread (x-legs)
+#pragma unroll
+   for (int r = 0; r < DR; r++)
+   {
+      const int t = tid + r * NT;
+      rg[r] = 0.0; mm[r] = 1.0; dg[r] = 1.0;
+#pragma unroll
+      for (int jx = 0; jx < Q; jx++) { cBg[r][jx] = 0.0; }
+      if (t < NB * D3)
+      {
+         const int eb = t / D3, i = t % D3;
+         const int ix = i % D, i2 = i / D;
+         const int idx[3] = {ix, i2 % D, i2 / D};
+         const double *R2 = sR1 + eb * C::R1;
+         double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+         for (int jx = 0; jx < Q; jx++)
+         {
+            cBg[r][jx] = stab[oBg + jx * D + ix];
+            a0 += cBg[r][jx] * R2[(0 * Q + jx) * S2 + i2];
+            a1 += stab[oB + jx * D + ix] * R2[(1 * Q + jx) * S2 + i2];
+            a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * S2 + i2];
+         }
+         // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
+#pragma unroll
+         for (int c = 0; c < 3; c++)
+         {
+            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+            const int kc = idx[c], k1 = idx[c1], k2 = idx[c2];
+#pragma unroll
+            for (int side = 0; side < 2; side++)
+            {
+               const double *F = sFq + eb * C::RF + (2 * c + side) * Q * D + k2;
+               double fa = 0.0;
+#pragma unroll
+               for (int q1 = 0; q1 < Q; q1++) { fa += stab[oBg + q1 * D + k1] * F[q1 * D]; }
+               a0 += stab[C::oBgE + side * D + kc] * fa;
+            }
+         }
+         rg[r] = a0; mm[r] = a1; dg[r] = a2;
+      }
+   }
+
+   // ---- phase I: element-local PCG in the GL nodal basis (DGMassInverse) ----------------------------------
+   double xg[DR], dd[DR], nom[DR], tol[DR], tmp[DR], red[DR];
+   int its[DR];
+#pragma unroll
+   for (int r = 0; r < DR; r++)
+   {
+      xg[r] = 0.0;
+      dd[r] = rg[r] / dg[r];
+      tmp[r] = rg[r] * dd[r];
+      its[r] = 0;
+   }
+   batch_dot<P>(tmp, nom, s_acc);
+#pragma unroll
+   for (int r = 0; r < DR; r++) { tol[r] = fmax(a.rel2 * nom[r], a.abs2); }
+   for (int it = 0; it < a.max_iter; it++)
+   {
+      // any element of the batch still active?
+      __syncthreads();
+      if (tid == 0) { s_flag[0] = 0; }
+      __syncthreads();
+      bool act[DR];
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         act[r] = (tid + r * NT < NB * D3) && (nom[r] > tol[r]);
+         any = any || act[r];
+      }
+      if (any) { s_flag[0] = 1; }
+      __syncthreads();
+      if (!s_flag[0]) { break; }
+      // Ad = M_g d
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         if (t < NB * D3) { sA[t] = dd[r]; }
+      }
+      __syncthreads();
+      for (int k = tid; k < NB * D2; k += NT)
+      {
+         const int eb = k / D2, i2 = k % D2;
+         const double *src = sA + eb * D3 + D * i2;
+         double in[D];
+#pragma unroll
+         for (int ix = 0; ix < D; ix++) { in[ix] = src[ix]; }
+         double *dst = sR1 + eb * C::R1 + i2;
+#pragma unroll
+         for (int q = 0; q < Q; q++)
+         {
+            double acc = 0.0;
+#pragma unroll
+            for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
+            dst[q * S2] = acc;
+         }
+      }
+      __syncthreads();
+      if (col)
+      {
+         const double *M1 = sR1 + ceb * C::R1 + qx * S2;
+         double Y[D];
+#pragma unroll
+         for (int iz = 0; iz < D; iz++)
+         {
+            double acc = 0.0;
+#pragma unroll
+            for (int iy = 0; iy < D; iy++) { acc += Bgy[iy] * M1[iy + D * iz]; }
+            Y[iz] = acc;
+         }
+         double rz[D];
+#pragma unroll
+         for (int iz = 0; iz < D; iz++) { rz[iz] = 0.0; }
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+            double acc = 0.0;
+#pragma unroll
+            for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
+            acc *= wd[qz];
+#pragma unroll
+            for (int iz = 0; iz < D; iz++) { rz[iz] += gt[oBg + qz * D + iz] * acc; }
+         }
+         double *R3 = sR0 + ceb * C::R0 + cc * D;
+#pragma unroll
+         for (int iz = 0; iz < D; iz++) { R3[iz] = rz[iz]; }
+      }
+      __syncthreads();
+      for (int k = tid; k < NB * Q * D; k += NT)
+      {
+         const int eb = k / (Q * D), rem = k % (Q * D);
+         const int q = rem / D, iz = rem % D;
+         const double *R3 = sR0 + eb * C::R0 + q * D + iz;
+         double in[Q];
+#pragma unroll
+         for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
+         double *dst = sR1 + eb * C::R1 + q * S2 + D * iz;
+#pragma unroll
+         for (int iy = 0; iy < D; iy++)
+         {
+            double acc = 0.0;
+#pragma unroll
+            for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
+            dst[iy] = acc;
+         }
+      }
+      __syncthreads();
+      double Ad[DR];
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         Ad[r] = 0.0;
+         tmp[r] = 0.0;
+         if (t < NB * D3)
+         {
+            const int eb = t / D3, i = t % D3;
+            const int ix = i % D, i2 = i / D;
+            const double *R2 = sR1 + eb * C::R1 + i2;
+            double acc = 0.0;
+#pragma unroll
+            for (int jx = 0; jx < Q; jx++) { acc += cBg[r][jx] * R2[jx * S2]; }
+            Ad[r] = acc;
+            tmp[r] = dd[r] * acc;
+         }
+      }
+      batch_dot<P>(tmp, red, s_acc); // den = d.Ad
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const bool ok = act[r] && red[r] > 0.0;
+         const double al = ok ? nom[r] / red[r] : 0.0;
+         if (act[r] && !ok) { tol[r] = INFINITY; } // breakdown: freeze this element
+         xg[r] += al * dd[r];
+         rg[r] -= al * Ad[r];
+         tmp[r] = rg[r] * (rg[r] / dg[r]);
+      }
+      batch_dot<P>(tmp, red, s_acc); // betanom = r.z
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const double z = rg[r] / dg[r];
+         if (act[r])
+         {
+            dd[r] = z + (red[r] / nom[r]) * dd[r];
+            nom[r] = red[r];
+            its[r]++;
+         }
+      }
+   }
+
+   // ---- phase J: back to Bernstein coefficients x_b = Ci (x) Ci (x) Ci x_g, stores --------------------------
+   __syncthreads();
+#pragma unroll
+   for (int r = 0; r < DR; r++)
+   {
+      const int t = tid + r * NT;
+      if (t < NB * D3) { sA[t] = xg[r]; }
+   }
+   __syncthreads();
+   for (int dir = 0; dir < 3; dir++)
+   {
+      const double *in = (dir & 1) ? sB : sA;
+      double *out = (dir & 1) ? sA : sB;
+      const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         if (t < NB * D3)
+         {
+            const int eb = t / D3, i = t % D3;
+            const int k = (i / stride) % D;
+            const double *src = in + eb * D3 + i - k * stride;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; j++) { acc += stab[oCi + k * D + j] * src[j * stride]; }
+            if (dir == 2) { xg[r] = acc; }
+            else { out[t] = acc; }
+         }
+      }
+      __syncthreads();
+   }
+   int itmax = 0;
+#pragma unroll
+   for (int r = 0; r < DR; r++)
+   {
+      const int t = tid + r * NT;
+      if (t < NB * D3 && e0 + t / D3 < a.ne_owned)
+      {
+         a.du[(size_t)e0 * D3 + t] = xg[r];
+         a.m[(size_t)e0 * D3 + t] = mm[r];
+         itmax = max(itmax, its[r]);
+      }
+   }
+   if (tid < NB && e0 + tid < a.ne_owned)
+   {
+      double lmin = INFINITY, lmax = -INFINITY;
+      for (int i = 0; i < D3; i++)
+      {
+         lmin = fmin(lmin, su[tid * D3 + i]);
+         lmax = fmax(lmax, su[tid * D3 + i]);
+      }
+      a.xe_min[e0 + tid] = lmin;
+      a.xe_max[e0 + tid] = lmax;
+   }
+   if ((tid & 63) == 0 && itmax > 0) { atomicMax(a.cg_iters, itmax); }
+}
+
+} // namespace rmh

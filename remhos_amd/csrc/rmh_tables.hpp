@@ -32,6 +32,8 @@ struct TabLayout
    static constexpr int oBg2 = oBg + Q * D; // Bg2 = Bg^2 (Jacobi diagonal)
    static constexpr int oCi = oBg2 + Q * D; // Ci[i*D+k]  inverse of C[k][i] = Bernstein_i(gl node k)
    static constexpr int N = oCi + D * D;
+   static constexpr int oBgE = N;           // BgE[side*D+k] GL nodal basis at xi = 0 / 1
+   static constexpr int N2 = oBgE + 2 * D;  // extended table (ho_kernel2)
 };
 
 inline void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
@@ -145,7 +147,7 @@ inline std::vector<double> make_tables()
 {
    using T = TabLayout<P>;
    constexpr int D = T::D, Q = T::Q;
-   std::vector<double> tab(T::N, 0.0);
+   std::vector<double> tab(T::N2, 0.0);
    std::vector<double> xq, wq, xg, wg;
    gauss_legendre_01(Q, xq, wq);
    gauss_legendre_01(D, xg, wg);
@@ -171,6 +173,11 @@ inline std::vector<double> make_tables()
          tab[T::oBg + q * D + k] = L[k];
          tab[T::oBg2 + q * D + k] = L[k] * L[k];
       }
+   }
+   for (int side = 0; side < 2; side++)
+   {
+      lagrange(xg, (double)side, L, dL);
+      for (int k = 0; k < D; k++) { tab[T::oBgE + side * D + k] = L[k]; }
    }
    // C[k][i] = Bernstein_i(x_gl[k]);  Ci = C^-1 stored as Ci[i*D+k]
    std::vector<double> C(D * D);

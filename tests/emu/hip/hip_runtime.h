@@ -57,11 +57,26 @@ inline double __shfl_xor(double v, int off)
    return r;
 }
 
+using std::max;
+using std::min;
+
+inline double atomicAdd(double *p, double v)
+{
+   unsigned long long *ip = reinterpret_cast<unsigned long long *>(p);
+   unsigned long long old = __atomic_load_n(ip, __ATOMIC_RELAXED), neu;
+   double o;
+   do {
+      std::memcpy(&o, &old, 8);
+      const double n = o + v;
+      std::memcpy(&neu, &n, 8);
+   } while (!__atomic_compare_exchange_n(ip, &old, neu, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+   return o;
+}
+
 inline int atomicMax(int *p, int v)
 {
-   // workgroups run sequentially and only one thread per workgroup calls this in the kernels
-   const int old = *p;
-   *p = std::max(old, v);
+   int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+   while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
    return old;
 }
 
