@@ -172,6 +172,16 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
 
 } // namespace
 
+#ifdef RMH_STAMPS
+extern "C" int rmh_debug_stamps(unsigned long long *out, int reset)
+{
+   unsigned long long z[32] = {0};
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rmh::g_stamps), sizeof(z)) != hipSuccess) { return -1; }
+   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(rmh::g_stamps), z, sizeof(z)) != hipSuccess) { return -1; }
+   return 0;
+}
+#endif
+
 extern "C" {
 
 const char *rmh_last_error(void) { return g_last_error.c_str(); }

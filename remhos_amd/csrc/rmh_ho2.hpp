@@ -43,34 +43,58 @@ struct K2Cfg : TabLayout<P>
    static constexpr int RF = 6 * Q * D;                  // face rows tested along q2
    static constexpr int EL = 162 + D3 + 6 * D2 + R0 + R1 + RF + 2 * D3;
    static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2;
+   static_assert(NB <= 64, "ring buffers sized for NB <= 64");
    static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
 };
 
-// sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r]
-// (the element total, broadcast back to the dof threads)
+// v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add(double v)
+{
+   const int lo = __double2loint(v), hi = __double2hiint(v);
+   const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+   const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+   return v + __hiloint2double(hi2, lo2);
+}
+
+// Sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r] (the
+// element total, broadcast back to the dof threads).  ONE barrier per call: results go through a
+// ring of three LDS buffers (s_acc3[3][NB]); the buffer of the call before the previous one is
+// re-zeroed here, when every thread is provably past its reads.
+//   fast path (p = 3: D3 = 64 dofs = one wavefront per element and round, two rounds): the two
+//   rounds are reduced together with a halving butterfly -- 6 cross-lane steps for both values;
+//   generic path: LDS float64 atomics.
 template <int P>
-__device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[K2Cfg<P>::DR], double *s_acc)
+__device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[K2Cfg<P>::DR], double *s_acc3, int &ring)
 {
    using C = K2Cfg<P>;
    const int tid = threadIdx.x;
-   __syncthreads();
-   if (tid < C::NB) { s_acc[tid] = 0.0; }
-   __syncthreads();
-#pragma unroll
-   for (int r = 0; r < C::DR; r++)
+   double *cur = s_acc3 + ring * C::NB;
+   double *old = s_acc3 + ((ring + 1) % 3) * C::NB; // used two calls ago
+   if (C::WAVE_ALIGNED && C::DR == 2)
    {
-      const int t = tid + r * C::NT;
-      const int eb = t / C::D3;
-      double x = (t < C::NB * C::D3) ? v[r] : 0.0;
-      if (C::WAVE_ALIGNED)
-      {
+      const int lane = tid & 63, wave = tid >> 6;
+      const bool lo = lane < 32;
+      const double v0 = v[0];
+      const double v1 = (tid + C::NT < C::NB * C::D3) ? v[1] : 0.0;
+      // lanes 0..31 gather round 0, lanes 32..63 round 1; then DPP row reductions (VALU, no LDS)
+      double x = (lo ? v0 : v1) + __shfl_xor(lo ? v1 : v0, 32);
+      x = dpp_add<0xB1, 0xF>(x);  // quad_perm [1,0,3,2]
+      x = dpp_add<0x4E, 0xF>(x);  // quad_perm [2,3,0,1]
+      x = dpp_add<0x141, 0xF>(x); // row_half_mirror
+      x = dpp_add<0x140, 0xF>(x); // row_mirror: every lane of a row holds the row total
+      x = dpp_add<0x142, 0xA>(x); // row_bcast:15 into rows 1 and 3: half-wave totals
+      if (lane == 31) { cur[wave] = x; }
+      if (lane == 63 && (C::NT / C::D3 + wave) < C::NB) { cur[C::NT / C::D3 + wave] = x; }
+   }
+   else
+   {
+      if (tid < C::NB) { old[tid] = 0.0; }
 #pragma unroll
-         for (int off = 32; off > 0; off >>= 1) { x += __shfl_xor(x, off); }
-         if ((tid & 63) == 0 && t < C::NB * C::D3) { s_acc[eb] = x; }
-      }
-      else
+      for (int r = 0; r < C::DR; r++)
       {
-         if (t < C::NB * C::D3) { atomicAdd(&s_acc[eb], x); }
+         const int t = tid + r * C::NT;
+         if (t < C::NB * C::D3) { atomicAdd(&cur[t / C::D3], v[r]); }
       }
    }
    __syncthreads();
@@ -78,13 +102,33 @@ __device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[
    for (int r = 0; r < C::DR; r++)
    {
       const int t = tid + r * C::NT;
-      out[r] = (t < C::NB * C::D3) ? s_acc[t / C::D3] : 0.0;
+      out[r] = (t < C::NB * C::D3) ? cur[t / C::D3] : 0.0;
    }
+   ring = (ring + 1) % 3;
 }
+
+#ifdef RMH_STAMPS
+// diagnostic build only: per-phase cycle shares of workgroup-thread 0, accumulated in a debug buffer
+__device__ unsigned long long g_stamps[32];
+#define RMH_STAMP(k)                                                                   \
+   do {                                                                                \
+      if (threadIdx.x == 0)                                                            \
+      {                                                                                \
+         const unsigned long long now_ = clock64();                                    \
+         atomicAdd(&g_stamps[k], now_ - stamp_prev_);                                  \
+         stamp_prev_ = now_;                                                           \
+      }                                                                                \
+   } while (0)
+#else
+#define RMH_STAMP(k)
+#endif
 
 template <int P>
 __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
 {
+#ifdef RMH_STAMPS
+   unsigned long long stamp_prev_ = clock64();
+#endif
    using C = K2Cfg<P>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NB = C::NB, DR = C::DR;
    constexpr int S2 = C::S2;
@@ -98,8 +142,8 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    double *sFq = sR1 + NB * C::R1;     // [NB][6*Q*D] face values tested along q2
    double *sA = sFq + NB * C::RF;      // [NB][D3]    ping
    double *sB = sA + NB * D3;          // [NB][D3]    pong
-   double *s_acc = sB + NB * D3;       // [NB]
-   int *s_flag = (int *)(s_acc + 4 * NB);
+   double *s_acc = sB + NB * D3;       // [3][NB] ring of reduction buffers (+ NB spare)
+   int *s_flag = (int *)(s_acc + 4 * NB); // [4] "any element still active" flags (ring of 2 used)
    double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
 
    const int tid = threadIdx.x;
@@ -110,43 +154,93 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
 
    // ---- phase A: loads ----------------------------------------------------------------------
    for (int i = tid; i < C::N2; i += NT) { stab[i] = a.tab[i]; }
-   for (int k = tid; k < NB * 81; k += NT)
+   if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
+   // all global loads are issued before the first LDS store so that they are in flight together
+   // (neighbour indices first: the trace loads depend on them)
+   constexpr int NLX = (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
+   int nbi[NLN];
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
    {
-      const int eb = k / 81, i = k % 81;
-      const int e = min(e0 + eb, a.ne_owned - 1);
-      const double x0 = a.x0[(size_t)e * 81 + i];
-      const double v = a.vel[(size_t)e * 81 + i];
-      sXV[eb * 162 + 81 + i] = v;
-      sXV[eb * 162 + i] = a.move ? x0 + a.t * v : x0;
-   }
-   for (int k = tid; k < NB * D3; k += NT)
-   {
-      const int eb = k / D3, i = k % D3;
-      const int e = min(e0 + eb, a.ne_owned - 1);
-      su[k] = a.u[(size_t)e * D3 + i];
-   }
-   for (int k = tid; k < NB * 6 * D2; k += NT)
-   {
-      const int eb = k / (6 * D2), r6 = k % (6 * D2);
-      const int f = r6 / D2, r = r6 % D2;
-      const int i1 = r % D, i2 = r / D;
-      const int c = f >> 1, side = f & 1;
-      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-      const int strc = (c == 0) ? 1 : (c == 1 ? D : D2);
-      const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
-      const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
-      const int e = min(e0 + eb, a.ne_owned - 1);
-      const int nb = a.face_nbr[(size_t)e * 6 + f];
-      double val = 0.0;
-      if (nb >= 0)
+      const int k = tid + j * NT;
+      nbi[j] = -1;
+      if (k < NB * 6 * D2)
       {
-         const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * D3;
-         val = un[(side ? 0 : P) * strc + i1 * str1 + i2 * str2];
+         const int eb = k / (6 * D2), f = (k % (6 * D2)) / D2;
+         nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.ne_owned - 1) * 6 + f];
       }
-      sNb[k] = val;
+   }
+   double gx0[NLX], gv[NLX], gu[NLU], gn[NLN];
+#pragma unroll
+   for (int j = 0; j < NLX; j++)
+   {
+      const int k = tid + j * NT;
+      gx0[j] = 0.0; gv[j] = 0.0;
+      if (k < NB * 81)
+      {
+         const int eb = k / 81, i = k % 81;
+         const int e = min(e0 + eb, a.ne_owned - 1);
+         gx0[j] = a.x0[(size_t)e * 81 + i];
+         gv[j] = a.vel[(size_t)e * 81 + i];
+      }
+   }
+#pragma unroll
+   for (int j = 0; j < NLU; j++)
+   {
+      const int k = tid + j * NT;
+      gu[j] = 0.0;
+      if (k < NB * D3)
+      {
+         const int e = min(e0 + k / D3, a.ne_owned - 1);
+         gu[j] = a.u[(size_t)e * D3 + k % D3];
+      }
+   }
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
+   {
+      const int k = tid + j * NT;
+      gn[j] = 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
+      if (k < NB * 6 * D2 && nbi[j] >= 0)
+      {
+         const int r6 = k % (6 * D2);
+         const int f = r6 / D2, r = r6 % D2;
+         const int i1 = r % D, i2 = r / D;
+         const int c = f >> 1, side = f & 1;
+         const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+         const int strc = (c == 0) ? 1 : (c == 1 ? D : D2);
+         const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
+         const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
+         const int nb = nbi[j];
+         const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * D3;
+         gn[j] = un[(side ? 0 : P) * strc + i1 * str1 + i2 * str2]; // the neighbour's opposite face layer
+      }
+   }
+#pragma unroll
+   for (int j = 0; j < NLX; j++)
+   {
+      const int k = tid + j * NT;
+      if (k < NB * 81)
+      {
+         const int eb = k / 81, i = k % 81;
+         sXV[eb * 162 + 81 + i] = gv[j];
+         sXV[eb * 162 + i] = a.move ? gx0[j] + a.t * gv[j] : gx0[j];
+      }
+   }
+#pragma unroll
+   for (int j = 0; j < NLU; j++)
+   {
+      const int k = tid + j * NT;
+      if (k < NB * D3) { su[k] = gu[j]; }
+   }
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
+   {
+      const int k = tid + j * NT;
+      if (k < NB * 6 * D2) { sNb[k] = gn[j]; }
    }
    __syncthreads();
 
+   RMH_STAMP(0);
    // ---- phase B: x-contractions of the geometry and of u; face rows -------------------------------
    // T1[eb][(arr*Q + qx)*9 + n2], arr = 3*comp + kind, kind 0: L.X, 1: dL.X, 2: L.V
    // pencil tasks (eb, comp, n2): 3 node values in, Q values out per kind; basis entries are
@@ -192,6 +286,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          dst[(1 * Q + q) * S2] = ug;
       }
    }
+   RMH_STAMP(1);
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
@@ -283,6 +378,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    }
    __syncthreads();
 
+   RMH_STAMP(2);
    // ---- phase C: column threads: geometry, grad u, z-leg of the test contractions -------------------
    const bool col = tid < NB * Q2;
    const int ceb = col ? tid / Q2 : 0, cc = tid % Q2;
@@ -420,6 +516,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    }
    __syncthreads();
 
+   RMH_STAMP(3);
    // ---- phase F: y-leg of the three test contractions (R2 overlays U1) ---------------------------------
    for (int k = tid; k < NB * Q * D; k += NT)
    {
@@ -449,6 +546,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    }
    __syncthreads();
 
+   RMH_STAMP(4);
    // ---- phase G: dof threads: x-leg, face contributions ------------------------------------------------
    double rg[DR], mm[DR], dg[DR];
    double cBg[DR][Q]; // column ix of the GL basis table of each dof of this thread (x-legs)
@@ -494,9 +592,12 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       }
    }
 
+   RMH_STAMP(5);
    // ---- phase I: element-local PCG in the GL nodal basis (DGMassInverse) ----------------------------------
    double xg[DR], dd[DR], nom[DR], tol[DR], tmp[DR], red[DR];
    int its[DR];
+   int ring = 0;
+   if (tid < 4) { s_flag[tid] = 0; }
 #pragma unroll
    for (int r = 0; r < DR; r++)
    {
@@ -505,26 +606,22 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
    }
-   batch_dot<P>(tmp, nom, s_acc);
-#pragma unroll
-   for (int r = 0; r < DR; r++) { tol[r] = fmax(a.rel2 * nom[r], a.abs2); }
-   for (int it = 0; it < a.max_iter; it++)
+   batch_dot<P>(tmp, nom, s_acc, ring);
+   bool act[DR];
    {
-      // any element of the batch still active?
-      __syncthreads();
-      if (tid == 0) { s_flag[0] = 0; }
-      __syncthreads();
-      bool act[DR];
       bool any = false;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
+         tol[r] = fmax(a.rel2 * nom[r], a.abs2);
          act[r] = (tid + r * NT < NB * D3) && (nom[r] > tol[r]);
          any = any || act[r];
       }
-      if (any) { s_flag[0] = 1; }
-      __syncthreads();
-      if (!s_flag[0]) { break; }
+      if (any) { s_flag[0] = 1; } // visible after the first barrier of the loop
+   }
+   for (int it = 0; it < a.max_iter; it++)
+   {
+      RMH_STAMP(9);
       // Ad = M_g d
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -532,7 +629,9 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          const int t = tid + r * NT;
          if (t < NB * D3) { sA[t] = dd[r]; }
       }
+      if (tid == 0) { s_flag[(it + 1) & 1] = 0; }
       __syncthreads();
+      if (!s_flag[it & 1]) { break; } // no element of the batch is active any more
       for (int k = tid; k < NB * D2; k += NT)
       {
          const int eb = k / D2, i2 = k % D2;
@@ -610,7 +709,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          if (t < NB * D3)
          {
             const int eb = t / D3, i = t % D3;
-            const int ix = i % D, i2 = i / D;
+            const int i2 = i / D;
             const double *R2 = sR1 + eb * C::R1 + i2;
             double acc = 0.0;
 #pragma unroll
@@ -619,7 +718,8 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
             tmp[r] = dd[r] * acc;
          }
       }
-      batch_dot<P>(tmp, red, s_acc); // den = d.Ad
+      RMH_STAMP(8);
+      batch_dot<P>(tmp, red, s_acc, ring); // den = d.Ad
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -630,7 +730,8 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          rg[r] -= al * Ad[r];
          tmp[r] = rg[r] * (rg[r] / dg[r]);
       }
-      batch_dot<P>(tmp, red, s_acc); // betanom = r.z
+      batch_dot<P>(tmp, red, s_acc, ring); // betanom = r.z
+      bool any = false;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -641,9 +742,13 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
             nom[r] = red[r];
             its[r]++;
          }
+         act[r] = act[r] && (nom[r] > tol[r]);
+         any = any || act[r];
       }
+      if (any) { s_flag[(it + 1) & 1] = 1; } // read after the first barrier of the next iteration
    }
 
+   RMH_STAMP(6);
    // ---- phase J: back to Bernstein coefficients x_b = Ci (x) Ci (x) Ci x_g, stores --------------------------
    __syncthreads();
 #pragma unroll
@@ -700,6 +805,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       a.xe_max[e0 + tid] = lmax;
    }
    if ((tid & 63) == 0 && itmax > 0) { atomicMax(a.cg_iters, itmax); }
+   RMH_STAMP(7);
 }
 
 } // namespace rmh

@@ -57,6 +57,35 @@ inline double __shfl_xor(double v, int off)
    return r;
 }
 
+inline int __double2loint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b & 0xffffffffll); }
+inline int __double2hiint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b >> 32); }
+inline double __hiloint2double(int hi, int lo)
+{
+   const unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+   double v;
+   std::memcpy(&v, &b, 8);
+   return v;
+}
+
+// data-parallel primitive (DPP) emulation for the controls the kernels use
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_mask*/, bool /*bc*/)
+{
+   const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane;
+   hipemu::g_xchg[t] = (unsigned)src;
+   __syncthreads();
+   const unsigned row = lane >> 4, inrow = lane & 15u;
+   int srclane = -1;
+   if (ctrl >= 0 && ctrl <= 0xFF) { srclane = (int)((lane & ~3u) + ((ctrl >> (2 * (lane & 3u))) & 3)); } // quad_perm
+   else if (ctrl == 0x140) { srclane = (int)(row * 16 + (15 - inrow)); }                                  // row_mirror
+   else if (ctrl == 0x141) { srclane = (int)(row * 16 + (inrow < 8 ? 7 - inrow : 23 - inrow)); }          // row_half_mirror
+   else if (ctrl == 0x142) { srclane = (row >= 1) ? (int)(row * 16 - 1) : -1; }                           // row_bcast:15
+   else if (ctrl == 0x143) { srclane = (row >= 2) ? 31 : -1; }                                            // row_bcast:31
+   int r = old;
+   if (((row_mask >> row) & 1) && srclane >= 0) { r = (int)hipemu::g_xchg[base + srclane]; }
+   __syncthreads();
+   return r;
+}
+
 using std::max;
 using std::min;
 
