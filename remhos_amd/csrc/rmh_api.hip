@@ -132,6 +132,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.vel = c->d_vel;
    a.face_nbr = c->d_nbr;
    a.tab = c->d_tab;
+   a.subvel = c->d_subvel;
    a.du = du;
    a.m = m;
    a.xe_min = c->d_xe_min;
@@ -314,8 +315,17 @@ int rmh_lo_massavg(rmh_ctx *c, const double *u, const double *du_ho, double dt, 
 
 int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 {
-   (void)c; (void)u; (void)du_lo;
-   return fail(RMH_ERR_INVALID, "rmh_lo_rdsubcell: subcell residual distribution is not implemented yet");
+   if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (c->p < 2) { return fail(RMH_ERR_INVALID, "Subcell schemes require FE order > 2."); } // remhos.cpp:612-616
+   if (!c->d_subvel) { return fail(RMH_ERR_STATE, "rmh_lo_rdsubcell needs rmh_layout.subcell_vel"); }
+   if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
+   EventPair ep;
+   int rc = timer_begin(c, 2, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, rc = (launch_ho<P, 2>(c, u, du_lo, c->d_m, c->t)));
+   if (rc) { return rc; }
+   c->ho_done = true; // lumped mass and element extrema are current
+   return timer_end(c, 2, ep);
 }
 
 int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)

@@ -359,14 +359,16 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
                   }
                   const int i = ix + D * (iy + D * iz);
                   out.u0[(size_t)e * out.ndof + i] = u0_function(problem, bmin, bmax, x);
-                  if (lo4 && remap)
+                  if (lo4)
                   {
-                     // v_sub_gf: instantaneous velocity at the sub-mesh nodes, zero on the
-                     // domain boundary of non-periodic meshes (remhos.cpp:837-853)
+                     // remap: v_sub_gf, the instantaneous velocity at the sub-mesh nodes, zero on the
+                     // domain boundary of non-periodic meshes (remhos.cpp:837-853);
+                     // transport: the advection velocity at the sub-mesh nodes (the subcell midpoint
+                     // value lom.subcellCoeff->Eval of remhos_lo.cpp:1051-1082 is their mean)
                      double v[3];
                      velocity_function(problem, bmin, bmax, x, v);
                      bool bdr = false;
-                     if (!md.periodic)
+                     if (remap && !md.periodic)
                      {
                         const int g[3] = {out.lo[0] + lx, out.lo[1] + ly, out.lo[2] + lz};
                         const int id[3] = {ix, iy, iz};

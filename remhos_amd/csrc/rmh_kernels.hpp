@@ -38,6 +38,7 @@ struct HoArgs
    const double *vel;      // [ne][3][27]
    const int *face_nbr;    // [ne][6]
    const double *tab;      // TabLayout<P>
+   const double *subvel;   // [ne][3][D3] sub-mesh node velocity (lo 4) or null
    double *du;             // [ne][D3]
    double *m;              // [ne][D3] lumped mass
    double *xe_min, *xe_max; // [ne]
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
    using C = KCfg<P>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NW = C::NW;
 
-   __shared__ double tab[C::N];
+   __shared__ double tab[C::N2];
    __shared__ double sX[81], sV[81];
    __shared__ double su[D3];
    __shared__ double sNb[6 * D2];
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
    const double *tW = tab + C::oW, *tBg = tab + C::oBg, *tBg2 = tab + C::oBg2, *tCi = tab + C::oCi;
 
    // ---- phase A: coalesced loads ------------------------------------------------------
-   for (int i = tid; i < C::N; i += NT) { tab[i] = a.tab[i]; }
+   for (int i = tid; i < C::N2; i += NT) { tab[i] = a.tab[i]; }
    for (int i = tid; i < 81; i += NT)
    {
       const double x0 = a.x0[(size_t)e * 81 + i];
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
       sV[i] = v;
       sX[i] = a.move ? x0 + a.t * v : x0;
    }
-   if (MODE == 0)
+   if (MODE != 1)
    {
       for (int i = tid; i < D3; i += NT) { su[i] = a.u[(size_t)e * D3 + i]; }
       // neighbour traces: the D^2 face-layer Bernstein coefficients of the neighbour
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
    }
 
    // ---- phase D: u contracted along x -------------------------------------------------
-   if (MODE == 0)
+   if (MODE != 1)
    {
       for (int k = tid; k < 2 * Q * D2; k += NT)
       {
@@ -296,7 +297,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
    if (col)
    {
       double g[Q];
-      if (MODE == 0)
+      if (MODE != 1)
       {
          double UB[D], UG[D], UU[D];
 #pragma unroll
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
          for (int qz = 0; qz < Q; qz++)
          {
             const double Bz = tB[qz * D + iz];
-            if (MODE == 0) { r0 += Bz * g[qz]; r2 += tBg2[qz * D + iz] * wd[qz]; }
+            if (MODE != 1) { r0 += Bz * g[qz]; r2 += tBg2[qz * D + iz] * wd[qz]; }
             r1 += Bz * wd[qz];
          }
          sR3[(0 * Q2 + qx + Q * qy) * D + iz] = r0;
@@ -441,9 +442,201 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
          }
          jump += tB[q2 * D + i2] * rowacc;
       }
-      sF[k] = s * jump;
+      sF[k] = (MODE == 2) ? s : s * jump;
    }
    __syncthreads();
+   if (MODE == 2)
+   {
+      // ============ subcell residual distribution (PAResidualDistributionSubcell::CalcLOSolution,
+      // remhos_lo.cpp:1620-1802; host form remhos_lo.cpp:111-245) ============================
+      // here s_rhs = z = K_vol u (Bernstein test), s_m = lumped mass, sF = w_q max(0, upw v.n_out)
+      constexpr int NS = P * P * P; // subcells (remhos_tools.cpp:678-734)
+      // [3][D3] sub-mesh node positions at pseudo-time t live in the (unused) PCG vectors
+      auto s_xs3 = [&](int comp) -> double * { return comp == 0 ? s_x : (comp == 1 ? s_r : s_d); };
+      double *s_fl = sR3;            // [6][NS]: fluctP, fluctN, xMax, xMin, swP, swN per subcell
+      static_assert(6 * NS <= 3 * Q2 * D, "s_fl fits in sR3");
+      const double eps = 1.E-15, gamma = 1.0;
+      // (1) sub-mesh nodes: x_sub(t) = x0_sub + t * v_sub, x0_sub = Q2 map of the START mesh at the
+      //     closed-uniform points i/p (remhos.cpp:796-867, 1262-1274)
+      for (int k = tid; k < 3 * D3; k += NT)
+      {
+         const int comp = k / D3, i = k % D3;
+         const int ix = i % D, iy = (i / D) % D, iz = i / D2;
+         const double *x0 = a.x0 + (size_t)e * 81 + comp * 27;
+         const double *Lx = tab + C::oLcu + ix * 3, *Ly = tab + C::oLcu + iy * 3, *Lz = tab + C::oLcu + iz * 3;
+         double acc = 0.0;
+#pragma unroll
+         for (int az = 0; az < 3; az++)
+         {
+#pragma unroll
+            for (int ay = 0; ay < 3; ay++)
+            {
+#pragma unroll
+               for (int ax = 0; ax < 3; ax++) { acc += Lx[ax] * Ly[ay] * Lz[az] * x0[ax + 3 * (ay + 3 * az)]; }
+            }
+         }
+         const double vs = a.subvel[((size_t)e * 3 + comp) * D3 + i];
+         s_xs3(comp)[i] = a.move ? acc + a.t * vs : acc;
+      }
+      // (2) lumped upwind face fluxes (ApplyFaceTerms, remhos_lo.cpp:795-871): gathered per dof
+      double duf[C::DPT];
+#pragma unroll
+      for (int kk = 0; kk < C::DPT; kk++)
+      {
+         const int i = tid + kk * NT;
+         duf[kk] = 0.0;
+         if (i < D3)
+         {
+            const int idx[3] = {i % D, (i / D) % D, i / D2};
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+               const int ic = idx[c];
+               if (ic == 0 || ic == P)
+               {
+                  const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                  const int i1 = idx[c1], i2 = idx[c2];
+                  const int side = (ic == P) ? 1 : 0;
+                  const double *F = sF + (2 * c + side) * Q2;
+                  double coef = 0.0;
+#pragma unroll
+                  for (int q2 = 0; q2 < Q; q2++)
+                  {
+                     double rowacc = 0.0;
+#pragma unroll
+                     for (int q1 = 0; q1 < Q; q1++) { rowacc += tB[q1 * D + i1] * F[q1 + Q * q2]; }
+                     coef += tB[q2 * D + i2] * rowacc;
+                  }
+                  acc += coef * (sNb[(2 * c + side) * D2 + i1 + D * i2] - su[i]);
+               }
+            }
+            duf[kk] = acc;
+         }
+      }
+      __syncthreads();
+      // (3) subcell fluctuations F_m = sum_j W_mj u_j with the 1-point rule on the trilinear subcell
+      //     (SetupSubCellPA3D / ApplySubCellWeights, remhos_lo.cpp:1137-1192, 1313-1618) and the
+      //     subcell extrema (remhos_lo.cpp:1733-1757)
+      for (int m = tid; m < NS; m += NT)
+      {
+         const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
+         const int base = mx + D * my + D2 * mz;
+         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
+         double umax = -INFINITY, umin = INFINITY, usum = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+         {
+            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
+            const double uj = su[i];
+            umax = fmax(umax, uj);
+            umin = fmin(umin, uj);
+            usum += uj;
+#pragma unroll
+            for (int comp = 0; comp < 3; comp++)
+            {
+               const double x = s_xs3(comp)[i];
+               J[comp][0] += ((j & 1) ? 0.25 : -0.25) * x;
+               J[comp][1] += ((j & 2) ? 0.25 : -0.25) * x;
+               J[comp][2] += ((j & 4) ? 0.25 : -0.25) * x;
+               vm[comp] += 0.125 * a.subvel[((size_t)e * 3 + comp) * D3 + i];
+            }
+         }
+         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
+         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
+         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
+         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
+         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+         const double q0 = a.alpha * (A11 * vm[0] + A12 * vm[1] + A13 * vm[2]);
+         const double q1 = a.alpha * (A21 * vm[0] + A22 * vm[1] + A23 * vm[2]);
+         const double q2 = a.alpha * (A31 * vm[0] + A32 * vm[1] + A33 * vm[2]);
+         double fluct = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+         {
+            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
+            const double w = ((j & 1) ? 0.25 : -0.25) * q0 + ((j & 2) ? 0.25 : -0.25) * q1 + ((j & 4) ? 0.25 : -0.25) * q2;
+            fluct += w * su[i];
+         }
+         s_fl[0 * NS + m] = fmax(0., fluct);
+         s_fl[1 * NS + m] = fmin(0., fluct);
+         s_fl[2 * NS + m] = umax;
+         s_fl[3 * NS + m] = umin;
+         s_fl[4 * NS + m] = 8 * umax - usum + eps;
+         s_fl[5 * NS + m] = 8 * umin - usum - eps;
+      }
+      __syncthreads();
+      // (4) element sums (remhos_lo.cpp:1702-1716)
+      double lmax = -INFINITY, lmin = INFINITY, lsum = 0.0, lrp = 0.0, lrn = 0.0, lfp = 0.0, lfn = 0.0;
+      for (int i = tid; i < D3; i += NT)
+      {
+         const double ui = su[i], zi = s_rhs[i];
+         lmax = fmax(lmax, ui);
+         lmin = fmin(lmin, ui);
+         lsum += ui;
+         lrp += fmax(0., zi);
+         lrn += fmin(0., zi);
+      }
+      for (int m = tid; m < NS; m += NT) { lfp += s_fl[m]; lfn += s_fl[NS + m]; }
+      const double xe_max = block_max<NW>(lmax, s_red);
+      const double xe_min = block_min<NW>(lmin, s_red);
+      const double xSum = block_sum<NW>(lsum, s_red);
+      const double rhoP = block_sum<NW>(lrp, s_red);
+      const double rhoN = block_sum<NW>(lrn, s_red);
+      const double sumFluctP = block_sum<NW>(lfp, s_red);
+      const double sumFluctN = block_sum<NW>(lfn, s_red);
+      const double sumWeightsP = D3 * xe_max - xSum + eps;
+      const double sumWeightsN = D3 * xe_min - xSum - eps;
+      // (5) nodal weights (eqs. 58-59) gathered from the <= 8 subcells around each dof, final formula
+#pragma unroll
+      for (int kk = 0; kk < C::DPT; kk++)
+      {
+         const int i = tid + kk * NT;
+         if (i < D3)
+         {
+            const int ix = i % D, iy = (i / D) % D, iz = i / D2;
+            const double ui = su[i];
+            double nwP = 0.0, nwN = 0.0;
+            // the reference accumulates over subcells m ascending; same order here
+            for (int dz = 1; dz >= 0; dz--)
+            {
+               for (int dy = 1; dy >= 0; dy--)
+               {
+                  for (int dx = 1; dx >= 0; dx--)
+                  {
+                     const int mx = ix - dx, my = iy - dy, mz = iz - dz;
+                     if (mx >= 0 && mx < P && my >= 0 && my < P && mz >= 0 && mz < P)
+                     {
+                        const int m = mx + P * (my + P * mz);
+                        nwP += s_fl[0 * NS + m] * ((s_fl[2 * NS + m] - ui) / s_fl[4 * NS + m]);
+                        nwN += s_fl[1 * NS + m] * ((s_fl[3 * NS + m] - ui) / s_fl[5 * NS + m]);
+                     }
+                  }
+               }
+            }
+            double weightP = (xe_max - ui) / sumWeightsP;
+            double weightN = (xe_min - ui) / sumWeightsN;
+            double aux = gamma / (rhoP + eps);
+            weightP *= 1. - fmin(aux * sumFluctP, 1.);
+            weightP += fmin(aux, 1. / (sumFluctP + eps)) * nwP;
+            aux = gamma / (rhoN - eps);
+            weightN *= 1. - fmin(aux * sumFluctN, 1.);
+            weightN += fmax(aux, 1. / (sumFluctN - eps)) * nwN;
+            a.du[(size_t)e * D3 + i] = (duf[kk] + weightP * rhoP + weightN * rhoN) / s_m[i];
+            a.m[(size_t)e * D3 + i] = s_m[i];
+         }
+      }
+      if (tid == 0)
+      {
+         a.xe_min[e] = xe_min;
+         a.xe_max[e] = xe_max;
+      }
+      return;
+   }
    // test with the face-layer basis functions, gathered per dof (no atomics)
    for (int i = tid; i < D3; i += NT)
    {

@@ -33,7 +33,8 @@ struct TabLayout
    static constexpr int oCi = oBg2 + Q * D; // Ci[i*D+k]  inverse of C[k][i] = Bernstein_i(gl node k)
    static constexpr int N = oCi + D * D;
    static constexpr int oBgE = N;           // BgE[side*D+k] GL nodal basis at xi = 0 / 1
-   static constexpr int N2 = oBgE + 2 * D;  // extended table (ho_kernel2)
+   static constexpr int oLcu = oBgE + 2 * D; // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
+   static constexpr int N2 = oLcu + 3 * D;  // extended table
 };
 
 inline void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
@@ -178,6 +179,11 @@ inline std::vector<double> make_tables()
    {
       lagrange(xg, (double)side, L, dL);
       for (int k = 0; k < D; k++) { tab[T::oBgE + side * D + k] = L[k]; }
+   }
+   for (int i = 0; i < D; i++)
+   {
+      lagrange(mesh_nodes, (double)i / P, L, dL);
+      for (int a = 0; a < 3; a++) { tab[T::oLcu + i * 3 + a] = L[a]; }
    }
    // C[k][i] = Bernstein_i(x_gl[k]);  Ci = C^-1 stored as Ci[i*D+k]
    std::vector<double> C(D * D);

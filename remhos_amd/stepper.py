@@ -19,7 +19,9 @@ class Stepper:
         self.case = case
         self.dev = torch.device(device)
         self.dist = dist if (dist is not None and case.peers) else None
-        self.fused = fused
+        self.lo = int(case.cfg.lo_type)
+        self.fused = fused and self.lo == 5
+        fused = self.fused
         dev_index = self.dev.index or 0
         self.ctx = Context(lib, order=case.order, exec_mode=case.exec_mode, x0=case.x0, vel=case.vel,
                            face_nbr=case.face_nbr, stencil27=case.stencil27, ne_ghost=case.ne_ghost,
@@ -89,7 +91,10 @@ class Stepper:
             return
         # the reference's call sequence (remhos.cpp:1815-1831)
         c.compute_lumped_mass(t, self.m)
-        c.lo_massavg(u, self.k, dt, self.du_lo)
+        if self.lo == 4:
+            c.lo_rdsubcell(u, self.du_lo)
+        else:
+            c.lo_massavg(u, self.k, dt, self.du_lo)
         c.elem_minmax(u, self.xe_min, self.xe_max)
         c.bounds(self.xe_min, self.xe_max, self.umin, self.umax)
         du = torch.empty_like(u)

@@ -75,3 +75,27 @@ def test_run_vs_oracle(lib, mesh, rs, p, prob, steps):
     l2 = float(np.sqrt((r.m * err**2).sum()))
     assert l1 < 1e-11 and l2 < 1e-11
     st.close()
+
+
+# autotest/out_baseline.dat: "-ho 3 -lo 4 -fct 2" (:66-69, :46-49) and the PA twin "-ho 2 -lo 4 -fct 2 -pa"
+# (:140-143, :120-123) print identical values; the suite diffs 10 significant digits.
+AUTOTEST_LO4 = [
+    ("periodic-cube transport", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo_type=4),
+     0.9607429525, 0.9334903111, 134),
+    ("cube01_hex remap", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo_type=4),
+     0.1197299801, 0.9997499683, 50),
+]
+
+
+@pytest.mark.parametrize("name,kw,mass,umax,steps", AUTOTEST_LO4, ids=[k[0] for k in AUTOTEST_LO4])
+def test_autotest_baseline_lo4(lib, name, kw, mass, umax, steps):
+    """Subcell residual distribution (lo 4) + HO + ClipScale over the whole run: the reference's
+    own printed 'Final mass u' / 'Max value u' (10 digits)."""
+    from remhos_amd.case import RmhdResult, make_config
+
+    cfg = make_config(fused=0, **kw)
+    res = RmhdResult()
+    assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, lib.rmhd_last_error()
+    assert res.steps == steps
+    assert float(f"{res.final_mass:.10g}") == mass
+    assert float(f"{res.max_value:.10g}") == umax

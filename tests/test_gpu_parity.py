@@ -143,3 +143,30 @@ def test_errors_are_reported(gpu):
     with pytest.raises(RmhError):  # limiter before HO: call order violated
         ctx.limit_fused(u, u, 0.1, du=torch.empty_like(u))
     ctx.close()
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,t", [("cube01_hex", 1, 2, 10, 0.3), ("cube01_hex", 1, 3, 10, 0.6),
+                                             ("periodic-cube", 1, 3, 0, 0.0), ("periodic-cube", 1, 2, 10, 0.5),
+                                             ("cube01_hex", 0, 6, 10, 0.3), ("cube01_hex", 1, 4, 10, 0.2)])
+def test_lo_rdsubcell_parity(gpu, mesh, rs, p, prob, t):
+    """PAResidualDistributionSubcell::CalcLOSolution (remhos_lo.cpp:1620-1802) against the oracle's
+    restatement of the host form (remhos_lo.cpp:111-245).  No linear solve involved: 1e-12."""
+    torch, lib = gpu
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=4)
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    sub = r.Vs if r.exec_mode == 1 else r.vel(r.Xs0)
+    ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st,
+                  subcell_vel=np.ascontiguousarray(sub.transpose(0, 2, 1)))
+    u_h = perturbed(r.u)
+    keep = {}
+    r.stage(u_h, t, cfg.dt, keep)
+    u = torch.from_numpy(u_h).to("cuda:0")
+    du_lo = torch.empty_like(u)
+    ctx.setup(t)
+    ctx.lo_rdsubcell(u, du_lo)
+    torch.cuda.synchronize()
+    assert _relerr(du_lo.cpu().numpy(), keep["du_lo"]) < 1e-12
+    ctx.close()
