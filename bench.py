@@ -15,9 +15,9 @@ itself allows on a device, remhos.cpp:391-397), refined to --rs levels (default 
 56.6 M dofs).  For N > 1 the SAME global mesh is box-partitioned over the ranks (strong scaling);
 each stage does one RCCL neighbour exchange of ghost-element values.
 
-The same JSON line carries `roofline` for the dominant kernel (ho_kernel, duration from HIP events
-on the kernel's own stream inside the timed region) and `cpu_baseline` (the oracle timed on the
-host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
+The same JSON line carries `roofline` for the dominant kernel (ho_kernel2, duration from HIP events
+on the kernel's own stream inside the timed region) and `cpu_baseline` (the C++/OpenMP CPU port of
+oracle/ timed on the host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
 """
 import argparse
 import json
@@ -47,40 +47,29 @@ def stage_alg_bytes_per_dof(p):
     return 8.0 * (8 * D**3 + 6 * D**2 + 162 + 6 * p**3) / D**3
 
 
-def cpu_baseline(order, budget_s=20.0):
-    """Time the CPU oracle (numpy restatement of the reference algorithm, oracle/) on a bounded
-    sample of the same workload: periodic-cube remap, same order, refined once (216 hex)."""
-    import numpy as np
+def cpu_baseline(lib, order, budget_s=15.0):
+    """Time the CPU port (oracle/cpu_port.cpp: C++/OpenMP restatement of the reference's CPU
+    partial-assembly stage, validated against the reference's known answers) on the host cores, on a
+    bounded sample of the same workload: periodic-cube remap, same order, -rs 3 (13 824 hex)."""
+    from oracle.cpu_port import CpuPort
+    from remhos_amd.case import Case, make_config
 
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
-    from oracle.remhos_oracle import Config, Remhos
-
-    def run():
-        r = Remhos(Config(mesh="periodic-cube", rs=1, order=order, problem=10, dt=-1.0, t_final=0.5, lo=5))
-        ndofs = r.u.size
-        r.step(r.dt)  # warm-up (first-touch, einsum paths)
-        stages, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and r.t < 1.0 - r.dt:
-            r.step(r.dt)
-            stages += 3
-        el = time.perf_counter() - t0
-        return ndofs, stages, el
-
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            ndofs, stages, el = run()
-    else:
-        ndofs, stages, el = run()
+    case = Case(lib, make_config("periodic-cube", 3, order, 10, -1.0, 0.5))
+    cp = CpuPort(order, case.exec_mode, case.x0, case.vel, case.face_nbr, case.stencil27, case.u0)
+    cp.step(case.dt)  # warm-up
+    stages, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and stages < 30:
+        cp.step(case.dt)
+        stages += 3
+    el = time.perf_counter() - t0
+    ndofs = case.u0.size
     return {
         "value": 1e-6 * ndofs * stages / el,
         "unit": "MDOFs*RK-stage/s",
-        "cores": 1,
+        "cores": cp.threads,
         "kind": "port",
-        "sample": f"oracle/remhos_oracle.py (numpy, 1 thread): periodic-cube -rs 1 -o {order} -p 10 -lo 5 -fct 2, "
-                  f"{ndofs} dofs, {stages} RK stages in {el:.1f} s",
+        "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads): periodic-cube -rs 3 -o {order} -p 10 "
+                  f"-lo 5 -fct 2, {ndofs} dofs, {stages} RK stages in {el:.2f} s",
     }
 
 
@@ -203,7 +192,7 @@ def main():
                 "setup_s": setup_s,
             },
             "roofline": {
-                "kernel": f"ho_kernel<{args.order},0>",
+                "kernel": f"ho_kernel2<{args.order}>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"ho_kernel<{args.order},0>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -212,7 +201,7 @@ def main():
                 "traffic": traffic,
                 "avg_launch_ms": 1e3 * ho_avg_s,
                 "alg_bytes_per_launch": ho_bytes,
-                "note": "FP64-VALU-bound at p=3 in matrix-free form (geometry recomputed per stage); see DESIGN.md",
+                "note": "FP64 VALU / latency bound at p=3 in matrix-free form (geometry recomputed per stage), not HBM bound; see DESIGN.md 3.1",
             },
             "buckets_s": {"ho_rhs_plus_inv": tim[0], "lo": tim[2], "fct_fused_limiter": tim[3]},
             "stage_roofline": {
@@ -222,7 +211,7 @@ def main():
             },
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.order)
+            out["cpu_baseline"] = cpu_baseline(lib, args.order)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,62 @@
+"""ctypes wrapper of oracle/libcpu_port.so (TEST INFRASTRUCTURE: cpu_baseline + large-mesh checker)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load():
+    path = os.path.join(_HERE, "libcpu_port.so")
+    if not os.path.exists(path):
+        import subprocess
+
+        subprocess.check_call(["make", "-C", _HERE])
+    lib = C.CDLL(path)
+    p, d, i = C.c_void_p, C.c_double, C.c_int
+    lib.cpu_stage.argtypes = [i, i, i, p, p, p, p, d, d, p, p, p, p, p, d]
+    lib.cpu_rk3_step.argtypes = [i, i, i, p, p, p, p, d, d, p, p, d]
+    lib.cpu_lumped_mass.argtypes = [i, i, i, p, p, d, p]
+    lib.cpu_lumped_mass.restype = None
+    return lib
+
+
+class CpuPort:
+    """RK3 stepping of a case (arrays in the C-ABI layouts of include/rmh.h) on the host cores."""
+
+    def __init__(self, order, exec_mode, x0, vel, face_nbr, stencil27, u0, rel_tol=1e-14):
+        self.lib = load()
+        self.p, self.mode = order, exec_mode
+        self.x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        self.vel = np.ascontiguousarray(vel, dtype=np.float64)
+        self.nbr = np.ascontiguousarray(face_nbr, dtype=np.int32)
+        self.st = np.ascontiguousarray(stencil27, dtype=np.int32)
+        self.u = np.ascontiguousarray(u0, dtype=np.float64).copy()
+        self.ne = self.nbr.shape[0]
+        self.work = np.zeros(4 * self.u.size + 2 * self.ne)
+        self.t = 0.0
+        self.rel_tol = rel_tol
+        self.threads = self.lib.cpu_num_threads()
+
+    def step(self, dt):
+        it = self.lib.cpu_rk3_step(self.p, self.ne, self.mode, self.x0.ctypes.data, self.vel.ctypes.data,
+                                   self.nbr.ctypes.data, self.st.ctypes.data, self.t, dt, self.u.ctypes.data,
+                                   self.work.ctypes.data, self.rel_tol)
+        self.t += dt
+        return it
+
+    def stage(self, u, t, dt):
+        n = u.size
+        du, m, dh = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+        xe = np.zeros(2 * self.ne)
+        u = np.ascontiguousarray(u)
+        self.lib.cpu_stage(self.p, self.ne, self.mode, self.x0.ctypes.data, self.vel.ctypes.data, self.nbr.ctypes.data,
+                           self.st.ctypes.data, t, dt, u.ctypes.data, du.ctypes.data, m.ctypes.data, dh.ctypes.data,
+                           xe.ctypes.data, self.rel_tol)
+        return du, m, dh
+
+    def mass(self, t):
+        m = np.zeros_like(self.u)
+        self.lib.cpu_lumped_mass(self.p, self.ne, self.mode, self.x0.ctypes.data, self.vel.ctypes.data, t, m.ctypes.data)
+        return float((m * self.u).sum())
