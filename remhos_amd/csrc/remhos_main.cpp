@@ -1,0 +1,68 @@
+// remhos_amd -- command-line front end of the single-GPU driver (rmhd_run), accepting the subset of
+// the reference's flags that select the hot path (remhos.cpp:249-334) and printing the same report
+// lines (remhos.cpp:1423-1428, 1938-1952):
+//   remhos_amd -m periodic-cube -p 10 -rs 4 -o 3 -dt -1 -tf 0.5 -ms 20 -ho 3 -lo 5 -fct 2 -pa
+#include "../../include/rmh_driver.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+int main(int argc, char **argv)
+{
+   rmhd_config c;
+   std::memset(&c, 0, sizeof(c));
+   std::strcpy(c.mesh, "periodic-cube");
+   c.rs = 2; c.order = 3; c.problem = 10; c.dt = -1.0; c.t_final = 0.5; c.max_steps = -1;
+   c.lo_type = 5; c.fused = 1; c.px = c.py = c.pz = 1; c.rank = 0;
+   int ho = 3, fct = 2;
+   for (int i = 1; i < argc; i++)
+   {
+      const std::string a = argv[i];
+      auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
+      if (a == "-m")
+      {
+         // accept "data/periodic-cube.mesh" as well as the bare lattice name
+         std::string m = next();
+         const size_t s = m.find_last_of('/');
+         if (s != std::string::npos) { m = m.substr(s + 1); }
+         const size_t d = m.rfind(".mesh");
+         if (d != std::string::npos) { m = m.substr(0, d); }
+         std::snprintf(c.mesh, sizeof(c.mesh), "%s", m.c_str());
+      }
+      else if (a == "-rs") { c.rs = std::atoi(next()); }
+      else if (a == "-o") { c.order = std::atoi(next()); }
+      else if (a == "-p") { c.problem = std::atoi(next()); }
+      else if (a == "-dt") { c.dt = std::atof(next()); }
+      else if (a == "-tf") { c.t_final = std::atof(next()); }
+      else if (a == "-ms") { c.max_steps = std::atoi(next()); }
+      else if (a == "-lo") { c.lo_type = std::atoi(next()); }
+      else if (a == "-ho") { ho = std::atoi(next()); }
+      else if (a == "-fct") { fct = std::atoi(next()); }
+      else if (a == "-unfused") { c.fused = 0; }
+      else if (a == "-pa" || a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
+      else if (a == "-s") { if (std::atoi(next()) != 3) { std::fprintf(stderr, "only -s 3 (RK3 SSP)\n"); return 3; } }
+      else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+   }
+   if (ho != 3 || fct != 2 || (c.lo_type != 4 && c.lo_type != 5))
+   {
+      std::fprintf(stderr, "remhos_amd implements -ho 3, -lo 4|5, -fct 2 (the hot path of SURVEY.md section 8)\n");
+      return 1;
+   }
+   rmhd_result r;
+   if (rmhd_run(&c, &r) != 0)
+   {
+      std::fprintf(stderr, "remhos_amd: %s\n", rmhd_last_error());
+      return 2;
+   }
+   std::printf("Number of unknowns: %lld\n", r.global_dofs);
+   std::printf("time step: %d, time: %.8g, dt: %.8g\n", r.steps, r.t_end, r.dt);
+   std::printf("---\nRHS   kernel time: %.8g\nL2inv kernel time: %.8g\nLO    kernel time: %.8g\nFCT   kernel time: %.8g\n"
+               "Total kernel time: %.8g\n---\n", r.t_rhs, r.t_inv, r.t_lo, r.t_fct, r.t_total);
+   std::printf("FOM RHS: %.8g\nFOM INV: %.8g\nFOM LO:  %.8g\nFOM FCT: %.8g\nFOM:     %.8g\n"
+               "(megadofs x time steps / second)\n---\n", r.fom_rhs, r.fom_inv, r.fom_lo, r.fom_fct, r.fom);
+   std::printf("FOM wall (everything included): %.8g\nmax local PCG iterations: %d\n", r.fom_wall, r.cg_iters_max);
+   std::printf("Final mass u:  %.10g\nMax value u:   %.10g\nMass loss u:   %.6g\n", r.final_mass, r.max_value, r.mass_loss);
+   return 0;
+}

@@ -26,6 +26,10 @@
 namespace rmh
 {
 
+#ifndef RMH_ABL_MASK
+#define RMH_ABL_MASK 0 // diagnostic builds only: bit k skips a piece of the PCG iteration
+#endif
+
 template <int P>
 struct K2Cfg : TabLayout<P>
 {
@@ -35,15 +39,24 @@ struct K2Cfg : TabLayout<P>
    static constexpr int NT = 256;
    static constexpr int NB = NT / Q2;                 // elements per workgroup
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
-   // per-element LDS regions (doubles)
+   // per-element LDS block (doubles): a work region W whose contents change with the phase, and
+   // the face buffer.
+   //   phases A-C : [X(t),V nodes 162 | u D3 | neighbour traces 6 D2 | U1 2 Q S2]
+   //   phases C-G : [R3 3 Q2 D | R2 3 Q D2]
+   //   PCG, J     : [sA D3 | M1 / R2' Q S2 | R3' Q2 D | sB D3]
    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-   static constexpr int S2 = D2 + 1;                      // padded row stride of U1 / R2 (bank conflicts)
-   static constexpr int R0 = cmax(9 * Q * 9, 3 * Q2 * D); // T1 -> R3
-   static constexpr int R1 = 3 * Q * S2;                  // U1 -> R2
-   static constexpr int RF = 6 * Q * D;                  // face rows tested along q2
-   static constexpr int EL = 162 + D3 + 6 * D2 + R0 + R1 + RF + 2 * D3;
+   static constexpr int S2 = D2 + 1; // padded row stride of U1 / M1 (bank conflicts)
+   static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
+   static constexpr int oR3 = 0, oR2 = 3 * Q2 * D, PF = oR2 + 3 * Q * D2;
+   static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
+   static constexpr int W = cmax(PA, cmax(PF, PCG));
+   static constexpr int RF = 6 * Q * D; // face rows tested along q2
+   static constexpr int oF = W;
+   static constexpr int EL = W + RF;
    static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2;
-   static_assert(NB <= 64, "ring buffers sized for NB <= 64");
+   static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
+   // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
+   static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 4 ? 4 : (160 * 1024) / LDS_BYTES);
    static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
 };
 
@@ -124,7 +137,7 @@ __device__ unsigned long long g_stamps[32];
 #endif
 
 template <int P>
-__global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
+__global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 {
 #ifdef RMH_STAMPS
    unsigned long long stamp_prev_ = clock64();
@@ -132,23 +145,19 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    using C = K2Cfg<P>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NB = C::NB, DR = C::DR;
    constexpr int S2 = C::S2;
+   constexpr int oXV = C::oXV, oU = C::oU, oNb = C::oNb, oU1 = C::oU1, oR3 = C::oR3, oR2 = C::oR2, oSA = C::oSA,
+                 oM1 = C::oM1, oR3c = C::oR3c, oSB = C::oSB, oF = C::oF;
    __shared__ double lds[C::LDS_DOUBLES];
-   // per-element regions
-   double *sXV = lds;                  // [NB][162]   X(t) nodes (81) then V nodes (81)
-   double *su = sXV + NB * 162;        // [NB][D3]
-   double *sNb = su + NB * D3;         // [NB][6*D2]
-   double *sR0 = sNb + NB * 6 * D2;    // [NB][R0]    T1, later R3
-   double *sR1 = sR0 + NB * C::R0;     // [NB][R1]    U1, later R2
-   double *sFq = sR1 + NB * C::R1;     // [NB][6*Q*D] face values tested along q2
-   double *sA = sFq + NB * C::RF;      // [NB][D3]    ping
-   double *sB = sA + NB * D3;          // [NB][D3]    pong
-   double *s_acc = sB + NB * D3;       // [3][NB] ring of reduction buffers (+ NB spare)
+   // element-major blocks: element eb owns lds[eb*EL .. (eb+1)*EL)
+#define RMH_W(eb) (lds + (eb) * C::EL)
+   double *s_acc = lds + NB * C::EL;   // [3][NB] ring of reduction buffers (+ NB spare)
    int *s_flag = (int *)(s_acc + 4 * NB); // [4] "any element still active" flags (ring of 2 used)
    double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
 
    const int tid = threadIdx.x;
    const int e0 = blockIdx.x * NB;
-   const double *__restrict__ gt = a.tab; // uniform: compile-time indices become scalar loads
+   static_assert(C::N2 <= RMH_TAB_STRIDE, "constant table too small");
+   const double *gt = c_tab[P]; // constant memory: compile-time indices become scalar loads
    constexpr int oB = C::oB, oG = C::oG, oL = C::oL, odL = C::odL, oW = C::oW, oBg = C::oBg, oBg2 = C::oBg2,
                  oCi = C::oCi;
 
@@ -222,56 +231,46 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       if (k < NB * 81)
       {
          const int eb = k / 81, i = k % 81;
-         sXV[eb * 162 + 81 + i] = gv[j];
-         sXV[eb * 162 + i] = a.move ? gx0[j] + a.t * gv[j] : gx0[j];
+         RMH_W(eb)[oXV + 81 + i] = gv[j];
+         RMH_W(eb)[oXV + i] = a.move ? gx0[j] + a.t * gv[j] : gx0[j];
       }
    }
 #pragma unroll
    for (int j = 0; j < NLU; j++)
    {
       const int k = tid + j * NT;
-      if (k < NB * D3) { su[k] = gu[j]; }
+      if (k < NB * D3) { RMH_W(k / D3)[oU + k % D3] = gu[j]; }
    }
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
       const int k = tid + j * NT;
-      if (k < NB * 6 * D2) { sNb[k] = gn[j]; }
+      if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
    }
    __syncthreads();
 
    RMH_STAMP(0);
    // ---- phase B: x-contractions of the geometry and of u; face rows -------------------------------
-   // T1[eb][(arr*Q + qx)*9 + n2], arr = 3*comp + kind, kind 0: L.X, 1: dL.X, 2: L.V
-   // pencil tasks (eb, comp, n2): 3 node values in, Q values out per kind; basis entries are
-   // compile-time indexed (scalar operands)
-   for (int k = tid; k < NB * 27; k += NT)
+   // element extrema (remhos_tools.cpp:497-523) while u is still in LDS
+   double my_min = INFINITY, my_max = -INFINITY;
+   if (tid < NB)
    {
-      const int eb = k / 27, r = k % 27;
-      const int comp = r / 9, n2 = r % 9;
-      const double *X = sXV + eb * 162 + comp * 27 + 3 * n2;
-      const double x0 = X[0], x1 = X[1], x2 = X[2];
-      const double v0 = X[81], v1 = X[82], v2 = X[83];
-      double *dst = sR0 + eb * C::R0 + (comp * 3) * Q * 9 + n2;
-#pragma unroll
-      for (int q = 0; q < Q; q++)
+      const double *uu = RMH_W(tid) + oU;
+      for (int i = 0; i < D3; i++)
       {
-         const double l0 = gt[oL + q * 3], l1 = gt[oL + q * 3 + 1], l2 = gt[oL + q * 3 + 2];
-         const double d0 = gt[odL + q * 3], d1 = gt[odL + q * 3 + 1], d2 = gt[odL + q * 3 + 2];
-         dst[(0 * Q + q) * 9] = l0 * x0 + l1 * x1 + l2 * x2;
-         dst[(1 * Q + q) * 9] = d0 * x0 + d1 * x1 + d2 * x2;
-         dst[(2 * Q + q) * 9] = l0 * v0 + l1 * v1 + l2 * v2;
+         my_min = fmin(my_min, uu[i]);
+         my_max = fmax(my_max, uu[i]);
       }
    }
    // U1[eb][(kind*Q + qx)*S2 + i2], kind 0: B.u, 1: G.u; pencil tasks (eb, i2)
    for (int k = tid; k < NB * D2; k += NT)
    {
       const int eb = k / D2, i2 = k % D2;
-      const double *src = su + eb * D3 + D * i2;
+      const double *src = RMH_W(eb) + oU + D * i2;
       double uu[D];
 #pragma unroll
       for (int ix = 0; ix < D; ix++) { uu[ix] = src[ix]; }
-      double *dst = sR1 + eb * C::R1 + i2;
+      double *dst = RMH_W(eb) + oU1 + i2;
 #pragma unroll
       for (int q = 0; q < Q; q++)
       {
@@ -299,7 +298,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       const int nc = (c == 0) ? 1 : (c == 1 ? 3 : 9);
       const int n1 = (c1 == 0) ? 1 : (c1 == 1 ? 3 : 9);
       const int n2s = (c2 == 0) ? 1 : (c2 == 1 ? 3 : 9);
-      const double *X = sXV + eb * 162 + (side ? 2 * nc : 0);
+      const double *X = RMH_W(eb) + oXV + (side ? 2 * nc : 0);
       const double *V = X + 81;
       double L1[3], dL1[3];
 #pragma unroll
@@ -328,8 +327,8 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       const int dc = (c == 0) ? 1 : (c == 1 ? D : D2);
       const int d1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
       const int d2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
-      const double *uo = su + eb * D3 + (side ? P * dc : 0);
-      const double *un = sNb + eb * 6 * D2 + f * D2;
+      const double *uo = RMH_W(eb) + oU + (side ? P * dc : 0);
+      const double *un = RMH_W(eb) + oNb + f * D2;
       double jr[D];
 #pragma unroll
       for (int i2 = 0; i2 < D; i2++)
@@ -374,7 +373,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          for (int k2 = 0; k2 < D; k2++) { tq[k2] += gt[oBg + q2 * D + k2] * val; }
       }
 #pragma unroll
-      for (int k2 = 0; k2 < D; k2++) { sFq[eb * C::RF + (f * Q + q1) * D + k2] = tq[k2]; }
+      for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[oF + (f * Q + q1) * D + k2] = tq[k2]; }
    }
    __syncthreads();
 
@@ -402,31 +401,80 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          Gy[k] = stab[oG + qy * D + k];
          Bgy[k] = stab[oBg + qy * D + k];
       }
-      const double *T1 = sR0 + ceb * C::R0;
-      double A[3][4][3];
+      double Lx[3], dLx[3];
 #pragma unroll
-      for (int comp = 0; comp < 3; comp++)
+      for (int k = 0; k < 3; k++) { Lx[k] = stab[oL + qx * 3 + k]; dLx[k] = stab[odL + qx * 3 + k]; }
+      const double wxy = stab[oW + qx] * stab[oW + qy];
+      double Dq[3][Q];
       {
+         // pass 1: geometry.  x- and y-contractions of the 27 nodes of X(t) and V for this column
+         // (broadcast LDS reads: all columns of an element read the same node)
+         const double *XN = RMH_W(ceb) + oXV;
+         double A[3][4][3];
 #pragma unroll
-         for (int az = 0; az < 3; az++)
+         for (int comp = 0; comp < 3; comp++)
          {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-            for (int ay = 0; ay < 3; ay++)
+            for (int az = 0; az < 3; az++)
             {
-               const int n2 = ay + 3 * az;
-               const double xl = T1[((comp * 3 + 0) * Q + qx) * 9 + n2];
-               const double xd = T1[((comp * 3 + 1) * Q + qx) * 9 + n2];
-               const double vl = T1[((comp * 3 + 2) * Q + qx) * 9 + n2];
-               a0 += Ly[ay] * xd;
-               a1 += dLy[ay] * xl;
-               a2 += Ly[ay] * xl;
-               a3 += Ly[ay] * vl;
+               double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+               for (int ay = 0; ay < 3; ay++)
+               {
+                  const double *xr = XN + comp * 27 + 3 * (ay + 3 * az);
+                  const double x0n = xr[0], x1n = xr[1], x2n = xr[2];
+                  const double v0n = xr[81], v1n = xr[82], v2n = xr[83];
+                  const double xl = Lx[0] * x0n + Lx[1] * x1n + Lx[2] * x2n;
+                  const double xd = dLx[0] * x0n + dLx[1] * x1n + dLx[2] * x2n;
+                  const double vl = Lx[0] * v0n + Lx[1] * v1n + Lx[2] * v2n;
+                  a0 += Ly[ay] * xd;
+                  a1 += dLy[ay] * xl;
+                  a2 += Ly[ay] * xl;
+                  a3 += Ly[ay] * vl;
+               }
+               A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2; A[comp][3][az] = a3;
             }
-            A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2; A[comp][3][az] = a3;
+         }
+#pragma unroll
+         for (int qz = 0; qz < Q; qz++)
+         {
+            double J[3][3], v[3];
+#pragma unroll
+            for (int comp = 0; comp < 3; comp++)
+            {
+               double j0 = 0, j1 = 0, j2 = 0, vv = 0;
+#pragma unroll
+               for (int az = 0; az < 3; az++)
+               {
+                  const double Lz = gt[oL + qz * 3 + az], dLz = gt[odL + qz * 3 + az];
+                  j0 += Lz * A[comp][0][az];
+                  j1 += Lz * A[comp][1][az];
+                  j2 += dLz * A[comp][2][az];
+                  vv += Lz * A[comp][3][az];
+               }
+               J[comp][0] = j0; J[comp][1] = j1; J[comp][2] = j2; v[comp] = vv;
+            }
+            // adj(J), rows as in remhos_lo.cpp:1168-1180
+            const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+            const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
+            const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
+            const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
+            const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+            const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
+            const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+            const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+            const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+            const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
+            const double w3 = wxy * gt[oW + qz];
+            const double aw = a.alpha * w3;
+            Dq[0][qz] = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
+            Dq[1][qz] = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
+            Dq[2][qz] = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
+            wd[qz] = w3 * detJ;
          }
       }
-      const double *U1 = sR1 + ceb * C::R1;
+      // pass 2: grad u, D.grad u and the z-leg of the three test contractions
+      const double *U1 = RMH_W(ceb) + oU1;
       double UB[D], UG[D], UU[D];
 #pragma unroll
       for (int iz = 0; iz < D; iz++)
@@ -443,44 +491,9 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          }
          UB[iz] = b0; UG[iz] = b1; UU[iz] = b2;
       }
-      const double wxy = stab[oW + qx] * stab[oW + qy];
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
-         double J[3][3], v[3];
-#pragma unroll
-         for (int comp = 0; comp < 3; comp++)
-         {
-            double j0 = 0, j1 = 0, j2 = 0, vv = 0;
-#pragma unroll
-            for (int az = 0; az < 3; az++)
-            {
-               const double Lz = gt[oL + qz * 3 + az], dLz = gt[odL + qz * 3 + az];
-               j0 += Lz * A[comp][0][az];
-               j1 += Lz * A[comp][1][az];
-               j2 += dLz * A[comp][2][az];
-               vv += Lz * A[comp][3][az];
-            }
-            J[comp][0] = j0; J[comp][1] = j1; J[comp][2] = j2; v[comp] = vv;
-         }
-         // adj(J), rows as in remhos_lo.cpp:1168-1180
-         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
-         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
-         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
-         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
-         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
-         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
-         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-         const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
-         const double w3 = wxy * gt[oW + qz];
-         const double aw = a.alpha * w3;
-         const double D0 = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
-         const double D1 = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
-         const double D2q = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
-         const double wdq = w3 * detJ;
-         wd[qz] = wdq;
          double gx = 0, gy = 0, gz = 0;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
@@ -490,7 +503,8 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
             gy += Bz * UG[iz];
             gz += Gz * UU[iz];
          }
-         const double g = D0 * gx + D1 * gy + D2q * gz;
+         const double g = Dq[0][qz] * gx + Dq[1][qz] * gy + Dq[2][qz] * gz;
+         const double wdq = wd[qz];
          // test along z: r0: GL nodal basis x (D.grad u); r1: Bernstein x w detJ (lumped mass);
          //               r2: GL basis squared x w detJ (Jacobi diagonal)
 #pragma unroll
@@ -502,10 +516,10 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          }
       }
    }
-   __syncthreads(); // R3 overlays T1: every column thread is done with T1
+   __syncthreads(); // R3 overlays the phase A-C data: every thread is done with nodes, u, traces, U1
    if (col)
    {
-      double *R3 = sR0 + ceb * C::R0;
+      double *R3 = RMH_W(ceb) + oR3;
 #pragma unroll
       for (int iz = 0; iz < D; iz++)
       {
@@ -525,11 +539,11 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
 #pragma unroll
       for (int r = 0; r < 3; r++)
       {
-         const double *R3 = sR0 + eb * C::R0 + (r * Q2 + q) * D + iz;
+         const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
          double in[Q];
 #pragma unroll
          for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
-         double *dst = sR1 + eb * C::R1 + (r * Q + q) * S2 + D * iz; // [r][qx][iy + D*iz]
+         double *dst = RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz; // [r][qx][iy + D*iz]
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
@@ -562,15 +576,15 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          const int eb = t / D3, i = t % D3;
          const int ix = i % D, i2 = i / D;
          const int idx[3] = {ix, i2 % D, i2 / D};
-         const double *R2 = sR1 + eb * C::R1;
+         const double *R2 = RMH_W(eb) + oR2;
          double a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
          for (int jx = 0; jx < Q; jx++)
          {
             cBg[r][jx] = stab[oBg + jx * D + ix];
-            a0 += cBg[r][jx] * R2[(0 * Q + jx) * S2 + i2];
-            a1 += stab[oB + jx * D + ix] * R2[(1 * Q + jx) * S2 + i2];
-            a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * S2 + i2];
+            a0 += cBg[r][jx] * R2[(0 * Q + jx) * D2 + i2];
+            a1 += stab[oB + jx * D + ix] * R2[(1 * Q + jx) * D2 + i2];
+            a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * D2 + i2];
          }
          // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
 #pragma unroll
@@ -581,7 +595,7 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
 #pragma unroll
             for (int side = 0; side < 2; side++)
             {
-               const double *F = sFq + eb * C::RF + (2 * c + side) * Q * D + k2;
+               const double *F = RMH_W(eb) + oF + (2 * c + side) * Q * D + k2;
                double fa = 0.0;
 #pragma unroll
                for (int q1 = 0; q1 < Q; q1++) { fa += stab[oBg + q1 * D + k1] * F[q1 * D]; }
@@ -627,19 +641,21 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
-         if (t < NB * D3) { sA[t] = dd[r]; }
+         if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = dd[r]; }
       }
       if (tid == 0) { s_flag[(it + 1) & 1] = 0; }
       __syncthreads();
       if (!s_flag[it & 1]) { break; } // no element of the batch is active any more
+      RMH_STAMP(10);
+      if (!(RMH_ABL_MASK & 1))
       for (int k = tid; k < NB * D2; k += NT)
       {
          const int eb = k / D2, i2 = k % D2;
-         const double *src = sA + eb * D3 + D * i2;
+         const double *src = RMH_W(eb) + oSA + D * i2;
          double in[D];
 #pragma unroll
          for (int ix = 0; ix < D; ix++) { in[ix] = src[ix]; }
-         double *dst = sR1 + eb * C::R1 + i2;
+         double *dst = RMH_W(eb) + oM1 + i2;
 #pragma unroll
          for (int q = 0; q < Q; q++)
          {
@@ -649,10 +665,11 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
             dst[q * S2] = acc;
          }
       }
-      __syncthreads();
-      if (col)
+      if (!(RMH_ABL_MASK & 16)) { __syncthreads(); }
+      RMH_STAMP(11);
+      if (col && !(RMH_ABL_MASK & 2))
       {
-         const double *M1 = sR1 + ceb * C::R1 + qx * S2;
+         const double *M1 = RMH_W(ceb) + oM1 + qx * S2;
          double Y[D];
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
@@ -675,20 +692,22 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { rz[iz] += gt[oBg + qz * D + iz] * acc; }
          }
-         double *R3 = sR0 + ceb * C::R0 + cc * D;
+         double *R3 = RMH_W(ceb) + oR3c + cc * D;
 #pragma unroll
          for (int iz = 0; iz < D; iz++) { R3[iz] = rz[iz]; }
       }
-      __syncthreads();
+      if (!(RMH_ABL_MASK & 16)) { __syncthreads(); }
+      RMH_STAMP(12);
+      if (!(RMH_ABL_MASK & 4))
       for (int k = tid; k < NB * Q * D; k += NT)
       {
          const int eb = k / (Q * D), rem = k % (Q * D);
          const int q = rem / D, iz = rem % D;
-         const double *R3 = sR0 + eb * C::R0 + q * D + iz;
+         const double *R3 = RMH_W(eb) + oR3c + q * D + iz;
          double in[Q];
 #pragma unroll
          for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
-         double *dst = sR1 + eb * C::R1 + q * S2 + D * iz;
+         double *dst = RMH_W(eb) + oM1 + q * S2 + D * iz;
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
@@ -698,7 +717,8 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
             dst[iy] = acc;
          }
       }
-      __syncthreads();
+      if (!(RMH_ABL_MASK & 16)) { __syncthreads(); }
+      RMH_STAMP(13);
       double Ad[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -710,35 +730,45 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          {
             const int eb = t / D3, i = t % D3;
             const int i2 = i / D;
-            const double *R2 = sR1 + eb * C::R1 + i2;
+            const double *R2 = RMH_W(eb) + oM1 + i2;
             double acc = 0.0;
 #pragma unroll
-            for (int jx = 0; jx < Q; jx++) { acc += cBg[r][jx] * R2[jx * S2]; }
+            for (int jx = 0; jx < ((RMH_ABL_MASK & 8) ? 0 : Q); jx++) { acc += cBg[r][jx] * R2[jx * S2]; }
             Ad[r] = acc;
             tmp[r] = dd[r] * acc;
          }
       }
       RMH_STAMP(8);
+#ifdef RMH_ABL_NODOT
+      for (int r = 0; r < DR; r++) { red[r] = nom[r]; }
+#else
       batch_dot<P>(tmp, red, s_acc, ring); // den = d.Ad
+#endif
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
          const bool ok = act[r] && red[r] > 0.0;
-         const double al = ok ? nom[r] / red[r] : 0.0;
+         const double al = ok ? ((RMH_ABL_MASK & 32) ? nom[r] : nom[r] / red[r]) : 0.0;
          if (act[r] && !ok) { tol[r] = INFINITY; } // breakdown: freeze this element
          xg[r] += al * dd[r];
          rg[r] -= al * Ad[r];
-         tmp[r] = rg[r] * (rg[r] / dg[r]);
+         tmp[r] = (RMH_ABL_MASK & 32) ? rg[r] * rg[r] : rg[r] * (rg[r] / dg[r]);
       }
+      RMH_STAMP(14);
+#ifdef RMH_ABL_NODOT
+      for (int r = 0; r < DR; r++) { red[r] = 0.0; }
+#else
       batch_dot<P>(tmp, red, s_acc, ring); // betanom = r.z
+#endif
+      RMH_STAMP(15);
       bool any = false;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
-         const double z = rg[r] / dg[r];
+         const double z = (RMH_ABL_MASK & 32) ? rg[r] : rg[r] / dg[r];
          if (act[r])
          {
-            dd[r] = z + (red[r] / nom[r]) * dd[r];
+            dd[r] = z + ((RMH_ABL_MASK & 32) ? red[r] : (red[r] / nom[r])) * dd[r];
             nom[r] = red[r];
             its[r]++;
          }
@@ -755,13 +785,12 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    for (int r = 0; r < DR; r++)
    {
       const int t = tid + r * NT;
-      if (t < NB * D3) { sA[t] = xg[r]; }
+      if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = xg[r]; }
    }
    __syncthreads();
    for (int dir = 0; dir < 3; dir++)
    {
-      const double *in = (dir & 1) ? sB : sA;
-      double *out = (dir & 1) ? sA : sB;
+      const int oin = (dir & 1) ? oSB : oSA, oout = (dir & 1) ? oSA : oSB;
       const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -771,12 +800,12 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
          {
             const int eb = t / D3, i = t % D3;
             const int k = (i / stride) % D;
-            const double *src = in + eb * D3 + i - k * stride;
+            const double *src = RMH_W(eb) + oin + i - k * stride;
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < D; j++) { acc += stab[oCi + k * D + j] * src[j * stride]; }
             if (dir == 2) { xg[r] = acc; }
-            else { out[t] = acc; }
+            else { RMH_W(eb)[oout + i] = acc; }
          }
       }
       __syncthreads();
@@ -795,17 +824,16 @@ __global__ void __launch_bounds__(256) ho_kernel2(HoArgs a)
    }
    if (tid < NB && e0 + tid < a.ne_owned)
    {
-      double lmin = INFINITY, lmax = -INFINITY;
-      for (int i = 0; i < D3; i++)
-      {
-         lmin = fmin(lmin, su[tid * D3 + i]);
-         lmax = fmax(lmax, su[tid * D3 + i]);
-      }
-      a.xe_min[e0 + tid] = lmin;
-      a.xe_max[e0 + tid] = lmax;
+      a.xe_min[e0 + tid] = my_min;
+      a.xe_max[e0 + tid] = my_max;
    }
-   if ((tid & 63) == 0 && itmax > 0) { atomicMax(a.cg_iters, itmax); }
+   // diagnostics: max PCG iteration count over the launch.  A global atomic per wavefront on ONE
+   // address serialises at the memory side (~5 ns each: 3 ms per launch at 500 k wavefronts), so the
+   // atomic is issued only when it can raise the (monotone) maximum.
+   if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(a.cg_iters)) { atomicMax(a.cg_iters, itmax); }
    RMH_STAMP(7);
 }
+
+#undef RMH_W
 
 } // namespace rmh

@@ -30,6 +30,12 @@ struct KCfg : TabLayout<P>
    static constexpr int DPT = (D3 + NT - 1) / NT; // dofs per thread
 };
 
+// 1-D tables of every order in constant memory: compile-time indexed reads become scalar loads
+// (s_load) everywhere, including after barriers where the compiler no longer treats loads from
+// ordinary global memory as invariant.  Filled by rmh_create (identical for all contexts).
+constexpr int RMH_TAB_STRIDE = 416;
+__constant__ double c_tab[7][RMH_TAB_STRIDE];
+
 struct HoArgs
 {
    const double *u;        // [ne_owned][D3]
@@ -796,7 +802,8 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
    {
       a.xe_min[e] = lmin;
       a.xe_max[e] = lmax;
-      if (it > 0) { atomicMax(a.cg_iters, it); }
+      // only when it can raise the maximum: atomics on one address serialise at the memory side
+      if (it > 0 && it > __builtin_nontemporal_load(a.cg_iters)) { atomicMax(a.cg_iters, it); }
    }
 }
 

@@ -18,6 +18,8 @@
 #define __device__
 #define __host__
 #define __shared__ static
+#define __constant__ static
+#define HIP_SYMBOL(x) (x)
 #define __launch_bounds__(...)
 
 struct dim3
@@ -86,6 +88,9 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
    return r;
 }
 
+template <typename T>
+inline T __builtin_nontemporal_load(const T *p) { return *p; }
+
 using std::max;
 using std::min;
 
@@ -115,6 +120,12 @@ inline hipError_t hipFree(void *p) { std::free(p); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
+template <typename S>
+inline hipError_t hipMemcpyToSymbol(S &sym, const void *src, size_t n, size_t off, hipMemcpyKind)
+{
+   std::memcpy((char *)&sym + off, src, n);
+   return 0;
+}
 inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
