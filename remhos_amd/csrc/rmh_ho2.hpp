@@ -52,7 +52,10 @@ struct K2Cfg : TabLayout<P>
    static constexpr int W = cmax(PA, cmax(PF, PCG));
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
    static constexpr int oF = W;
-   static constexpr int EL = W + RF;
+   // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
+   // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
+   static constexpr int EL0 = W + RF;
+   static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
    static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2;
    static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
@@ -68,6 +71,29 @@ __device__ inline double dpp_add(double v)
    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
    return v + __hiloint2double(hi2, lo2);
+}
+
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ inline double dpp_minmax(double v)
+{
+   const int lo = __double2loint(v), hi = __double2hiint(v);
+   const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+   const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+   const double o = __hiloint2double(hi2, lo2);
+   return IS_MIN ? fmin(v, o) : fmax(v, o);
+}
+
+// min or max over the 64 lanes of a wavefront; valid in lane 63
+template <bool IS_MIN>
+__device__ inline double wave_minmax(double v)
+{
+   v = dpp_minmax<0xB1, 0xF, IS_MIN>(v);
+   v = dpp_minmax<0x4E, 0xF, IS_MIN>(v);
+   v = dpp_minmax<0x141, 0xF, IS_MIN>(v);
+   v = dpp_minmax<0x140, 0xF, IS_MIN>(v);
+   v = dpp_minmax<0x142, 0xA, IS_MIN>(v);
+   v = dpp_minmax<0x143, 0xC, IS_MIN>(v);
+   return v;
 }
 
 // Sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r] (the
@@ -251,9 +277,25 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 
    RMH_STAMP(0);
    // ---- phase B: x-contractions of the geometry and of u; face rows -------------------------------
-   // element extrema (remhos_tools.cpp:497-523) while u is still in LDS
+   // element extrema (remhos_tools.cpp:497-523)
    double my_min = INFINITY, my_max = -INFINITY;
-   if (tid < NB)
+   if (C::WAVE_ALIGNED)
+   {
+      // D3 = 64: the values a wavefront loaded in round j all belong to element (j*NT + tid)/D3
+#pragma unroll
+      for (int j = 0; j < NLU; j++)
+      {
+         const int k = tid + j * NT;
+         const double lo = wave_minmax<true>(k < NB * D3 ? gu[j] : INFINITY);
+         const double hi = wave_minmax<false>(k < NB * D3 ? gu[j] : -INFINITY);
+         if ((tid & 63) == 63 && k < NB * D3 && e0 + k / D3 < a.ne_owned)
+         {
+            a.xe_min[e0 + k / D3] = lo;
+            a.xe_max[e0 + k / D3] = hi;
+         }
+      }
+   }
+   else if (tid < NB)
    {
       const double *uu = RMH_W(tid) + oU;
       for (int i = 0; i < D3; i++)
@@ -822,7 +864,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
          itmax = max(itmax, its[r]);
       }
    }
-   if (tid < NB && e0 + tid < a.ne_owned)
+   if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < a.ne_owned)
    {
       a.xe_min[e0 + tid] = my_min;
       a.xe_max[e0 + tid] = my_max;
