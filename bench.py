@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--problem", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference call sequence instead of the fused limiter")
+    ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +115,7 @@ def main():
     cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, part=PART[args.gpus], rank=rank)
     t0 = time.perf_counter()
     case = Case(lib, cfg)
-    st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused)
+    st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused, one_kernel=not args.two_kernels)
     setup_s = time.perf_counter() - t0
     global_dofs = case.ne_global * case.ndof
     dt = case.dt
@@ -154,14 +155,20 @@ def main():
 
     if rank == 0:
         ho_avg_s = tim[0] / stages
-        ho_bytes = ho_alg_bytes_per_element(args.order) * case.ne_owned
+        if st.one_kernel:
+            # the dominant kernel is the whole stage: SURVEY 8(d) matrix-free per-dof figure
+            ho_bytes = int(stage_alg_bytes_per_dof(args.order) * case.ne_owned * case.ndof)
+            kname = f"ho_kernel2<{args.order},true> (whole RK stage)"
+        else:
+            ho_bytes = ho_alg_bytes_per_element(args.order) * case.ne_owned
+            kname = f"ho_kernel2<{args.order},false>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"ho_kernel<{args.order},0>"
         achieved = ho_bytes / ho_avg_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.mesh}-rs{args.rs}-o{args.order}-n{args.gpus}"
+                key = f"{args.mesh}-rs{args.rs}-o{args.order}-n{args.gpus}" + ("-stage" if st.one_kernel else "")
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -184,7 +191,7 @@ def main():
                 "global_dofs": global_dofs,
                 "elements": case.ne_global,
                 "partition": "x".join(str(k) for k in PART[args.gpus]),
-                "limiter": "reference call sequence" if args.unfused else "fused (LO avg + bounds + ClipScale + RK update)",
+                "limiter": "reference call sequence" if args.unfused else ("inside the stage kernel" if st.one_kernel else "fused (LO avg + bounds + ClipScale + RK update)"),
                 "dt": dt,
                 "mass_cg_max_iters": cg_iters,
                 "final_mass": mass,
@@ -192,7 +199,7 @@ def main():
                 "setup_s": setup_s,
             },
             "roofline": {
-                "kernel": f"ho_kernel2<{args.order}>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"ho_kernel<{args.order},0>",
+                "kernel": kname,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

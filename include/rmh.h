@@ -132,6 +132,16 @@ int rmh_fct_clipscale(rmh_ctx *ctx, const double *u, const double *m,
 int rmh_limit_fused(rmh_ctx *ctx, const double *u, const double *du_ho, double dt, double *du,
                     const double *x_base, double a, double b, double dt_rk, double *y_out);
 
+/* The whole RK stage in ONE kernel for -ho 3 -lo 5 -fct 2: AdvectionOperator::Mult = MultUnlimited +
+ * LimitMult (remhos_solvers.hpp:46-50, remhos.cpp:1596-1916) and the RK vector update
+ *   y_out = a * x_base + b * (u + dt_rk * du)          (x_base may be NULL: a is ignored)
+ * du_HO, du_LO, the lumped mass and the per-dof bounds never leave the compute unit; the element extrema
+ * of y_out are kept for the next stage (normally its input).  du (may be NULL) receives the limited rate.
+ * y_out must not alias u (other workgroups still read neighbour traces of u); it may alias x_base.
+ * Ghost values of u and ghost extrema must be set for multi-rank runs. */
+int rmh_stage_fused(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
+                    double dt_rk, double *y_out, double *du);
+
 /* Stopwatch buckets of TimingData (remhos_tools.hpp:52-64; printed by
  * AdvectionOperator::PrintTimingData, remhos.cpp:1918-1966): seconds in
  * t[0]=RHS (K u), t[1]=L2inv (mass solve), t[2]=LO, t[3]=FCT since the last reset, measured

@@ -167,12 +167,16 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
    const double alpha = exec_mode == 1 ? 1.0 : -1.0, upw = exec_mode == 1 ? 1.0 : -1.0;
    int itmax = 0;
 
-#pragma omp parallel for schedule(static) reduction(max : itmax)
+#pragma omp parallel reduction(max : itmax)
+   {
+   // per-thread scratch (allocated once per thread, not per element)
+   Work w;
+   std::vector<double> X(81), V(81), Jc(9 * Q3), vq(3 * Q3), tmp(Q3), Dq(3 * Q3), wd(Q3), g(Q3), gr(3 * Q3);
+   std::vector<double> rhs(D3), rg(D3), xg(D3), dd(D3), Ad(D3), dg(D3), zz(D3), t1(D3), t2(D3), val(Q2), Bg2(Q * D);
+   for (int i = 0; i < Q * D; i++) { Bg2[i] = Bg[i] * Bg[i]; }
+#pragma omp for schedule(static)
    for (int e = 0; e < ne; e++)
    {
-      Work w;
-      std::vector<double> X(81), V(81), Jc(9 * Q3), vq(3 * Q3), tmp(Q3), Dq(3 * Q3), wd(Q3), g(Q3), gr(3 * Q3);
-      std::vector<double> rhs(D3), rg(D3), xg(D3), dd(D3), Ad(D3), dg(D3), zz(D3), t1(D3), t2(D3);
       const double *ue = u + (size_t)e * D3;
       for (int i = 0; i < 81; i++)
       {
@@ -220,7 +224,6 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
          const int pw3[3] = {1, 3, 9}, pwD[3] = {1, D, D2};
          const int nb = face_nbr[(size_t)e * 6 + f];
          const double *un = nb >= 0 ? u + (size_t)nb * D3 : nullptr;
-         std::vector<double> val(Q2);
          for (int q2 = 0; q2 < Q; q2++)
          {
             for (int q1 = 0; q1 < Q; q1++)
@@ -277,11 +280,7 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
       contract_t(Ci, D, D, 0, nD, rhs.data(), t1.data()); // b_g = Ci^T (x)3 b : out[k] = sum_i Ci[i*D+k] in[i]
       contract_t(Ci, D, D, 1, nD, t1.data(), t2.data());
       contract_t(Ci, D, D, 2, nD, t2.data(), rg.data());
-      {
-         std::vector<double> Bg2(Q * D);
-         for (int i = 0; i < Q * D; i++) { Bg2[i] = Bg[i] * Bg[i]; }
-         test3(Bg2.data(), Bg2.data(), Bg2.data(), Q, D, wd.data(), dg.data(), w);
-      }
+      test3(Bg2.data(), Bg2.data(), Bg2.data(), Q, D, wd.data(), dg.data(), w);
       double nom = 0.0;
       for (int i = 0; i < D3; i++)
       {
@@ -325,9 +324,13 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
       ws_xe[e] = lo;
       ws_xe[ne + e] = hi;
    }
+   } // omp parallel
 
    // LimitMult: MassBasedAvg + overlap bounds + ClipScale
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+   {
+   std::vector<double> fc(D3), dl(D3);
+#pragma omp for schedule(static)
    for (int e = 0; e < ne; e++)
    {
       const double *ue = u + (size_t)e * D3, *m = ws_m + (size_t)e * D3, *dh = ws_duho + (size_t)e * D3;
@@ -345,7 +348,6 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
          smin[s] = nb >= 0 ? ws_xe[nb] : INFINITY;
          smax[s] = nb >= 0 ? ws_xe[ne + nb] : -INFINITY;
       }
-      std::vector<double> fc(D3), dl(D3);
       double sumPos = 0.0, sumNeg = 0.0;
       const double eps = 1.0e-15;
       for (int i = 0; i < D3; i++)
@@ -383,6 +385,7 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
          du[(size_t)e * D3 + i] = dl[i] + f / m[i];
       }
    }
+   } // omp parallel
    return itmax;
 }
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace rmh;
@@ -45,6 +46,8 @@ struct rmh_ctx
    double t = 0.0;
    double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
+   double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
+   const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold
    int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
    const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
    double rel_tol = 1e-14, abs_tol = 0.0;
@@ -149,15 +152,68 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.rel2 = c->rel_tol * c->rel_tol;
    a.abs2 = c->abs_tol * c->abs_tol;
    a.max_iter = c->max_iter;
+   a.stencil27 = c->d_st27;
+   a.gh_min = c->gh_min;
+   a.gh_max = c->gh_max;
+   a.dt = 0.0;
+   a.x_base = nullptr;
+   a.rk_a = 0.0;
+   a.rk_b = 1.0;
+   a.dt_rk = 0.0;
+   a.y_out = nullptr;
+   a.xe_min_out = nullptr;
+   a.xe_max_out = nullptr;
    if (MODE == 0 && c->ho_variant == 2)
    {
       constexpr int NB = K2Cfg<P>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+      hipLaunchKernelGGL((ho_kernel2<P, false>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    else
    {
       hipLaunchKernelGGL((ho_kernel<P, MODE>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, a);
    }
+   RMH_HIP(hipGetLastError());
+   return 0;
+}
+
+template <int P>
+int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double ra, double rb, double dt_rk,
+                       double *y_out, double *du)
+{
+   HoArgs a;
+   a.u = u;
+   a.u_ghost = c->u_ghost;
+   a.x0 = c->d_x0;
+   a.vel = c->d_vel;
+   a.face_nbr = c->d_nbr;
+   a.tab = c->d_tab;
+   a.subvel = c->d_subvel;
+   a.du = du;
+   a.m = c->d_m;
+   a.xe_min = c->d_xe_min;
+   a.xe_max = c->d_xe_max;
+   a.cg_iters = c->d_cg;
+   a.ne_owned = c->ne;
+   a.t = c->t;
+   a.move = c->exec_mode == 1;
+   a.alpha = c->exec_mode == 1 ? 1.0 : -1.0;
+   a.upw = c->exec_mode == 1 ? 1.0 : -1.0;
+   a.rel2 = c->rel_tol * c->rel_tol;
+   a.abs2 = c->abs_tol * c->abs_tol;
+   a.max_iter = c->max_iter;
+   a.stencil27 = c->d_st27;
+   a.gh_min = c->gh_min;
+   a.gh_max = c->gh_max;
+   a.dt = dt;
+   a.x_base = x_base;
+   a.rk_a = ra;
+   a.rk_b = rb;
+   a.dt_rk = dt_rk;
+   a.y_out = y_out;
+   a.xe_min_out = c->d_xe_min2;
+   a.xe_max_out = c->d_xe_max2;
+   constexpr int NB = K2Cfg<P>::NB;
+   hipLaunchKernelGGL((ho_kernel2<P, true>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    RMH_HIP(hipGetLastError());
    return 0;
 }
@@ -230,6 +286,8 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_min2, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_max2, ne * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_cg, sizeof(int)));
    RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
    *out = c;
@@ -239,7 +297,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
 void rmh_destroy(rmh_ctx *c)
 {
    if (!c) { return; }
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_m, c->d_xe_min, c->d_xe_max, c->d_nbr, c->d_st27, c->d_cg};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {
@@ -290,6 +348,7 @@ int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
    if (rc) { return rc; }
    rc = timer_end(c, 0, ep);
    c->ho_done = true;
+   c->xe_of = u;
    return rc;
 }
 
@@ -396,6 +455,34 @@ int rmh_limit_fused(rmh_ctx *c, const double *u, const double *du_ho, double dt,
    RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, la));
    RMH_HIP(hipGetLastError());
    return timer_end(c, 3, ep);
+}
+
+int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,
+                    double *y_out, double *du)
+{
+   if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
+   if (y_out == u || du == u) { return fail(RMH_ERR_INVALID, "rmh_stage_fused: the output must not alias u"); }
+   if (c->ng > 0 && (!c->u_ghost || !c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost data not set"); }
+   int rc = 0;
+   if (c->xe_of != u)
+   {
+      // element extrema of the stage input are not at hand: one streaming pass (normally they are
+      // left behind by the previous fused stage, whose output is this stage's input)
+      rc = rmh_elem_minmax(c, u, c->d_xe_min, c->d_xe_max);
+      if (rc) { return rc; }
+   }
+   EventPair ep;
+   rc = timer_begin(c, 0, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, rc = launch_stage_fused<P>(c, u, dt, x_base, a, b, dt_rk, y_out, du));
+   if (rc) { return rc; }
+   rc = timer_end(c, 0, ep);
+   std::swap(c->d_xe_min, c->d_xe_min2);
+   std::swap(c->d_xe_max, c->d_xe_max2);
+   c->xe_of = y_out;
+   c->ho_done = false; // the lumped mass vector is not refreshed by the fused stage
+   return rc;
 }
 
 int rmh_enable_timers(rmh_ctx *c, int on)

@@ -291,11 +291,24 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       int ti = 0;
       HIP_CALL(hipDeviceSynchronize());
       const auto w0 = std::chrono::steady_clock::now();
+      Vector y1(fused ? vsize : 0), y2(fused ? vsize : 0);
       while (!done)
       {
          double dt_real = std::min(dt, t_final - t);
          adv.SetDt(dt_real);
-         ode_solver.Step(u, t, dt_real);
+         if (fused)
+         {
+            // one kernel per RK stage (rmh_stage_fused): same stage times and combinations as
+            // RK3SSPSolver::Step; input and output vectors of a stage differ
+            RMH_CALL(rmh_setup(ctx, t));
+            RMH_CALL(rmh_stage_fused(ctx, u.Read(), dt_real, nullptr, 0.0, 1.0, dt_real, y1.Write(), nullptr));
+            RMH_CALL(rmh_setup(ctx, t + dt_real));
+            RMH_CALL(rmh_stage_fused(ctx, y1.Read(), dt_real, u.Read(), 3. / 4, 1. / 4, dt_real, y2.Write(), nullptr));
+            RMH_CALL(rmh_setup(ctx, t + dt_real / 2));
+            RMH_CALL(rmh_stage_fused(ctx, y2.Read(), dt_real, u.Read(), 1. / 3, 2. / 3, dt_real, u.Write(), nullptr));
+            t += dt_real;
+         }
+         else { ode_solver.Step(u, t, dt_real); }
          ti++;
          done = (t >= t_final - 1.e-8 * dt);
          if (ti == cc.max_steps) { done = true; }

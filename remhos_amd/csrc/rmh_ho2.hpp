@@ -162,7 +162,13 @@ __device__ unsigned long long g_stamps[32];
 #define RMH_STAMP(k)
 #endif
 
-template <int P>
+// FUSED = false: HOSolver::CalcHOSolution (writes du_HO, lumped mass, element extrema of u).
+// FUSED = true : the whole RK stage for -ho 3 -lo 5 -fct 2 (AdvectionOperator::Mult, remhos.cpp:1596-1916,
+//                plus the RK3 vector update): HO as above, then MassBasedAvg (remhos_lo.cpp:247-324),
+//                overlap bounds from the 27-element stencil (remhos_tools.cpp:432-495), ClipScale
+//                (remhos_fct.cpp:449-541), y_out = a*x_base + b*(u + dt_rk*du), and the element extrema of
+//                y_out for the next stage.  du_HO, du_LO, lumped mass and per-dof bounds never leave the CU.
+template <int P, bool FUSED>
 __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 {
 #ifdef RMH_STAMPS
@@ -279,7 +285,8 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
    // ---- phase B: x-contractions of the geometry and of u; face rows -------------------------------
    // element extrema (remhos_tools.cpp:497-523)
    double my_min = INFINITY, my_max = -INFINITY;
-   if (C::WAVE_ALIGNED)
+   if (FUSED) {}
+   else if (C::WAVE_ALIGNED)
    {
       // D3 = 64: the values a wavefront loaded in round j all belong to element (j*NT + tid)/D3
 #pragma unroll
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
          }
       }
    }
-   else if (tid < NB)
+   else if (!FUSED && tid < NB)
    {
       const double *uu = RMH_W(tid) + oU;
       for (int i = 0; i < D3; i++)
@@ -650,6 +657,41 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 
    RMH_STAMP(5);
    // ---- phase I: element-local PCG in the GL nodal basis (DGMassInverse) ----------------------------------
+   // fused stage: the global reads of the limiter part are issued here so that they are in flight during
+   // the PCG iterations (u is an L2 hit: this workgroup read it in phase A)
+   constexpr int NLS = (NB * 27 + NT - 1) / NT;
+   double uu[DR], xb[DR], slo[NLS], shi[NLS];
+   if (FUSED)
+   {
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         uu[r] = 0.0; xb[r] = 0.0;
+         if (t < NB * D3)
+         {
+            const size_t g = (size_t)min(e0 + t / D3, a.ne_owned - 1) * D3 + t % D3;
+            uu[r] = a.u[g];
+            if (a.x_base) { xb[r] = a.x_base[g]; }
+         }
+      }
+#pragma unroll
+      for (int j = 0; j < NLS; j++)
+      {
+         const int k = tid + j * NT;
+         slo[j] = INFINITY; shi[j] = -INFINITY;
+         if (k < NB * 27)
+         {
+            const int e = min(e0 + k / 27, a.ne_owned - 1);
+            const int nb = a.stencil27[(size_t)e * 27 + k % 27];
+            if (nb >= 0)
+            {
+               if (nb < a.ne_owned) { slo[j] = a.xe_min[nb]; shi[j] = a.xe_max[nb]; }
+               else { slo[j] = a.gh_min[nb - a.ne_owned]; shi[j] = a.gh_max[nb - a.ne_owned]; }
+            }
+         }
+      }
+   }
    double xg[DR], dd[DR], nom[DR], tol[DR], tmp[DR], red[DR];
    int its[DR];
    int ring = 0;
@@ -854,20 +896,131 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
    }
    int itmax = 0;
 #pragma unroll
-   for (int r = 0; r < DR; r++)
+   for (int r = 0; r < DR; r++) { itmax = max(itmax, its[r]); }
+   if (!FUSED)
    {
-      const int t = tid + r * NT;
-      if (t < NB * D3 && e0 + t / D3 < a.ne_owned)
+#pragma unroll
+      for (int r = 0; r < DR; r++)
       {
-         a.du[(size_t)e0 * D3 + t] = xg[r];
-         a.m[(size_t)e0 * D3 + t] = mm[r];
-         itmax = max(itmax, its[r]);
+         const int t = tid + r * NT;
+         if (t < NB * D3 && e0 + t / D3 < a.ne_owned)
+         {
+            a.du[(size_t)e0 * D3 + t] = xg[r];
+            a.m[(size_t)e0 * D3 + t] = mm[r];
+         }
+      }
+      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < a.ne_owned)
+      {
+         a.xe_min[e0 + tid] = my_min;
+         a.xe_max[e0 + tid] = my_max;
       }
    }
-   if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < a.ne_owned)
+   else
    {
-      a.xe_min[e0 + tid] = my_min;
-      a.xe_max[e0 + tid] = my_max;
+      // ---- phase K: LimitMult + RK update (W is free: the last back-transform leg ended with a barrier) ----
+      constexpr double eps = 1.0e-15;
+      // stencil extrema -> LDS: smin at W[0..27), smax at W[27..54)
+#pragma unroll
+      for (int j = 0; j < NLS; j++)
+      {
+         const int k = tid + j * NT;
+         if (k < NB * 27)
+         {
+            RMH_W(k / 27)[k % 27] = slo[j];
+            RMH_W(k / 27)[27 + k % 27] = shi[j];
+         }
+      }
+      // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
+      double mass[DR], vol[DR];
+#pragma unroll
+      for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + a.dt * xg[r]); }
+      batch_dot<P>(tmp, mass, s_acc, ring);
+      batch_dot<P>(mm, vol, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
+      double fcl[DR], dlo[DR], pos[DR], neg[DR];
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         fcl[r] = 0.0; dlo[r] = 0.0; pos[r] = 0.0; neg[r] = 0.0;
+         if (t < NB * D3)
+         {
+            const int eb = t / D3, i = t % D3;
+            double lo, hi;
+            dof_bounds<P>(i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
+            const double ubar = mass[r] / vol[r];
+            dlo[r] = (ubar - uu[r]) / a.dt;
+            const double u_new_lo = uu[r] + a.dt * dlo[r];
+            const double f_clip_min = mm[r] / a.dt * (lo - u_new_lo);
+            const double f_clip_max = mm[r] / a.dt * (hi - u_new_lo);
+            double fc = mm[r] * (xg[r] - dlo[r]);
+            fc = fmin(f_clip_max, fmax(f_clip_min, fc));
+            fcl[r] = fc;
+            neg[r] = fmin(fc, 0.0);
+            pos[r] = fmax(fc, 0.0);
+         }
+      }
+      double sumPos[DR], sumNeg[DR];
+      batch_dot<P>(pos, sumPos, s_acc, ring);
+      batch_dot<P>(neg, sumNeg, s_acc, ring);
+      double ynew[DR];
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         ynew[r] = 0.0;
+         if (t < NB * D3)
+         {
+            const double new_mass = sumNeg[r] + sumPos[r];
+            double fc = fcl[r];
+            if (new_mass > eps) { fc = fmin(0.0, fc) - fmax(0.0, fc) * sumNeg[r] / sumPos[r]; }
+            if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos[r] / sumNeg[r]; }
+            const double dui = dlo[r] + fc / mm[r];
+            ynew[r] = (a.x_base ? a.rk_a * xb[r] : 0.0) + a.rk_b * (uu[r] + a.dt_rk * dui);
+            if (e0 + t / D3 < a.ne_owned)
+            {
+               a.y_out[(size_t)e0 * D3 + t] = ynew[r];
+               if (a.du) { a.du[(size_t)e0 * D3 + t] = dui; }
+            }
+         }
+      }
+      // element extrema of the new state
+      if (C::WAVE_ALIGNED)
+      {
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            const double lo = wave_minmax<true>(t < NB * D3 ? ynew[r] : INFINITY);
+            const double hi = wave_minmax<false>(t < NB * D3 ? ynew[r] : -INFINITY);
+            if ((tid & 63) == 63 && t < NB * D3 && e0 + t / D3 < a.ne_owned)
+            {
+               a.xe_min_out[e0 + t / D3] = lo;
+               a.xe_max_out[e0 + t / D3] = hi;
+            }
+         }
+      }
+      else
+      {
+         __syncthreads();
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            if (t < NB * D3) { RMH_W(t / D3)[64 + t % D3] = ynew[r]; }
+         }
+         __syncthreads();
+         if (tid < NB && e0 + tid < a.ne_owned)
+         {
+            double lo = INFINITY, hi = -INFINITY;
+            for (int i = 0; i < D3; i++)
+            {
+               lo = fmin(lo, RMH_W(tid)[64 + i]);
+               hi = fmax(hi, RMH_W(tid)[64 + i]);
+            }
+            a.xe_min_out[e0 + tid] = lo;
+            a.xe_max_out[e0 + tid] = hi;
+         }
+      }
    }
    // diagnostics: max PCG iteration count over the launch.  A global atomic per wavefront on ONE
    // address serialises at the memory side (~5 ns each: 3 ms per launch at 500 k wavefronts), so the

@@ -56,6 +56,14 @@ struct HoArgs
    double upw;             // upwind sign: s = max(0, upw * v.n_out): -1 transport, +1 remap
    double rel2, abs2;      // squared tolerances of the local PCG
    int max_iter;
+   // fused stage (ho_kernel2<P, true>): LimitMult for -lo 5 -fct 2 and the RK update in the same kernel
+   const int *stencil27;            // [ne][27]
+   const double *gh_min, *gh_max;   // ghost element extrema
+   double dt;                       // full time step (LO / FCT)
+   const double *x_base;            // y_out = rk_a * x_base + rk_b * (u + dt_rk * du)
+   double rk_a, rk_b, dt_rk;
+   double *y_out;
+   double *xe_min_out, *xe_max_out; // extrema of y_out (input extrema of the next stage)
 };
 
 // ---------------------------------------------------------------------------------------

@@ -15,13 +15,14 @@ from .capi import Context
 
 
 class Stepper:
-    def __init__(self, lib, case, device="cuda:0", dist=None, fused=True):
+    def __init__(self, lib, case, device="cuda:0", dist=None, fused=True, one_kernel=True):
         self.case = case
         self.dev = torch.device(device)
         self.dist = dist if (dist is not None and case.peers) else None
         self.lo = int(case.cfg.lo_type)
         self.fused = fused and self.lo == 5
         fused = self.fused
+        self.one_kernel = one_kernel and self.fused  # whole stage in one kernel (rmh_stage_fused)
         dev_index = self.dev.index or 0
         self.ctx = Context(lib, order=case.order, exec_mode=case.exec_mode, x0=case.x0, vel=case.vel,
                            face_nbr=case.face_nbr, stencil27=case.stencil27, ne_ghost=case.ne_ghost,
@@ -33,6 +34,7 @@ class Stepper:
         self.x = torch.from_numpy(case.u0).to(self.dev).contiguous()
         self.y = torch.empty_like(self.x)
         self.k = torch.empty_like(self.x)
+        self.y2 = torch.empty_like(self.x) if self.one_kernel else None
         if not fused:
             self.du_lo = torch.empty_like(self.x)
             self.umin = torch.empty_like(self.x)
@@ -85,6 +87,9 @@ class Stepper:
         c = self.ctx
         self.exchange(u)
         c.setup(t)
+        if self.one_kernel:
+            c.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt)
+            return
         c.ho_apply(u, self.k)
         if self.fused:
             c.limit_fused(u, self.k, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
@@ -108,6 +113,14 @@ class Stepper:
     def step(self, dt):
         """RK3SSPSolver::Step: stage times t, t+dt, t+dt/2 (SURVEY A.6)."""
         x, y, t = self.x, self.y, self.t
+        if self.one_kernel:
+            # the one-kernel stage reads neighbour traces of its input while other workgroups already
+            # write the output: input and output must be different vectors (x_base may be the output)
+            self.stage(x, t, dt, None, 0.0, 1.0, y)
+            self.stage(y, t + dt, dt, x, 0.75, 0.25, self.y2)
+            self.stage(self.y2, t + dt / 2, dt, x, 1.0 / 3.0, 2.0 / 3.0, x)
+            self.t = t + dt
+            return
         self.stage(x, t, dt, None, 0.0, 1.0, y)
         self.stage(y, t + dt, dt, x, 0.75, 0.25, y)
         self.stage(y, t + dt / 2, dt, x, 1.0 / 3.0, 2.0 / 3.0, x)

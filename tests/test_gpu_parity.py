@@ -170,3 +170,44 @@ def test_lo_rdsubcell_parity(gpu, mesh, rs, p, prob, t):
     torch.cuda.synchronize()
     assert _relerr(du_lo.cpu().numpy(), keep["du_lo"]) < 1e-12
     ctx.close()
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,t", [("cube01_hex", 2, 3, 10, 0.5), ("periodic-cube", 1, 3, 10, 0.4),
+                                             ("cube01_hex", 1, 2, 10, 0.3), ("periodic-cube", 1, 1, 10, 0.6),
+                                             ("periodic-cube", 1, 3, 0, 0.0), ("cube01_hex", 1, 4, 10, 0.3),
+                                             ("cube01_hex", 0, 6, 10, 0.3)])
+def test_one_kernel_stage(gpu, mesh, rs, p, prob, t):
+    """rmh_stage_fused: HO + MassBasedAvg + bounds + ClipScale + RK update in one kernel, against the
+    oracle's stage and against the multi-kernel path; also the element extrema it leaves for the next
+    stage (checked through a second stage on its own output)."""
+    torch, lib = gpu
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    u_h = perturbed(r.u)
+    keep = {}
+    du_ref = r.stage(u_h, t, cfg.dt, keep)
+    y_ref = 0.75 * r.u + 0.25 * (u_h + cfg.dt * du_ref)
+    du2_ref = r.stage(y_ref, t, cfg.dt)
+    dev = "cuda:0"
+    u = torch.from_numpy(u_h).to(dev)
+    xb = torch.from_numpy(r.u.copy()).to(dev)
+    y, du, y2, du2 = (torch.empty_like(u) for _ in range(4))
+    ctx.setup(t)
+    ctx.stage_fused(u, cfg.dt, y, x_base=xb, a=0.75, b=0.25, dt_rk=cfg.dt, du=du)
+    ctx.stage_fused(y, cfg.dt, y2, du=du2)  # uses the extrema left behind by the first call
+    torch.cuda.synchronize()
+    tol = REL[p]
+    assert _relerr(du.cpu().numpy(), du_ref) < tol
+    assert _relerr(y.cpu().numpy(), y_ref) < tol
+    assert _relerr(du2.cpu().numpy(), du2_ref) < 10 * tol
+    # output must not alias the input
+    from remhos_amd.capi import RmhError
+
+    with pytest.raises(RmhError, match="alias"):
+        ctx.stage_fused(u, cfg.dt, u)
+    ctx.close()
