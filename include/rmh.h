@@ -95,6 +95,15 @@ int rmh_setup(rmh_ctx *ctx, double t);
 int rmh_set_ghost_u(rmh_ctx *ctx, const double *u_ghost);
 int rmh_set_ghost_minmax(rmh_ctx *ctx, const double *xe_min_ghost, const double *xe_max_ghost);
 
+/* Halo pack (device): for the nsend owned elements listed in send_elems (device int array; the send
+ * lists of all neighbour ranks concatenated) write their ndof values of u to rows[nsend][ndof] and their
+ * min / max to out_min/out_max[nsend].  The receiver stores the rows in its ghost block and the extrema in
+ * its ghost min/max arrays (one contiguous slice per neighbour rank), i.e. what
+ * ParGridFunction::ExchangeFaceNbrData (remhos_ho.cpp:122) and the GroupCommunicator min/max reduction
+ * (remhos_tools.cpp:461-466) deliver in the reference. */
+int rmh_halo_pack(rmh_ctx *ctx, const double *u, const int *send_elems, int nsend, double *rows,
+                  double *out_min, double *out_max);
+
 /* HOSolver::CalcHOSolution (remhos_ho.hpp:38, LocalInverseHOSolver remhos_ho.cpp:84-129):
  * du = M^-1 (K_vol + K_face) u with an element-local, tightly converged mass solve.
  * Also refreshes the lumped mass vector (remhos.cpp:1632) and the element extrema of u. */

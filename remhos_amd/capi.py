@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librmh.so")
 # every symbol include/rmh.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
-    "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_ho_apply", "rmh_lumped_mass",
+    "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_stage_fused", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
     "rmh_last_cg_iters", "rmh_set_mass_tol",
@@ -60,6 +60,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_setup.argtypes = [p, d]
     lib.rmh_set_ghost_u.argtypes = [p, p]
     lib.rmh_set_ghost_minmax.argtypes = [p, p, p]
+    lib.rmh_halo_pack.argtypes = [p, p, p, i, p, p, p]
     lib.rmh_ho_apply.argtypes = [p, p, p]
     lib.rmh_lumped_mass.argtypes = [p]
     lib.rmh_lumped_mass.restype = p
@@ -153,6 +154,10 @@ class Context:
 
     def _keep_ref(self, key, obj):
         self.__dict__["_ref_" + key] = obj
+
+    def halo_pack(self, u, send_elems, nsend, rows, out_min, out_max):
+        self._check(self.lib.rmh_halo_pack(self.h, _ptr(u), _ptr(send_elems), int(nsend), _ptr(rows), _ptr(out_min),
+                                           _ptr(out_max)))
 
     def ho_apply(self, u, du):
         self._check(self.lib.rmh_ho_apply(self.h, _ptr(u), _ptr(du)))

@@ -485,6 +485,17 @@ int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base
    return rc;
 }
 
+int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend, double *rows, double *out_min,
+                  double *out_max)
+{
+   if (!c || !u || (nsend > 0 && (!send_elems || !rows || !out_min || !out_max))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (nsend <= 0) { return RMH_OK; }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((halo_pack_kernel<P>), dim3(nsend), dim3(KCfg<P>::NT), 0, c->stream, u, send_elems,
+                                      rows, out_min, out_max));
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
 int rmh_enable_timers(rmh_ctx *c, int on)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }

@@ -56,7 +56,7 @@ struct K2Cfg : TabLayout<P>
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
    static constexpr int EL0 = W + RF;
    static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
-   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2;
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + 8 * NB;
    static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
    static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 4 ? 4 : (160 * 1024) / LDS_BYTES);
@@ -104,7 +104,8 @@ __device__ inline double wave_minmax(double v)
 //   rounds are reduced together with a halving butterfly -- 6 cross-lane steps for both values;
 //   generic path: LDS float64 atomics.
 template <int P>
-__device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[K2Cfg<P>::DR], double *s_acc3, int &ring)
+__device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[K2Cfg<P>::DR], double *lds, double *s_acc3,
+                                 int &ring)
 {
    using C = K2Cfg<P>;
    const int tid = threadIdx.x;
@@ -128,13 +129,44 @@ __device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[
    }
    else
    {
-      if (tid < C::NB) { old[tid] = 0.0; }
+      // generic orders: deterministic two-level sum (no atomics: the result must not depend on the
+      // arrival order -- rank-count invariance of the whole run is checked bit for bit).  Values go to
+      // the sB slot of the element block (free outside phase J), CH chunks per element are summed
+      // serially by one thread each, the chunk sums are added in order.
+      constexpr int CH = 8, CL = (C::D3 + CH - 1) / CH;
+      (void)old;
 #pragma unroll
       for (int r = 0; r < C::DR; r++)
       {
          const int t = tid + r * C::NT;
-         if (t < C::NB * C::D3) { atomicAdd(&cur[t / C::D3], v[r]); }
+         if (t < C::NB * C::D3) { (lds + (t / C::D3) * C::EL)[C::oSB + t % C::D3] = v[r]; }
       }
+      __syncthreads();
+      double *part = s_acc3 + 4 * C::NB + 8 + C::N2; // [NB][CH], behind the table copy
+      for (int k = tid; k < C::NB * CH; k += C::NT)
+      {
+         const double *src = lds + (k / CH) * C::EL + C::oSB;
+         const int i0 = (k % CH) * CL;
+         double acc = 0.0;
+         for (int i = i0; i < i0 + CL && i < C::D3; i++) { acc += src[i]; }
+         part[k] = acc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const int t = tid + r * C::NT;
+         double acc = 0.0;
+         if (t < C::NB * C::D3)
+         {
+            const double *pp = part + (t / C::D3) * CH;
+#pragma unroll
+            for (int c = 0; c < CH; c++) { acc += pp[c]; }
+         }
+         out[r] = acc;
+      }
+      ring = (ring + 1) % 3;
+      return;
    }
    __syncthreads();
 #pragma unroll
@@ -704,7 +736,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
    }
-   batch_dot<P>(tmp, nom, s_acc, ring);
+   batch_dot<P>(tmp, nom, lds, s_acc, ring);
    bool act[DR];
    {
       bool any = false;
@@ -826,7 +858,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #ifdef RMH_ABL_NODOT
       for (int r = 0; r < DR; r++) { red[r] = nom[r]; }
 #else
-      batch_dot<P>(tmp, red, s_acc, ring); // den = d.Ad
+      batch_dot<P>(tmp, red, lds, s_acc, ring); // den = d.Ad
 #endif
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -842,7 +874,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #ifdef RMH_ABL_NODOT
       for (int r = 0; r < DR; r++) { red[r] = 0.0; }
 #else
-      batch_dot<P>(tmp, red, s_acc, ring); // betanom = r.z
+      batch_dot<P>(tmp, red, lds, s_acc, ring); // betanom = r.z
 #endif
       RMH_STAMP(15);
       bool any = false;
@@ -934,8 +966,8 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
       double mass[DR], vol[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + a.dt * xg[r]); }
-      batch_dot<P>(tmp, mass, s_acc, ring);
-      batch_dot<P>(mm, vol, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
+      batch_dot<P>(tmp, mass, lds, s_acc, ring);
+      batch_dot<P>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
       double fcl[DR], dlo[DR], pos[DR], neg[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -960,8 +992,8 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
          }
       }
       double sumPos[DR], sumNeg[DR];
-      batch_dot<P>(pos, sumPos, s_acc, ring);
-      batch_dot<P>(neg, sumNeg, s_acc, ring);
+      batch_dot<P>(pos, sumPos, lds, s_acc, ring);
+      batch_dot<P>(neg, sumNeg, lds, s_acc, ring);
       double ynew[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)

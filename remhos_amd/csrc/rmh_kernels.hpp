@@ -905,6 +905,31 @@ __global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(const int *stencil2
    }
 }
 
+// Halo pack: for every element a neighbour rank needs (send_elems, all peers concatenated) copy its
+// ndof values of u and its min / max into contiguous send buffers -- the payload of
+// ParGridFunction::ExchangeFaceNbrData (remhos_ho.cpp:122) and of the GroupCommunicator min/max
+// reduction (remhos_tools.cpp:461-466) in one pass.
+template <int P>
+__global__ void __launch_bounds__(KCfg<P>::NT) halo_pack_kernel(const double *u, const int *send_elems, double *rows,
+                                                                double *out_min, double *out_max)
+{
+   using C = KCfg<P>;
+   __shared__ double s_red[4];
+   const int k = blockIdx.x;
+   const int e = send_elems[k];
+   double lmin = INFINITY, lmax = -INFINITY;
+   for (int i = threadIdx.x; i < C::D3; i += C::NT)
+   {
+      const double v = u[(size_t)e * C::D3 + i];
+      rows[(size_t)k * C::D3 + i] = v;
+      lmin = fmin(lmin, v);
+      lmax = fmax(lmax, v);
+   }
+   lmin = block_min<C::NW>(lmin, s_red);
+   lmax = block_max<C::NW>(lmax, s_red);
+   if (threadIdx.x == 0) { out_min[k] = lmin; out_max[k] = lmax; }
+}
+
 // MassBasedAvg::CalcLOSolution (remhos_lo.cpp:247-324): du_lo = (ubar - u)/dt with
 // ubar = int (u + dt du_ho) / int 1 over the element at the current mesh position.
 // int u_h = sum_i m_i u_i with the lumped mass (Bernstein partition of unity).

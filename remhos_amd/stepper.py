@@ -51,36 +51,41 @@ class Stepper:
         if ng:
             self.ctx.set_ghost_u(self.ug)
             self.ctx.set_ghost_minmax(self.gmin, self.gmax)
+        # exchange plan: ghost slots of a peer are a contiguous range (ghosts are ordered by owner rank,
+        # then global id), so received rows land directly in the ghost arrays; one device pack kernel
+        # gathers the rows (+ min / max) of all peers' send lists
         self.plan = []
+        send_all, off = [], 0
         for rank, send, recv in case.peers:
-            s = torch.from_numpy(send.astype("int64")).to(self.dev)
-            r = torch.from_numpy(recv.astype("int64")).to(self.dev)
-            sb = torch.empty(len(send), nd + 2, **f64)
-            rb = torch.empty(len(recv), nd + 2, **f64)
-            self.plan.append((rank, s, r, sb, rb))
+            r0, r1 = int(recv[0]), int(recv[-1]) + 1
+            assert r1 - r0 == len(recv) and (recv == range(r0, r1)).all(), "ghost slots of a peer must be contiguous"
+            self.plan.append((rank, off, off + len(send), r0, r1))
+            send_all.append(send)
+            off += len(send)
+        self.nsend = off
+        if self.plan:
+            import numpy as np
 
-    # -- halo exchange: neighbour all-to-all of packed [u | min | max] rows ---------------------
+            self.send_elems = torch.from_numpy(np.concatenate(send_all).astype("int32")).to(self.dev)
+            self.srows = torch.empty(self.nsend, nd, **f64)
+            self.smin = torch.empty(self.nsend, **f64)
+            self.smax = torch.empty(self.nsend, **f64)
+
+    # -- halo exchange: neighbour all-to-all of [u rows | min | max] ---------------------------------
     def exchange(self, u):
         if not self.plan:
             return
-        nd = self.case.ndof
-        ops = []
-        for rank, s, r, sb, rb in self.plan:
-            rows = u.index_select(0, s)
-            sb[:, :nd] = rows
-            sb[:, nd] = rows.amin(dim=1)
-            sb[:, nd + 1] = rows.amax(dim=1)
         if self.dist is None:
             raise RuntimeError("this rank has neighbour ranks but no torch.distributed group was given")
-        for rank, s, r, sb, rb in self.plan:
-            ops.append(self.dist.P2POp(self.dist.isend, sb, rank))
-            ops.append(self.dist.P2POp(self.dist.irecv, rb, rank))
-        for w in self.dist.batch_isend_irecv(ops):
+        d = self.dist
+        self.ctx.halo_pack(u, self.send_elems, self.nsend, self.srows, self.smin, self.smax)
+        ops = []
+        for rank, s0, s1, r0, r1 in self.plan:
+            ops += [d.P2POp(d.isend, self.srows[s0:s1], rank), d.P2POp(d.irecv, self.ug[r0:r1], rank),
+                    d.P2POp(d.isend, self.smin[s0:s1], rank), d.P2POp(d.irecv, self.gmin[r0:r1], rank),
+                    d.P2POp(d.isend, self.smax[s0:s1], rank), d.P2POp(d.irecv, self.gmax[r0:r1], rank)]
+        for w in d.batch_isend_irecv(ops):
             w.wait()
-        for rank, s, r, sb, rb in self.plan:
-            self.ug.index_copy_(0, r, rb[:, :nd])
-            self.gmin.index_copy_(0, r, rb[:, nd])
-            self.gmax.index_copy_(0, r, rb[:, nd + 1])
 
     # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
     def stage(self, u, t, dt, x_base, a, b, out):
