@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--order", type=int, default=3)
     ap.add_argument("--mesh", default="periodic-cube")
     ap.add_argument("--problem", type=int, default=10)
+    ap.add_argument("--lo", type=int, default=5, help="LO solver: 5 mass-based average (default), 4 subcell residual distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference call sequence instead of the fused limiter")
     ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
@@ -112,7 +113,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     lib = bind_driver(load_library())
-    cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, part=PART[args.gpus], rank=rank)
+    cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, lo_type=args.lo, part=PART[args.gpus], rank=rank)
     t0 = time.perf_counter()
     case = Case(lib, cfg)
     st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused, one_kernel=not args.two_kernels)
@@ -186,7 +187,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.mesh} -rs {args.rs} -o {args.order} -p {args.problem} remap, -pa -ho 3 -lo 5 -fct 2, RK3-SSP "
+                "workload": f"{args.mesh} -rs {args.rs} -o {args.order} -p {args.problem} remap, -pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP "
                             f"(BASELINE configs[1]); {case.ne_global} hex, {global_dofs} dofs",
                 "global_dofs": global_dofs,
                 "elements": case.ne_global,
@@ -210,7 +211,7 @@ def main():
                 "alg_bytes_per_launch": ho_bytes,
                 "note": "FP64 VALU / latency bound at p=3 in matrix-free form (geometry recomputed per stage), not HBM bound; see DESIGN.md 3.1",
             },
-            "buckets_s": {"ho_rhs_plus_inv": tim[0], "lo": tim[2], "fct_fused_limiter": tim[3]},
+            "buckets_s": {"ho_rhs_plus_inv_or_stage": tim[0], "lo": tim[2], "fct_or_fused_limiter": tim[3]},
             "stage_roofline": {
                 "alg_bytes_per_dof": stage_alg_bytes_per_dof(args.order),
                 "achieved_GBs": value * 1e6 * stage_alg_bytes_per_dof(args.order) / 1e9,

@@ -141,6 +141,11 @@ int rmh_fct_clipscale(rmh_ctx *ctx, const double *u, const double *m,
 int rmh_limit_fused(rmh_ctx *ctx, const double *u, const double *du_ho, double dt, double *du,
                     const double *x_base, double a, double b, double dt_rk, double *y_out);
 
+/* Same limiter pass for an LO rate that was computed by another LOSolver (lo 4: rmh_lo_rdsubcell):
+ * overlap bounds + ClipScale (+ RK update) without materialising u_min / u_max. */
+int rmh_limit_fused_lo(rmh_ctx *ctx, const double *u, const double *du_ho, const double *du_lo, double dt,
+                       double *du, const double *x_base, double a, double b, double dt_rk, double *y_out);
+
 /* The whole RK stage in ONE kernel for -ho 3 -lo 5 -fct 2: AdvectionOperator::Mult = MultUnlimited +
  * LimitMult (remhos_solvers.hpp:46-50, remhos.cpp:1596-1916) and the RK vector update
  *   y_out = a * x_base + b * (u + dt_rk * du)          (x_base may be NULL: a is ignored)

@@ -45,6 +45,7 @@ struct rmh_ctx
    hipStream_t stream = nullptr;
    double t = 0.0;
    double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
+   double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
    double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
    const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold
@@ -139,6 +140,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.face_nbr = c->d_nbr;
    a.tab = c->d_tab;
    a.subvel = c->d_subvel;
+   a.subx0 = c->d_subx0;
+   a.subvmid = c->d_subvmid;
    a.du = du;
    a.m = m;
    a.xe_min = c->d_xe_min;
@@ -163,10 +166,15 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.y_out = nullptr;
    a.xe_min_out = nullptr;
    a.xe_max_out = nullptr;
-   if (MODE == 0 && c->ho_variant == 2)
+   if (MODE == 2 && c->ho_variant == 2 && P >= 2)
+   {
+      constexpr int NB = K2Cfg<P, true>::NB;
+      hipLaunchKernelGGL((ho_kernel2<(P >= 2 ? P : 2), 2>), dim3((c->ne + NB - 1) / NB), dim3(256), 0, c->stream, a);
+   }
+   else if (MODE == 0 && c->ho_variant == 2)
    {
       constexpr int NB = K2Cfg<P>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P, false>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+      hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    else
    {
@@ -188,6 +196,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.face_nbr = c->d_nbr;
    a.tab = c->d_tab;
    a.subvel = c->d_subvel;
+   a.subx0 = c->d_subx0;
+   a.subvmid = c->d_subvmid;
    a.du = du;
    a.m = c->d_m;
    a.xe_min = c->d_xe_min;
@@ -213,7 +223,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.xe_min_out = c->d_xe_min2;
    a.xe_max_out = c->d_xe_max2;
    constexpr int NB = K2Cfg<P>::NB;
-   hipLaunchKernelGGL((ho_kernel2<P, true>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+   hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    RMH_HIP(hipGetLastError());
    return 0;
 }
@@ -283,6 +293,16 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    }
    RMH_DISPATCH(c, rc = create_tables<P>(c));
    if (rc) { delete c; return rc; }
+   if (c->d_subvel)
+   {
+      const size_t ns = (size_t)c->p * c->p * c->p;
+      RMH_HIP(hipMalloc((void **)&c->d_subx0, ne * 3 * c->ndof * sizeof(double)));
+      RMH_HIP(hipMalloc((void **)&c->d_subvmid, ne * 3 * ns * sizeof(double)));
+      RMH_DISPATCH(c, hipLaunchKernelGGL((subcell_setup_kernel<P>), dim3(c->ne), dim3(64), 0, nullptr, (const double *)c->d_x0,
+                                         (const double *)c->d_subvel, (const double *)c->d_tab, c->d_subx0, c->d_subvmid));
+      RMH_HIP(hipGetLastError());
+      RMH_HIP(hipDeviceSynchronize());
+   }
    RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));
@@ -297,7 +317,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
 void rmh_destroy(rmh_ctx *c)
 {
    if (!c) { return; }
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {
@@ -426,8 +446,8 @@ int rmh_fct_clipscale(rmh_ctx *c, const double *u, const double *m, const double
    return timer_end(c, 3, ep);
 }
 
-int rmh_limit_fused(rmh_ctx *c, const double *u, const double *du_ho, double dt, double *du, const double *x_base,
-                    double a, double b, double dt_rk, double *y_out)
+static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, const double *du_lo, double dt, double *du,
+                            const double *x_base, double a, double b, double dt_rk, double *y_out)
 {
    if (!c || !u || !du_ho || (!du && !y_out)) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_limit_fused must follow rmh_ho_apply on the same u"); }
@@ -436,6 +456,7 @@ int rmh_limit_fused(rmh_ctx *c, const double *u, const double *du_ho, double dt,
    la.u = u;
    la.du_ho = du_ho;
    la.m = c->d_m;
+   la.du_lo = du_lo;
    la.stencil27 = c->d_st27;
    la.xe_min = c->d_xe_min;
    la.xe_max = c->d_xe_max;
@@ -455,6 +476,19 @@ int rmh_limit_fused(rmh_ctx *c, const double *u, const double *du_ho, double dt,
    RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, la));
    RMH_HIP(hipGetLastError());
    return timer_end(c, 3, ep);
+}
+
+int rmh_limit_fused(rmh_ctx *c, const double *u, const double *du_ho, double dt, double *du, const double *x_base,
+                    double a, double b, double dt_rk, double *y_out)
+{
+   return limit_fused_impl(c, u, du_ho, nullptr, dt, du, x_base, a, b, dt_rk, y_out);
+}
+
+int rmh_limit_fused_lo(rmh_ctx *c, const double *u, const double *du_ho, const double *du_lo, double dt, double *du,
+                       const double *x_base, double a, double b, double dt_rk, double *y_out)
+{
+   if (!du_lo) { return fail(RMH_ERR_INVALID, "null du_lo"); }
+   return limit_fused_impl(c, u, du_ho, du_lo, dt, du, x_base, a, b, dt_rk, y_out);
 }
 
 int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,

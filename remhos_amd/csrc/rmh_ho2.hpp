@@ -30,7 +30,7 @@ namespace rmh
 #define RMH_ABL_MASK 0 // diagnostic builds only: bit k skips a piece of the PCG iteration
 #endif
 
-template <int P>
+template <int P, bool LO4 = false>
 struct K2Cfg : TabLayout<P>
 {
    using T = TabLayout<P>;
@@ -49,12 +49,17 @@ struct K2Cfg : TabLayout<P>
    static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    static constexpr int oR3 = 0, oR2 = 3 * Q2 * D, PF = oR2 + 3 * Q * D2;
    static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
-   static constexpr int W = cmax(PA, cmax(PF, PCG));
+   // lo 4 (subcell residual distribution) extras: sub-mesh node positions behind the phase A-C data,
+   // subcell data [6][NS] and the lumped face flux per dof behind the face buffer
+   static constexpr int NS = P * P * P;
+   static constexpr int oXs = PA;
+   static constexpr int W = cmax(PA + (LO4 ? 3 * D3 : 0), cmax(PF, PCG));
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
    static constexpr int oF = W;
+   static constexpr int oSub = oF + RF, oDuf = oSub + 6 * NS;
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
-   static constexpr int EL0 = W + RF;
+   static constexpr int EL0 = W + RF + (LO4 ? 6 * NS + D3 : 0);
    static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
    static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + 8 * NB;
    static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
@@ -103,11 +108,9 @@ __device__ inline double wave_minmax(double v)
 //   fast path (p = 3: D3 = 64 dofs = one wavefront per element and round, two rounds): the two
 //   rounds are reduced together with a halving butterfly -- 6 cross-lane steps for both values;
 //   generic path: LDS float64 atomics.
-template <int P>
-__device__ inline void batch_dot(const double (&v)[K2Cfg<P>::DR], double (&out)[K2Cfg<P>::DR], double *lds, double *s_acc3,
-                                 int &ring)
+template <class C>
+__device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR], double *lds, double *s_acc3, int &ring)
 {
-   using C = K2Cfg<P>;
    const int tid = threadIdx.x;
    double *cur = s_acc3 + ring * C::NB;
    double *old = s_acc3 + ((ring + 1) % 3) * C::NB; // used two calls ago
@@ -200,13 +203,19 @@ __device__ unsigned long long g_stamps[32];
 //                overlap bounds from the 27-element stencil (remhos_tools.cpp:432-495), ClipScale
 //                (remhos_fct.cpp:449-541), y_out = a*x_base + b*(u + dt_rk*du), and the element extrema of
 //                y_out for the next stage.  du_HO, du_LO, lumped mass and per-dof bounds never leave the CU.
-template <int P, bool FUSED>
-__global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
+// MODE 2        : PAResidualDistributionSubcell::CalcLOSolution (remhos_lo.cpp:1620-1802) with the same batching:
+//                 z = K_vol u, lumped upwind face fluxes, sub-mesh motion and subcell fluctuations, nodal
+//                 weights, du_LO; also writes the lumped mass and the element extrema (like the reference's
+//                 RD solver does, remhos_lo.cpp:1702-1716).  No mass solve.
+template <int P, int MODE>
+__global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_kernel2(HoArgs a)
 {
+   constexpr bool FUSED = MODE == 1;
+   constexpr bool LO4 = MODE == 2;
 #ifdef RMH_STAMPS
    unsigned long long stamp_prev_ = clock64();
 #endif
-   using C = K2Cfg<P>;
+   using C = K2Cfg<P, MODE == 2>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NB = C::NB, DR = C::DR;
    constexpr int S2 = C::S2;
    constexpr int oXV = C::oXV, oU = C::oU, oNb = C::oNb, oU1 = C::oU1, oR3 = C::oR3, oR2 = C::oR2, oSA = C::oSA,
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
    // ---- phase B: x-contractions of the geometry and of u; face rows -------------------------------
    // element extrema (remhos_tools.cpp:497-523)
    double my_min = INFINITY, my_max = -INFINITY;
-   if (FUSED) {}
+   if (FUSED || LO4) {}
    else if (C::WAVE_ALIGNED)
    {
       // D3 = 64: the values a wavefront loaded in round j all belong to element (j*NT + tid)/D3
@@ -334,7 +343,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
          }
       }
    }
-   else if (!FUSED && tid < NB)
+   else if (!FUSED && !LO4 && tid < NB)
    {
       const double *uu = RMH_W(tid) + oU;
       for (int i = 0; i < D3; i++)
@@ -367,6 +376,17 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
       }
    }
    RMH_STAMP(1);
+   if (LO4)
+   {
+      // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
+      for (int k = tid; k < NB * 3 * D3; k += NT)
+      {
+         const int eb = k / (3 * D3), r3 = k % (3 * D3);
+         const size_t g = (size_t)min(e0 + eb, a.ne_owned - 1) * 3 * D3 + r3;
+         const double xs0 = a.subx0[g];
+         RMH_W(eb)[C::oXs + r3] = a.move ? xs0 + a.t * a.subvel[g] : xs0;
+      }
+   }
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
@@ -449,15 +469,106 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
          double jump = 0.0;
 #pragma unroll
          for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
-         const double val = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2] * jump;
+         const double sq = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2];
+         const double val = LO4 ? sq : sq * jump;
 #pragma unroll
-         for (int k2 = 0; k2 < D; k2++) { tq[k2] += gt[oBg + q2 * D + k2] * val; }
+         for (int k2 = 0; k2 < D; k2++) { tq[k2] += gt[(LO4 ? oB : oBg) + q2 * D + k2] * val; }
       }
 #pragma unroll
       for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[oF + (f * Q + q1) * D + k2] = tq[k2]; }
    }
    __syncthreads();
 
+   if (LO4)
+   {
+      constexpr int NS = C::NS;
+      const double eps = 1.E-15;
+      // subcell fluctuations with the 1-point rule on the trilinear subcells and subcell extrema
+      // (SetupSubCellPA3D / ApplySubCellWeights remhos_lo.cpp:1137-1192, 1313-1618; :1733-1757)
+      for (int k = tid; k < NB * NS; k += NT)
+      {
+         const int eb = k / NS, m = k % NS;
+         const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
+         const int base = mx + D * my + D2 * mz;
+         const double *su_ = RMH_W(eb) + oU, *xs = RMH_W(eb) + C::oXs;
+         const int e = min(e0 + eb, a.ne_owned - 1);
+         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
+         double umax = -INFINITY, umin = INFINITY, usum = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+         {
+            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
+            const double uj = su_[i];
+            umax = fmax(umax, uj);
+            umin = fmin(umin, uj);
+            usum += uj;
+#pragma unroll
+            for (int comp = 0; comp < 3; comp++)
+            {
+               const double x = xs[comp * D3 + i];
+               J[comp][0] += ((j & 1) ? 0.25 : -0.25) * x;
+               J[comp][1] += ((j & 2) ? 0.25 : -0.25) * x;
+               J[comp][2] += ((j & 4) ? 0.25 : -0.25) * x;
+            }
+         }
+#pragma unroll
+         for (int comp = 0; comp < 3; comp++) { vm[comp] = a.subvmid[((size_t)e * 3 + comp) * NS + m]; }
+         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
+         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
+         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
+         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
+         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+         const double q0 = a.alpha * (A11 * vm[0] + A12 * vm[1] + A13 * vm[2]);
+         const double q1v = a.alpha * (A21 * vm[0] + A22 * vm[1] + A23 * vm[2]);
+         const double q2v = a.alpha * (A31 * vm[0] + A32 * vm[1] + A33 * vm[2]);
+         double fluct = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+         {
+            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
+            const double w = ((j & 1) ? 0.25 : -0.25) * q0 + ((j & 2) ? 0.25 : -0.25) * q1v + ((j & 4) ? 0.25 : -0.25) * q2v;
+            fluct += w * su_[i];
+         }
+         double *fl = RMH_W(eb) + C::oSub;
+         fl[0 * NS + m] = fmax(0., fluct);
+         fl[1 * NS + m] = fmin(0., fluct);
+         fl[2 * NS + m] = umax;
+         fl[3 * NS + m] = umin;
+         // eqs. (58)-(59): the ratio fluct^+- / sumWeightsSubcell^+- is formed once per subcell
+         fl[4 * NS + m] = fmax(0., fluct) / (8 * umax - usum + eps);
+         fl[5 * NS + m] = fmin(0., fluct) / (8 * umin - usum - eps);
+      }
+      // lumped upwind face fluxes (ApplyFaceTerms3D, remhos_lo.cpp:795-871), gathered per dof:
+      // (B^T D B 1)_i (u_nbr,i - u_i) with the face rows already tested along q2
+      for (int t = tid; t < NB * D3; t += NT)
+      {
+         const int eb = t / D3, i = t % D3;
+         const int idx[3] = {i % D, (i / D) % D, i / D2};
+         const double ui = RMH_W(eb)[oU + i];
+         double acc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 3; c++)
+         {
+            const int ic = idx[c];
+            if (ic == 0 || ic == P)
+            {
+               const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+               const int i1 = idx[c1], i2 = idx[c2];
+               const int f = 2 * c + (ic == P ? 1 : 0);
+               const double *F = RMH_W(eb) + oF + f * Q * D + i2;
+               double coef = 0.0;
+#pragma unroll
+               for (int q1 = 0; q1 < Q; q1++) { coef += stab[oB + q1 * D + i1] * F[q1 * D]; }
+               acc += coef * (RMH_W(eb)[oNb + f * D2 + i1 + D * i2] - ui);
+            }
+         }
+         RMH_W(eb)[C::oDuf + i] = acc;
+      }
+   }
    RMH_STAMP(2);
    // ---- phase C: column threads: geometry, grad u, z-leg of the test contractions -------------------
    const bool col = tid < NB * Q2;
@@ -591,7 +702,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
          {
-            r0[iz] += gt[oBg + qz * D + iz] * g;
+            r0[iz] += gt[(LO4 ? oB : oBg) + qz * D + iz] * g;
             r1[iz] += gt[oB + qz * D + iz] * wdq;
             r2[iz] += gt[oBg2 + qz * D + iz] * wdq;
          }
@@ -632,7 +743,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
             {
-               const double w = (r == 0) ? gt[oBg + jy * D + iy] : (r == 1 ? gt[oB + jy * D + iy] : gt[oBg2 + jy * D + iy]);
+               const double w = (r == 0) ? gt[(LO4 ? oB : oBg) + jy * D + iy] : (r == 1 ? gt[oB + jy * D + iy] : gt[oBg2 + jy * D + iy]);
                acc += w * in[jy];
             }
             dst[iy] = acc;
@@ -662,14 +773,14 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #pragma unroll
          for (int jx = 0; jx < Q; jx++)
          {
-            cBg[r][jx] = stab[oBg + jx * D + ix];
+            cBg[r][jx] = stab[(LO4 ? oB : oBg) + jx * D + ix];
             a0 += cBg[r][jx] * R2[(0 * Q + jx) * D2 + i2];
             a1 += stab[oB + jx * D + ix] * R2[(1 * Q + jx) * D2 + i2];
             a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * D2 + i2];
          }
          // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
 #pragma unroll
-         for (int c = 0; c < 3; c++)
+         for (int c = 0; c < (LO4 ? 0 : 3); c++)
          {
             const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
             const int kc = idx[c], k1 = idx[c1], k2 = idx[c2];
@@ -687,6 +798,142 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
       }
    }
 
+   if (LO4)
+   {
+      // ---- residual distribution per element (remhos_lo.cpp:1702-1800); rg = z = K_vol u, mm = lumped mass
+      constexpr int NS = C::NS;
+      const double eps = 1.E-15, gamma = 1.0;
+      double uu4[DR], t0[DR], t1[DR], t2[DR], xSum[DR], rhoP[DR], rhoN[DR];
+      int ring4 = 0;
+      __syncthreads(); // R2 has been consumed: the front of W is free
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         uu4[r] = 0.0;
+         if (t < NB * D3)
+         {
+            uu4[r] = a.u[(size_t)min(e0 + t / D3, a.ne_owned - 1) * D3 + t % D3];
+            RMH_W(t / D3)[oSA + t % D3] = uu4[r];
+         }
+         t0[r] = uu4[r];
+         t1[r] = fmax(0., rg[r]);
+         t2[r] = fmin(0., rg[r]);
+      }
+      batch_dot<C>(t0, xSum, lds, s_acc, ring4);
+      batch_dot<C>(t1, rhoP, lds, s_acc, ring4);
+      batch_dot<C>(t2, rhoN, lds, s_acc, ring4);
+      // element extrema (el[0..1]) and the sums of the subcell fluctuations (8 partial sums each, el[2..17])
+      if (C::WAVE_ALIGNED)
+      {
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            const double lo = wave_minmax<true>(t < NB * D3 ? uu4[r] : INFINITY);
+            const double hi = wave_minmax<false>(t < NB * D3 ? uu4[r] : -INFINITY);
+            if ((tid & 63) == 63 && t < NB * D3)
+            {
+               double *el = RMH_W(t / D3) + oM1;
+               el[0] = lo; el[1] = hi;
+               if (e0 + t / D3 < a.ne_owned)
+               {
+                  a.xe_min[e0 + t / D3] = lo;
+                  a.xe_max[e0 + t / D3] = hi;
+               }
+            }
+         }
+      }
+      else if (tid < NB)
+      {
+         const double *uu = RMH_W(tid) + oSA;
+         double lo = INFINITY, hi = -INFINITY;
+         for (int i = 0; i < D3; i++)
+         {
+            lo = fmin(lo, uu[i]);
+            hi = fmax(hi, uu[i]);
+         }
+         double *el = RMH_W(tid) + oM1;
+         el[0] = lo; el[1] = hi;
+         if (e0 + tid < a.ne_owned)
+         {
+            a.xe_min[e0 + tid] = lo;
+            a.xe_max[e0 + tid] = hi;
+         }
+      }
+      {
+         constexpr int CH = 8, CL = (NS + CH - 1) / CH;
+         for (int k = tid; k < NB * CH; k += NT)
+         {
+            const double *fl = RMH_W(k / CH) + C::oSub;
+            const int m0 = (k % CH) * CL;
+            double sp = 0.0, sn = 0.0;
+            for (int m = m0; m < m0 + CL && m < NS; m++)
+            {
+               sp += fl[m];
+               sn += fl[NS + m];
+            }
+            double *el = RMH_W(k / CH) + oM1;
+            el[2 + k % CH] = sp;
+            el[10 + k % CH] = sn;
+         }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         if (t < NB * D3)
+         {
+            const int eb = t / D3, i = t % D3;
+            const int ix = i % D, iy = (i / D) % D, iz = i / D2;
+            const double *el = RMH_W(eb) + oM1, *fl = RMH_W(eb) + C::oSub;
+            const double xe_min = el[0], xe_max = el[1];
+            double sumFluctP = 0.0, sumFluctN = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+            {
+               sumFluctP += el[2 + c];
+               sumFluctN += el[10 + c];
+            }
+            const double ui = uu4[r];
+            double nwP = 0.0, nwN = 0.0;
+            for (int dz = 1; dz >= 0; dz--)
+            {
+               for (int dy = 1; dy >= 0; dy--)
+               {
+                  for (int dx = 1; dx >= 0; dx--)
+                  {
+                     const int mx = ix - dx, my = iy - dy, mz = iz - dz;
+                     if (mx >= 0 && mx < P && my >= 0 && my < P && mz >= 0 && mz < P)
+                     {
+                        const int m = mx + P * (my + P * mz);
+                        nwP += fl[4 * NS + m] * (fl[2 * NS + m] - ui); // eq. (58)
+                        nwN += fl[5 * NS + m] * (fl[3 * NS + m] - ui); // eq. (59)
+                     }
+                  }
+               }
+            }
+            const double sumWeightsP = D3 * xe_max - xSum[r] + eps;
+            const double sumWeightsN = D3 * xe_min - xSum[r] - eps;
+            double weightP = (xe_max - ui) / sumWeightsP;
+            double weightN = (xe_min - ui) / sumWeightsN;
+            double aux = gamma / (rhoP[r] + eps);
+            weightP *= 1. - fmin(aux * sumFluctP, 1.);
+            weightP += fmin(aux, 1. / (sumFluctP + eps)) * nwP;
+            aux = gamma / (rhoN[r] - eps);
+            weightN *= 1. - fmin(aux * sumFluctN, 1.);
+            weightN += fmax(aux, 1. / (sumFluctN - eps)) * nwN;
+            const double duf = RMH_W(eb)[C::oDuf + i];
+            if (e0 + eb < a.ne_owned)
+            {
+               a.du[(size_t)e0 * D3 + t] = (duf + weightP * rhoP[r] + weightN * rhoN[r]) / mm[r];
+               a.m[(size_t)e0 * D3 + t] = mm[r];
+            }
+         }
+      }
+      return;
+   }
    RMH_STAMP(5);
    // ---- phase I: element-local PCG in the GL nodal basis (DGMassInverse) ----------------------------------
    // fused stage: the global reads of the limiter part are issued here so that they are in flight during
@@ -736,7 +983,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
    }
-   batch_dot<P>(tmp, nom, lds, s_acc, ring);
+   batch_dot<C>(tmp, nom, lds, s_acc, ring);
    bool act[DR];
    {
       bool any = false;
@@ -858,7 +1105,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #ifdef RMH_ABL_NODOT
       for (int r = 0; r < DR; r++) { red[r] = nom[r]; }
 #else
-      batch_dot<P>(tmp, red, lds, s_acc, ring); // den = d.Ad
+      batch_dot<C>(tmp, red, lds, s_acc, ring); // den = d.Ad
 #endif
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -874,7 +1121,7 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
 #ifdef RMH_ABL_NODOT
       for (int r = 0; r < DR; r++) { red[r] = 0.0; }
 #else
-      batch_dot<P>(tmp, red, lds, s_acc, ring); // betanom = r.z
+      batch_dot<C>(tmp, red, lds, s_acc, ring); // betanom = r.z
 #endif
       RMH_STAMP(15);
       bool any = false;
@@ -966,8 +1213,8 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
       double mass[DR], vol[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + a.dt * xg[r]); }
-      batch_dot<P>(tmp, mass, lds, s_acc, ring);
-      batch_dot<P>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
+      batch_dot<C>(tmp, mass, lds, s_acc, ring);
+      batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
       double fcl[DR], dlo[DR], pos[DR], neg[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -992,8 +1239,8 @@ __global__ void __launch_bounds__(256, K2Cfg<P>::WG_PER_CU) ho_kernel2(HoArgs a)
          }
       }
       double sumPos[DR], sumNeg[DR];
-      batch_dot<P>(pos, sumPos, lds, s_acc, ring);
-      batch_dot<P>(neg, sumNeg, lds, s_acc, ring);
+      batch_dot<C>(pos, sumPos, lds, s_acc, ring);
+      batch_dot<C>(neg, sumNeg, lds, s_acc, ring);
       double ynew[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)

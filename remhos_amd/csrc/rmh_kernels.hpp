@@ -45,6 +45,8 @@ struct HoArgs
    const int *face_nbr;    // [ne][6]
    const double *tab;      // TabLayout<P>
    const double *subvel;   // [ne][3][D3] sub-mesh node velocity (lo 4) or null
+   const double *subx0;    // [ne][3][D3] sub-mesh start positions (set up once by subcell_setup_kernel)
+   const double *subvmid;  // [ne][3][P^3] subcell midpoint velocity = mean of the 8 corner values
    double *du;             // [ne][D3]
    double *m;              // [ne][D3] lumped mass
    double *xe_min, *xe_max; // [ne]
@@ -905,6 +907,46 @@ __global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(const int *stencil2
    }
 }
 
+// lo 4 set-up (once per context): sub-mesh start positions = Q2 map of the start mesh at the closed-uniform
+// points i/p (ParMesh::MakeRefined(pmesh, order, ClosedUniform), remhos.cpp:796-826) and the subcell midpoint
+// velocities (mean of the corner values of v_sub_gf; lom.subcellCoeff->Eval at the 1-point rule,
+// remhos_lo.cpp:1051-1082).
+template <int P>
+__global__ void __launch_bounds__(64) subcell_setup_kernel(const double *x0, const double *subvel, const double *tab,
+                                                           double *subx0, double *subvmid)
+{
+   constexpr int D = P + 1, D2 = D * D, D3 = D2 * D, NS = P * P * P;
+   using T = TabLayout<P>;
+   const int e = blockIdx.x;
+   for (int k = threadIdx.x; k < 3 * D3; k += 64)
+   {
+      const int comp = k / D3, i = k % D3;
+      const int ix = i % D, iy = (i / D) % D, iz = i / D2;
+      const double *xn = x0 + (size_t)e * 81 + comp * 27;
+      const double *Lx = tab + T::oLcu + ix * 3, *Ly = tab + T::oLcu + iy * 3, *Lz = tab + T::oLcu + iz * 3;
+      double acc = 0.0;
+      for (int az = 0; az < 3; az++)
+      {
+         for (int ay = 0; ay < 3; ay++)
+         {
+            for (int ax = 0; ax < 3; ax++) { acc += Lx[ax] * Ly[ay] * Lz[az] * xn[ax + 3 * (ay + 3 * az)]; }
+         }
+      }
+      subx0[(size_t)e * 3 * D3 + k] = acc;
+   }
+   for (int k = threadIdx.x; k < 3 * NS; k += 64)
+   {
+      const int comp = k / NS, m = k % NS;
+      const int base = (m % P) + D * ((m / P) % P) + D2 * (m / (P * P));
+      double acc = 0.0;
+      for (int j = 0; j < 8; j++)
+      {
+         acc += 0.125 * subvel[((size_t)e * 3 + comp) * D3 + base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2)];
+      }
+      subvmid[(size_t)e * 3 * NS + k] = acc;
+   }
+}
+
 // Halo pack: for every element a neighbour rank needs (send_elems, all peers concatenated) copy its
 // ndof values of u and its min / max into contiguous send buffers -- the payload of
 // ParGridFunction::ExchangeFaceNbrData (remhos_ho.cpp:122) and of the GroupCommunicator min/max
@@ -1023,6 +1065,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) fct_clipscale_kernel(const double
 struct LimitArgs
 {
    const double *u, *du_ho, *m;
+   const double *du_lo; // null: mass-based average computed here (lo 5); else the LO rate of another solver (lo 4)
    const int *stencil27;
    const double *xe_min, *xe_max, *gh_min, *gh_max;
    int ne_owned;
@@ -1074,7 +1117,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
       {
          double lo, hi;
          dof_bounds<P>(i, smin, smax, lo, hi);
-         dl[k] = (ubar - uu[k]) / a.dt;
+         dl[k] = a.du_lo ? a.du_lo[(size_t)e * C::D3 + i] : (ubar - uu[k]) / a.dt;
          const double u_new_lo = uu[k] + a.dt * dl[k];
          const double f_clip_min = mm[k] / a.dt * (lo - u_new_lo);
          const double f_clip_max = mm[k] / a.dt * (hi - u_new_lo);

@@ -20,6 +20,7 @@ class Stepper:
         self.dev = torch.device(device)
         self.dist = dist if (dist is not None and case.peers) else None
         self.lo = int(case.cfg.lo_type)
+        self.fused_lo4 = fused and self.lo == 4  # lo 4: HO kernel + RD kernel + fused limiter/RK kernel
         self.fused = fused and self.lo == 5
         fused = self.fused
         self.one_kernel = one_kernel and self.fused  # whole stage in one kernel (rmh_stage_fused)
@@ -35,7 +36,9 @@ class Stepper:
         self.y = torch.empty_like(self.x)
         self.k = torch.empty_like(self.x)
         self.y2 = torch.empty_like(self.x) if self.one_kernel else None
-        if not fused:
+        if self.fused_lo4:
+            self.du_lo = torch.empty_like(self.x)
+        elif not fused:
             self.du_lo = torch.empty_like(self.x)
             self.umin = torch.empty_like(self.x)
             self.umax = torch.empty_like(self.x)
@@ -96,11 +99,15 @@ class Stepper:
             c.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt)
             return
         c.ho_apply(u, self.k)
+        if self.fused_lo4:
+            c.lo_rdsubcell(u, self.du_lo)
+            c.limit_fused_lo(u, self.k, self.du_lo, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
+            return
         if self.fused:
             c.limit_fused(u, self.k, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
             return
         # the reference's call sequence (remhos.cpp:1815-1831)
-        c.compute_lumped_mass(t, self.m)
+        m = c.lumped_mass_ptr()  # refreshed by rmh_ho_apply at this stage's mesh position (remhos.cpp:1632)
         if self.lo == 4:
             c.lo_rdsubcell(u, self.du_lo)
         else:
@@ -108,7 +115,7 @@ class Stepper:
         c.elem_minmax(u, self.xe_min, self.xe_max)
         c.bounds(self.xe_min, self.xe_max, self.umin, self.umax)
         du = torch.empty_like(u)
-        c.fct_clipscale(u, self.m, self.k, self.du_lo, self.umin, self.umax, dt, du)
+        c.fct_clipscale(u, m, self.k, self.du_lo, self.umin, self.umax, dt, du)
         y = u + dt * du
         if x_base is None:
             out.copy_(b * y)

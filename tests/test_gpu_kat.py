@@ -99,3 +99,23 @@ def test_autotest_baseline_lo4(lib, name, kw, mass, umax, steps):
     assert res.steps == steps
     assert float(f"{res.final_mass:.10g}") == mass
     assert float(f"{res.max_value:.10g}") == umax
+
+
+def test_autotest_lo4_through_stepper(lib):
+    """The same reference values through the Python stepper (batched HO kernel + batched RD kernel + fused
+    limiter/RK kernel): cube01_hex remap, autotest/out_baseline.dat:46-49."""
+    import torch
+
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    cfg = make_config("cube01_hex", 1, 2, 10, 0.02, 0.7, lo_type=4)
+    st = Stepper(lib, Case(lib, cfg), device="cuda:0")
+    assert st.fused_lo4
+    n = st.run()
+    torch.cuda.synchronize()
+    mass, umax = st.local_mass_and_max()
+    assert n == 50
+    assert float(f"{mass:.10g}") == 0.1197299801
+    assert float(f"{umax:.10g}") == 0.9997499683
+    st.close()
