@@ -1,0 +1,117 @@
+"""Size-independent properties of the stage at BASELINE.json's full single-GPU size (configs[1]:
+periodic-cube remap, p = 3, -rs 4: 110 592 hex, 7.08 M dofs) and degenerate inputs.
+
+The oracle cannot run this size in seconds, so the checks are the invariants the scheme guarantees
+(remhos_fct.hpp:69-72): bounds preservation  u_min_i <= u_i + dt du_i <= u_max_i  and conservation
+sum_i m_i du_i = sum_i m_i du_HO,i  per element, plus run-to-run bitwise determinism and agreement of the
+one-kernel stage with the multi-kernel path.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    assert torch.cuda.is_available()
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+
+    return torch, bind_driver(load_library())
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob", [("periodic-cube", 4, 3, 10), ("cube01_hex", 4, 2, 10), ("periodic-cube", 3, 3, 0)])
+def test_full_size_invariants(env, mesh, rs, p, prob):
+    torch, lib = env
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(lib, make_config(mesh, rs, p, prob, -1.0 if prob >= 10 else 0.002, 0.5))
+    st = Stepper(lib, case, device="cuda:0")
+    st.step(st.dt)  # a generic state (not the initial bump)
+    c, u, dt = st.ctx, st.x, st.dt
+    t = st.t
+    nd = case.ndof
+    new = lambda: torch.empty_like(u)
+    du_ho, du2, du1, y, umin, umax = (new() for _ in range(6))
+    xmn = torch.empty(case.ne_owned, dtype=torch.float64, device=u.device)
+    xmx = torch.empty_like(xmn)
+    c.setup(t)
+    c.ho_apply(u, du_ho)
+    m = torch.empty_like(u)
+    c.compute_lumped_mass(t, m)
+    c.limit_fused(u, du_ho, dt, du=du2)
+    c.elem_minmax(u, xmn, xmx)
+    c.bounds(xmn, xmx, umin, umax)
+    c.stage_fused(u, dt, y, du=du1)
+    torch.cuda.synchronize()
+    # (c) one-kernel stage == HO kernel + fused limiter kernel (different reduction trees: round-off)
+    # du_LO = (ubar - u)/dt amplifies the round-off of the element average by 1/dt: scale accordingly
+    scale = float(u.abs().max()) / dt
+    assert float((du1 - du2).abs().max()) <= 1e-13 * scale
+    assert float((y - (u + 0.0 * du1)).abs().max()) == 0.0  # a = 0, b = 1, dt_rk = 0: y_out = u exactly
+    for du in (du1, du2):
+        # (a) conservation per element (remhos_fct.hpp:71)
+        lhs = (m * du).view(-1, nd).sum(1)
+        rhs = (m * du_ho).view(-1, nd).sum(1)
+        # round-off floor: the limiter moves fluxes of size m |du_LO| ~ m |u - ubar| / dt and rescales them
+        ref = m.view(-1, nd).sum(1).max() * u.abs().max() / dt
+        assert float((lhs - rhs).abs().max()) <= 1e-12 * float(ref)
+        # (b) bounds preservation (remhos_fct.hpp:70); tolerance as in the reference's check_violation (1e-12)
+        un = u + dt * du
+        assert float((umin - un).max()) <= 1e-12
+        assert float((un - umax).max()) <= 1e-12
+    # (d) bitwise determinism of repeated launches
+    du3, y3 = new(), new()
+    c.stage_fused(u, dt, y3, du=du3)
+    torch.cuda.synchronize()
+    assert torch.equal(du3, du1)
+    # transport (static mesh): the global mass after a full RK3 step equals the mass before to round-off;
+    # remap conserves only up to the time discretisation of the moving mass matrix (the reference prints
+    # "Mass loss u" for it, remhos.cpp:1427), so it is checked to that level only
+    mass0, _ = st.local_mass_and_max()
+    st.step(st.dt)
+    mass1, _ = st.local_mass_and_max()
+    assert abs(mass1 - mass0) <= (1e-12 if case.exec_mode == 0 else 1e-6) * abs(mass0)
+    st.close()
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_constant_field_is_a_fixed_point(env, p):
+    """u = const: K u = 0 exactly up to round-off, the PCG takes no iteration (zero right-hand side),
+    the limiter sees zero fluxes (no 0/0): du = 0 to round-off, no NaN."""
+    torch, lib = env
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(lib, make_config("periodic-cube", 1, p, 10, -1.0, 0.5))
+    st = Stepper(lib, case, device="cuda:0")
+    st.x.fill_(0.75)
+    y, du = torch.empty_like(st.x), torch.empty_like(st.x)
+    st.ctx.setup(0.4)
+    st.ctx.stage_fused(st.x, st.dt, y, du=du)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(du).any())
+    assert float(du.abs().max()) < 1e-12
+    assert float((y - 0.75).abs().max()) < 1e-13
+    st.close()
+
+
+def test_single_workgroup_and_ragged_tail(env):
+    """element counts that are not a multiple of the batch size (7 at p = 3) incl. fewer elements than one batch"""
+    torch, lib = env
+    from oracle.remhos_oracle import Config, Remhos
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    for mesh, rs in (("cube01_hex", 0), ("periodic-cube", 0), ("cube01_hex", 1)):  # 8, 27, 64 elements
+        r = Remhos(Config(mesh=mesh, rs=rs, order=3, problem=10, dt=-1.0, t_final=0.5, lo=5, max_steps=2))
+        out = r.run()
+        st = Stepper(lib, Case(lib, make_config(mesh, rs, 3, 10, -1.0, 0.5)), device="cuda:0")
+        st.run(max_steps=2)
+        torch.cuda.synchronize()
+        assert np.abs(st.x.cpu().numpy() - r.u).max() < 1e-10
+        st.close()
