@@ -979,7 +979,8 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
    for (int r = 0; r < DR; r++)
    {
       xg[r] = 0.0;
-      dd[r] = rg[r] / dg[r];
+      dg[r] = 1.0 / dg[r]; // from here on dg holds the inverse diagonal (one division per dof instead of two per iteration)
+      dd[r] = rg[r] * dg[r];
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
    }
@@ -1111,11 +1112,11 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
       for (int r = 0; r < DR; r++)
       {
          const bool ok = act[r] && red[r] > 0.0;
-         const double al = ok ? ((RMH_ABL_MASK & 32) ? nom[r] : nom[r] / red[r]) : 0.0;
+         const double al = ok ? nom[r] / red[r] : 0.0;
          if (act[r] && !ok) { tol[r] = INFINITY; } // breakdown: freeze this element
          xg[r] += al * dd[r];
          rg[r] -= al * Ad[r];
-         tmp[r] = (RMH_ABL_MASK & 32) ? rg[r] * rg[r] : rg[r] * (rg[r] / dg[r]);
+         tmp[r] = rg[r] * (rg[r] * dg[r]);
       }
       RMH_STAMP(14);
 #ifdef RMH_ABL_NODOT
@@ -1128,10 +1129,10 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
-         const double z = (RMH_ABL_MASK & 32) ? rg[r] : rg[r] / dg[r];
+         const double z = rg[r] * dg[r];
          if (act[r])
          {
-            dd[r] = z + ((RMH_ABL_MASK & 32) ? red[r] : (red[r] / nom[r])) * dd[r];
+            dd[r] = z + (red[r] / nom[r]) * dd[r];
             nom[r] = red[r];
             its[r]++;
          }
