@@ -37,7 +37,18 @@ struct K2Cfg : TabLayout<P>
    static constexpr int D = T::D, Q = T::Q;
    static constexpr int D2 = D * D, D3 = D * D * D, Q2 = Q * Q;
    static constexpr int NT = 256;
-   static constexpr int NB = NT / Q2;                 // elements per workgroup
+#ifndef RMH_NB6
+#define RMH_NB6 2
+#endif
+#ifndef RMH_NB5
+#define RMH_NB5 4
+#endif
+#ifndef RMH_NB4
+#define RMH_NB4 4
+#endif
+   // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
+   // footprint would otherwise limit the CU to one workgroup (measured per order)
+   static constexpr int NB = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : NT / Q2));
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
