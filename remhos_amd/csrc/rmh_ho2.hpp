@@ -947,6 +947,9 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
    }
    RMH_STAMP(5);
    // ---- phase I: element-local PCG in the GL nodal basis (DGMassInverse) ----------------------------------
+   // generic orders: the deterministic reductions stage their operands in the sB slot of W, which may
+   // overlap the tail of R2 that slower threads are still reading in phase G
+   if (!C::WAVE_ALIGNED) { __syncthreads(); }
    // fused stage: the global reads of the limiter part are issued here so that they are in flight during
    // the PCG iterations (u is an L2 hit: this workgroup read it in phase A)
    constexpr int NLS = (NB * 27 + NT - 1) / NT;
