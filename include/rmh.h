@@ -146,7 +146,7 @@ int rmh_limit_fused(rmh_ctx *ctx, const double *u, const double *du_ho, double d
 int rmh_limit_fused_lo(rmh_ctx *ctx, const double *u, const double *du_ho, const double *du_lo, double dt,
                        double *du, const double *x_base, double a, double b, double dt_rk, double *y_out);
 
-/* The whole RK stage in ONE kernel for -ho 3 -lo 5 -fct 2: AdvectionOperator::Mult = MultUnlimited +
+/* The whole RK stage in ONE kernel for -ho 3 -lo 5|4 -fct 2 (LO solver: rmh_set_lo_type): AdvectionOperator::Mult = MultUnlimited +
  * LimitMult (remhos_solvers.hpp:46-50, remhos.cpp:1596-1916) and the RK vector update
  *   y_out = a * x_base + b * (u + dt_rk * du)          (x_base may be NULL: a is ignored)
  * du_HO, du_LO, the lumped mass and the per-dof bounds never leave the compute unit; the element extrema
@@ -155,6 +155,10 @@ int rmh_limit_fused_lo(rmh_ctx *ctx, const double *u, const double *du_ho, const
  * Ghost values of u and ghost extrema must be set for multi-rank runs. */
 int rmh_stage_fused(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
                     double dt_rk, double *y_out, double *du);
+
+/* Which LOSolver rmh_stage_fused runs inside the stage kernel: 5 = MassBasedAvg (default), 4 =
+ * PAResidualDistributionSubcell (-lo, remhos.cpp:268-276); lo 4 needs rmh_layout.subcell_vel. */
+int rmh_set_lo_type(rmh_ctx *ctx, int lo_type);
 
 /* Stopwatch buckets of TimingData (remhos_tools.hpp:52-64; printed by
  * AdvectionOperator::PrintTimingData, remhos.cpp:1918-1966): seconds in

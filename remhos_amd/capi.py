@@ -17,7 +17,7 @@ SYMBOLS = [
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
-    "rmh_last_cg_iters", "rmh_set_mass_tol",
+    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_set_lo_type",
 ]
 
 
@@ -78,6 +78,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_enable_timers.argtypes = [p, i]
     lib.rmh_last_cg_iters.argtypes = [p, C.POINTER(i)]
     lib.rmh_set_mass_tol.argtypes = [p, d, d, i]
+    lib.rmh_set_lo_type.argtypes = [p, i]
     return lib
 
 
@@ -212,6 +213,9 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.rmh_last_cg_iters(self.h, C.byref(n)))
         return n.value
+
+    def set_lo_type(self, lo_type):
+        self._check(self.lib.rmh_set_lo_type(self.h, int(lo_type)))
 
     def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
         self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))

@@ -54,6 +54,7 @@ struct rmh_ctx
    double rel_tol = 1e-14, abs_tol = 0.0;
    int max_iter = 100;
    bool ho_done = false;
+   int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
    int ho_variant = 2; // 2: batched kernel (rmh_ho2.hpp), 1: one element per workgroup (rmh_kernels.hpp)
    // stopwatches (TimingData, remhos_tools.hpp:52-64)
    bool timers_on = false;
@@ -222,8 +223,17 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.y_out = y_out;
    a.xe_min_out = c->d_xe_min2;
    a.xe_max_out = c->d_xe_max2;
-   constexpr int NB = K2Cfg<P>::NB;
-   hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+   if (c->lo_type == 4)
+   {
+      constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
+      constexpr int NB = K2Cfg<P4, true, true>::NB;
+      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3((c->ne + NB - 1) / NB), dim3(256), 0, c->stream, a);
+   }
+   else
+   {
+      constexpr int NB = K2Cfg<P>::NB;
+      hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+   }
    RMH_HIP(hipGetLastError());
    return 0;
 }
@@ -497,6 +507,10 @@ int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base
    if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    if (y_out == u || du == u) { return fail(RMH_ERR_INVALID, "rmh_stage_fused: the output must not alias u"); }
+   if (c->lo_type == 4 && (c->p < 2 || !c->d_subvel))
+   {
+      return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 4 needs order >= 2 and rmh_layout.subcell_vel");
+   }
    if (c->ng > 0 && (!c->u_ghost || !c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost data not set"); }
    int rc = 0;
    if (c->xe_of != u)
@@ -559,6 +573,14 @@ int rmh_last_cg_iters(rmh_ctx *c, int *max_iters)
    RMH_HIP(hipStreamSynchronize(c->stream));
    RMH_HIP(hipMemcpy(max_iters, c->d_cg, sizeof(int), hipMemcpyDeviceToHost));
    RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
+   return RMH_OK;
+}
+
+int rmh_set_lo_type(rmh_ctx *c, int lo_type)
+{
+   if (!c || (lo_type != 4 && lo_type != 5)) { return fail(RMH_ERR_INVALID, "lo_type must be 4 or 5"); }
+   if (lo_type == 4 && (c->p < 2 || !c->d_subvel)) { return fail(RMH_ERR_STATE, "lo 4 needs order >= 2 and rmh_layout.subcell_vel"); }
+   c->lo_type = lo_type;
    return RMH_OK;
 }
 

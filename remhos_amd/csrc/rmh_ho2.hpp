@@ -30,7 +30,7 @@ namespace rmh
 #define RMH_ABL_MASK 0 // diagnostic builds only: bit k skips a piece of the PCG iteration
 #endif
 
-template <int P, bool LO4 = false>
+template <int P, bool LO4 = false, bool BOTH = false>
 struct K2Cfg : TabLayout<P>
 {
    using T = TabLayout<P>;
@@ -48,7 +48,9 @@ struct K2Cfg : TabLayout<P>
 #endif
    // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
    // footprint would otherwise limit the CU to one workgroup (measured per order)
-   static constexpr int NB = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : NT / Q2));
+   static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : NT / Q2));
+   // HO + RD in one kernel carries more LDS per element: one element less keeps two workgroups per CU
+   static constexpr int NB = (BOTH && NB0 > 2) ? NB0 - 1 : NB0;
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
@@ -58,7 +60,10 @@ struct K2Cfg : TabLayout<P>
    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
    static constexpr int S2 = D2 + 1; // padded row stride of U1 / M1 (bank conflicts)
    static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
-   static constexpr int oR3 = 0, oR2 = 3 * Q2 * D, PF = oR2 + 3 * Q * D2;
+   // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal,
+   // 3 z = K_vol u in the Bernstein basis (only when HO and RD run in the same kernel)
+   static constexpr int NR = BOTH ? 4 : 3;
+   static constexpr int oR3 = 0, oR2 = NR * Q2 * D, PF = oR2 + NR * Q * D2;
    static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
    // lo 4 (subcell residual distribution) extras: sub-mesh node positions behind the phase A-C data,
    // subcell data [6][NS] and the lumped face flux per dof behind the face buffer
@@ -66,11 +71,12 @@ struct K2Cfg : TabLayout<P>
    static constexpr int oXs = PA;
    static constexpr int W = cmax(PA + (LO4 ? 3 * D3 : 0), cmax(PF, PCG));
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
-   static constexpr int oF = W;
-   static constexpr int oSub = oF + RF, oDuf = oSub + 6 * NS;
+   static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
+   static constexpr int oF2 = BOTH ? oF + RF : oF;    // s rows (Bernstein basis) of the RD solver
+   static constexpr int oSub = oF2 + RF, oDuf = oSub + 6 * NS;
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
-   static constexpr int EL0 = W + RF + (LO4 ? 6 * NS + D3 : 0);
+   static constexpr int EL0 = W + RF + (BOTH ? RF : 0) + (LO4 ? 6 * NS + D3 : 0);
    static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
    static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + 8 * NB;
    static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
@@ -219,14 +225,18 @@ __device__ unsigned long long g_stamps[32];
 //                 weights, du_LO; also writes the lumped mass and the element extrema (like the reference's
 //                 RD solver does, remhos_lo.cpp:1702-1716).  No mass solve.
 template <int P, int MODE>
-__global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_kernel2(HoArgs a)
+// MODE 3        : the whole RK stage for -ho 3 -lo 4 -fct 2: MODE 0 + MODE 2 + overlap bounds + ClipScale + RK
+//                 update in one kernel (geometry, face data and u-contractions shared by HO and RD).
+__global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_PER_CU)) ho_kernel2(HoArgs a)
 {
-   constexpr bool FUSED = MODE == 1;
-   constexpr bool LO4 = MODE == 2;
+   constexpr bool FUSED = MODE == 1 || MODE == 3; // limiter + RK update at the end
+   constexpr bool LO4 = MODE >= 2;                // subcell residual distribution pieces
+   constexpr bool BOTH = MODE == 3;               // HO and RD in the same kernel
+   constexpr bool HAS_HO = MODE != 2;
 #ifdef RMH_STAMPS
    unsigned long long stamp_prev_ = clock64();
 #endif
-   using C = K2Cfg<P, MODE == 2>;
+   using C = K2Cfg<P, (MODE >= 2), (MODE == 3)>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NB = C::NB, DR = C::DR;
    constexpr int S2 = C::S2;
    constexpr int oXV = C::oXV, oU = C::oU, oNb = C::oNb, oU1 = C::oU1, oR3 = C::oR3, oR2 = C::oR2, oSA = C::oSA,
@@ -451,9 +461,9 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
          jr[i2] = acc;
       }
       const double w1 = stab[oW + q1];
-      double tq[D];
+      double tq[D], tq2[D];
 #pragma unroll
-      for (int k2 = 0; k2 < D; k2++) { tq[k2] = 0.0; }
+      for (int k2 = 0; k2 < D; k2++) { tq[k2] = 0.0; tq2[k2] = 0.0; }
 #pragma unroll
       for (int q2 = 0; q2 < Q; q2++)
       {
@@ -481,12 +491,28 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
 #pragma unroll
          for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
          const double sq = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2];
-         const double val = LO4 ? sq : sq * jump;
+         if (HAS_HO)
+         {
+            const double val = sq * jump;
 #pragma unroll
-         for (int k2 = 0; k2 < D; k2++) { tq[k2] += gt[(LO4 ? oB : oBg) + q2 * D + k2] * val; }
+            for (int k2 = 0; k2 < D; k2++) { tq[k2] += gt[oBg + q2 * D + k2] * val; }
+         }
+         if (LO4)
+         {
+#pragma unroll
+            for (int k2 = 0; k2 < D; k2++) { tq2[k2] += gt[oB + q2 * D + k2] * sq; }
+         }
       }
+      if (HAS_HO)
+      {
 #pragma unroll
-      for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[oF + (f * Q + q1) * D + k2] = tq[k2]; }
+         for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[oF + (f * Q + q1) * D + k2] = tq[k2]; }
+      }
+      if (LO4)
+      {
+#pragma unroll
+         for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[C::oF2 + (f * Q + q1) * D + k2] = tq2[k2]; }
+      }
    }
    __syncthreads();
 
@@ -570,7 +596,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
                const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
                const int i1 = idx[c1], i2 = idx[c2];
                const int f = 2 * c + (ic == P ? 1 : 0);
-               const double *F = RMH_W(eb) + oF + f * Q * D + i2;
+               const double *F = RMH_W(eb) + C::oF2 + f * Q * D + i2;
                double coef = 0.0;
 #pragma unroll
                for (int q1 = 0; q1 < Q; q1++) { coef += stab[oB + q1 * D + i1] * F[q1 * D]; }
@@ -587,9 +613,9 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
    const int qx = cc % Q, qy = cc / Q;
    double wd[Q];
    double Bgy[D]; // GL basis row of this thread's qy (mass apply)
-   double r0[D], r1[D], r2[D];
+   double r0[D], r1[D], r2[D], r3[D];
 #pragma unroll
-   for (int iz = 0; iz < D; iz++) { r0[iz] = 0; r1[iz] = 0; r2[iz] = 0; Bgy[iz] = 0; }
+   for (int iz = 0; iz < D; iz++) { r0[iz] = 0; r1[iz] = 0; r2[iz] = 0; r3[iz] = 0; Bgy[iz] = 0; }
 #pragma unroll
    for (int qz = 0; qz < Q; qz++) { wd[qz] = 0; }
    if (col)
@@ -713,9 +739,10 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
          {
-            r0[iz] += gt[(LO4 ? oB : oBg) + qz * D + iz] * g;
+            r0[iz] += gt[(HAS_HO ? oBg : oB) + qz * D + iz] * g;
             r1[iz] += gt[oB + qz * D + iz] * wdq;
-            r2[iz] += gt[oBg2 + qz * D + iz] * wdq;
+            if (HAS_HO) { r2[iz] += gt[oBg2 + qz * D + iz] * wdq; }
+            if (BOTH) { r3[iz] += gt[oB + qz * D + iz] * g; }
          }
       }
    }
@@ -729,6 +756,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
          R3[(0 * Q2 + cc) * D + iz] = r0[iz];
          R3[(1 * Q2 + cc) * D + iz] = r1[iz];
          R3[(2 * Q2 + cc) * D + iz] = r2[iz];
+         if (BOTH) { R3[(3 * Q2 + cc) * D + iz] = r3[iz]; }
       }
    }
    __syncthreads();
@@ -740,7 +768,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
       const int eb = k / (Q * D), rem = k % (Q * D);
       const int q = rem / D, iz = rem % D;
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+      for (int r = 0; r < C::NR; r++)
       {
          const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
          double in[Q];
@@ -754,7 +782,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
             {
-               const double w = (r == 0) ? gt[(LO4 ? oB : oBg) + jy * D + iy] : (r == 1 ? gt[oB + jy * D + iy] : gt[oBg2 + jy * D + iy]);
+               const double w = (r == 0) ? gt[(HAS_HO ? oBg : oB) + jy * D + iy] : (r == 2 ? gt[oBg2 + jy * D + iy] : gt[oB + jy * D + iy]);
                acc += w * in[jy];
             }
             dst[iy] = acc;
@@ -765,13 +793,13 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
 
    RMH_STAMP(4);
    // ---- phase G: dof threads: x-leg, face contributions ------------------------------------------------
-   double rg[DR], mm[DR], dg[DR];
+   double rg[DR], mm[DR], dg[DR], zb[DR];
    double cBg[DR][Q]; // column ix of the GL basis table of each dof of this thread (x-legs)
 #pragma unroll
    for (int r = 0; r < DR; r++)
    {
       const int t = tid + r * NT;
-      rg[r] = 0.0; mm[r] = 1.0; dg[r] = 1.0;
+      rg[r] = 0.0; mm[r] = 1.0; dg[r] = 1.0; zb[r] = 0.0;
 #pragma unroll
       for (int jx = 0; jx < Q; jx++) { cBg[r][jx] = 0.0; }
       if (t < NB * D3)
@@ -780,18 +808,20 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
          const int ix = i % D, i2 = i / D;
          const int idx[3] = {ix, i2 % D, i2 / D};
          const double *R2 = RMH_W(eb) + oR2;
-         double a0 = 0, a1 = 0, a2 = 0;
+         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
          for (int jx = 0; jx < Q; jx++)
          {
-            cBg[r][jx] = stab[(LO4 ? oB : oBg) + jx * D + ix];
+            cBg[r][jx] = stab[(HAS_HO ? oBg : oB) + jx * D + ix];
+            const double bx = stab[oB + jx * D + ix];
             a0 += cBg[r][jx] * R2[(0 * Q + jx) * D2 + i2];
-            a1 += stab[oB + jx * D + ix] * R2[(1 * Q + jx) * D2 + i2];
-            a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * D2 + i2];
+            a1 += bx * R2[(1 * Q + jx) * D2 + i2];
+            if (HAS_HO) { a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * D2 + i2]; }
+            if (BOTH) { a3 += bx * R2[(3 * Q + jx) * D2 + i2]; }
          }
          // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
 #pragma unroll
-         for (int c = 0; c < (LO4 ? 0 : 3); c++)
+         for (int c = 0; c < (HAS_HO ? 3 : 0); c++)
          {
             const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
             const int kc = idx[c], k1 = idx[c1], k2 = idx[c2];
@@ -806,12 +836,16 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
             }
          }
          rg[r] = a0; mm[r] = a1; dg[r] = a2;
+         zb[r] = BOTH ? a3 : a0; // z = K_vol u in the Bernstein basis (RD)
       }
    }
 
+   double dlo[DR]; // du_LO of the RD solver (MODE 2 / 3)
+#pragma unroll
+   for (int r = 0; r < DR; r++) { dlo[r] = 0.0; }
    if (LO4)
    {
-      // ---- residual distribution per element (remhos_lo.cpp:1702-1800); rg = z = K_vol u, mm = lumped mass
+      // ---- residual distribution per element (remhos_lo.cpp:1702-1800); zb = z = K_vol u, mm = lumped mass
       constexpr int NS = C::NS;
       const double eps = 1.E-15, gamma = 1.0;
       double uu4[DR], t0[DR], t1[DR], t2[DR], xSum[DR], rhoP[DR], rhoN[DR];
@@ -828,8 +862,8 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
             RMH_W(t / D3)[oSA + t % D3] = uu4[r];
          }
          t0[r] = uu4[r];
-         t1[r] = fmax(0., rg[r]);
-         t2[r] = fmin(0., rg[r]);
+         t1[r] = fmax(0., zb[r]);
+         t2[r] = fmin(0., zb[r]);
       }
       batch_dot<C>(t0, xSum, lds, s_acc, ring4);
       batch_dot<C>(t1, rhoP, lds, s_acc, ring4);
@@ -847,7 +881,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
             {
                double *el = RMH_W(t / D3) + oM1;
                el[0] = lo; el[1] = hi;
-               if (e0 + t / D3 < a.ne_owned)
+               if (!BOTH && e0 + t / D3 < a.ne_owned)
                {
                   a.xe_min[e0 + t / D3] = lo;
                   a.xe_max[e0 + t / D3] = hi;
@@ -866,7 +900,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
          }
          double *el = RMH_W(tid) + oM1;
          el[0] = lo; el[1] = hi;
-         if (e0 + tid < a.ne_owned)
+         if (!BOTH && e0 + tid < a.ne_owned)
          {
             a.xe_min[e0 + tid] = lo;
             a.xe_max[e0 + tid] = hi;
@@ -936,14 +970,16 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
             weightN *= 1. - fmin(aux * sumFluctN, 1.);
             weightN += fmax(aux, 1. / (sumFluctN - eps)) * nwN;
             const double duf = RMH_W(eb)[C::oDuf + i];
-            if (e0 + eb < a.ne_owned)
+            dlo[r] = (duf + weightP * rhoP[r] + weightN * rhoN[r]) / mm[r];
+            if (!BOTH && e0 + eb < a.ne_owned)
             {
-               a.du[(size_t)e0 * D3 + t] = (duf + weightP * rhoP[r] + weightN * rhoN[r]) / mm[r];
+               a.du[(size_t)e0 * D3 + t] = dlo[r];
                a.m[(size_t)e0 * D3 + t] = mm[r];
             }
          }
       }
-      return;
+      if (!BOTH) { return; }
+      __syncthreads(); // the PCG reuses the front of W
    }
    RMH_STAMP(5);
    // ---- phase I: element-local PCG in the GL nodal basis (DGMassInverse) ----------------------------------
@@ -1230,19 +1266,19 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE == 2)>::WG_PER_CU)) ho_ke
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + a.dt * xg[r]); }
       batch_dot<C>(tmp, mass, lds, s_acc, ring);
       batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
-      double fcl[DR], dlo[DR], pos[DR], neg[DR];
+      double fcl[DR], pos[DR], neg[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
-         fcl[r] = 0.0; dlo[r] = 0.0; pos[r] = 0.0; neg[r] = 0.0;
+         fcl[r] = 0.0; pos[r] = 0.0; neg[r] = 0.0;
          if (t < NB * D3)
          {
             const int eb = t / D3, i = t % D3;
             double lo, hi;
             dof_bounds<P>(i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
             const double ubar = mass[r] / vol[r];
-            dlo[r] = (ubar - uu[r]) / a.dt;
+            if (!BOTH) { dlo[r] = (ubar - uu[r]) / a.dt; } // MassBasedAvg; with RD dlo is already there
             const double u_new_lo = uu[r] + a.dt * dlo[r];
             const double f_clip_min = mm[r] / a.dt * (lo - u_new_lo);
             const double f_clip_max = mm[r] / a.dt * (hi - u_new_lo);

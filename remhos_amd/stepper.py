@@ -23,13 +23,15 @@ class Stepper:
         self.fused_lo4 = fused and self.lo == 4  # lo 4: HO kernel + RD kernel + fused limiter/RK kernel
         self.fused = fused and self.lo == 5
         fused = self.fused
-        self.one_kernel = one_kernel and self.fused  # whole stage in one kernel (rmh_stage_fused)
+        self.one_kernel = one_kernel and (self.fused or self.fused_lo4)  # whole stage in one kernel (rmh_stage_fused)
         dev_index = self.dev.index or 0
         self.ctx = Context(lib, order=case.order, exec_mode=case.exec_mode, x0=case.x0, vel=case.vel,
                            face_nbr=case.face_nbr, stencil27=case.stencil27, ne_ghost=case.ne_ghost,
                            subcell_vel=case.subcell_vel, device=dev_index if self.dev.type == "cuda" else 0)
         if self.dev.type == "cuda":
             self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        if self.lo == 4:
+            self.ctx.set_lo_type(4)
         ne, nd, ng = case.ne_owned, case.ndof, case.ne_ghost
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.x = torch.from_numpy(case.u0).to(self.dev).contiguous()

@@ -211,3 +211,33 @@ def test_one_kernel_stage(gpu, mesh, rs, p, prob, t):
     with pytest.raises(RmhError, match="alias"):
         ctx.stage_fused(u, cfg.dt, u)
     ctx.close()
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,t", [("cube01_hex", 2, 3, 10, 0.5), ("periodic-cube", 1, 3, 0, 0.0),
+                                             ("cube01_hex", 1, 2, 10, 0.3), ("cube01_hex", 1, 4, 10, 0.3)])
+def test_one_kernel_stage_lo4(gpu, mesh, rs, p, prob, t):
+    """rmh_stage_fused with rmh_set_lo_type(4): HO + subcell RD + bounds + ClipScale + RK update in one kernel
+    (geometry and face data shared by the two solvers) against the oracle's lo 4 stage."""
+    torch, lib = gpu
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=4)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    sub = r.Vs if r.exec_mode == 1 else r.vel(r.Xs0)
+    ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st,
+                  subcell_vel=np.ascontiguousarray(sub.transpose(0, 2, 1)))
+    ctx.set_lo_type(4)
+    u_h = perturbed(r.u)
+    du_ref = r.stage(u_h, t, cfg.dt)
+    y_ref = (1.0 / 3.0) * r.u + (2.0 / 3.0) * (u_h + cfg.dt * du_ref)
+    u = torch.from_numpy(u_h).to("cuda:0")
+    xb = torch.from_numpy(r.u.copy()).to("cuda:0")
+    y, du = torch.empty_like(u), torch.empty_like(u)
+    ctx.setup(t)
+    ctx.stage_fused(u, cfg.dt, y, x_base=xb, a=1.0 / 3.0, b=2.0 / 3.0, dt_rk=cfg.dt, du=du)
+    torch.cuda.synchronize()
+    assert _relerr(du.cpu().numpy(), du_ref) < REL[p]
+    assert _relerr(y.cpu().numpy(), y_ref) < REL[p]
+    ctx.close()
