@@ -50,7 +50,10 @@ struct K2Cfg : TabLayout<P>
    // footprint would otherwise limit the CU to one workgroup (measured per order)
    static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : NT / Q2));
    // HO + RD in one kernel carries more LDS per element: one element less keeps two workgroups per CU
-   static constexpr int NB = (BOTH && NB0 > 2) ? NB0 - 1 : NB0;
+#ifndef RMH_BOTH_DROP
+#define RMH_BOTH_DROP 1
+#endif
+   static constexpr int NB = (BOTH && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0;
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
