@@ -156,6 +156,14 @@ int rmh_limit_fused_lo(rmh_ctx *ctx, const double *u, const double *du_ho, const
 int rmh_stage_fused(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
                     double dt_rk, double *y_out, double *du);
 
+/* The same stage for the owned elements [e_begin, e_end) only, so that a multi-rank caller can run
+ * the elements that touch no ghost while the halo exchange (ParGridFunction::ExchangeFaceNbrData,
+ * remhos_ho.cpp:122, and the min/max GroupCommunicator of remhos_tools.cpp:461-466) is in flight, and
+ * the halo-dependent ones after it.  All ranges of one stage take the same arguments; finish != 0 on
+ * the last one (the element extrema of y_out then become the next stage's input extrema). */
+int rmh_stage_fused_range(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
+                          double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish);
+
 /* Which LOSolver rmh_stage_fused runs inside the stage kernel: 5 = MassBasedAvg (default), 4 =
  * PAResidualDistributionSubcell (-lo, remhos.cpp:268-276); lo 4 needs rmh_layout.subcell_vel. */
 int rmh_set_lo_type(rmh_ctx *ctx, int lo_type);

@@ -32,6 +32,8 @@ typedef struct {
 
 typedef struct {
    int order, exec_mode, ndof, ne_owned, ne_ghost, n_peers;
+   int ne_halo;       /* owned elements [0, ne_halo) reach a ghost through their 27-stencil */
+   int pad_;
    long long ne_global;
    int n[3], lo[3], nl[3];
    double dt;

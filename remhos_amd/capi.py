@@ -16,7 +16,7 @@ SYMBOLS = [
     "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
-    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
+    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
     "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_set_lo_type",
 ]
 
@@ -73,6 +73,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_limit_fused.argtypes = [p, p, p, d, p, p, d, d, d, p]
     lib.rmh_limit_fused_lo.argtypes = [p, p, p, p, d, p, p, d, d, d, p]
     lib.rmh_stage_fused.argtypes = [p, p, d, p, d, d, d, p, p]
+    lib.rmh_stage_fused_range.argtypes = [p, p, d, p, d, d, d, p, p, C.c_int, C.c_int, C.c_int]
     lib.rmh_timers.argtypes = [p, C.POINTER(d * 4)]
     lib.rmh_reset_timers.argtypes = [p]
     lib.rmh_enable_timers.argtypes = [p, i]
@@ -197,6 +198,11 @@ class Context:
     def stage_fused(self, u, dt, y_out, x_base=None, a=0.0, b=1.0, dt_rk=0.0, du=None):
         self._check(self.lib.rmh_stage_fused(self.h, _ptr(u), float(dt), _ptr(x_base), float(a), float(b), float(dt_rk),
                                              _ptr(y_out), _ptr(du)))
+
+    def stage_fused_range(self, u, dt, y_out, e_begin, e_end, finish, x_base=None, a=0.0, b=1.0, dt_rk=0.0, du=None):
+        self._check(self.lib.rmh_stage_fused_range(self.h, _ptr(u), float(dt), _ptr(x_base), float(a), float(b),
+                                                   float(dt_rk), _ptr(y_out), _ptr(du), int(e_begin), int(e_end),
+                                                   1 if finish else 0))
 
     def enable_timers(self, on=True):
         self._check(self.lib.rmh_enable_timers(self.h, 1 if on else 0))

@@ -29,7 +29,7 @@ class RmhdConfig(C.Structure):
 class RmhdCaseInfo(C.Structure):
     _fields_ = [
         ("order", C.c_int), ("exec_mode", C.c_int), ("ndof", C.c_int), ("ne_owned", C.c_int),
-        ("ne_ghost", C.c_int), ("n_peers", C.c_int), ("ne_global", C.c_longlong),
+        ("ne_ghost", C.c_int), ("n_peers", C.c_int), ("ne_halo", C.c_int), ("pad_", C.c_int), ("ne_global", C.c_longlong),
         ("n", C.c_int * 3), ("lo", C.c_int * 3), ("nl", C.c_int * 3), ("dt", C.c_double),
         ("bb_min", C.c_double * 3), ("bb_max", C.c_double * 3),
     ]
@@ -104,6 +104,7 @@ class Case:
         self.cfg = cfg
         self.order, self.exec_mode, self.ndof = info.order, info.exec_mode, info.ndof
         self.ne_owned, self.ne_ghost, self.ne_global = info.ne_owned, info.ne_ghost, info.ne_global
+        self.ne_halo = info.ne_halo
         self.n, self.lo, self.nl = list(info.n), list(info.lo), list(info.nl)
         self.dt = info.dt
         self.bb_min, self.bb_max = list(info.bb_min), list(info.bb_max)

@@ -149,6 +149,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.xe_max = c->d_xe_max;
    a.cg_iters = c->d_cg;
    a.ne_owned = c->ne;
+   a.e_begin = 0;
+   a.e_end = c->ne;
    a.t = t;
    a.move = c->exec_mode == 1;
    a.alpha = c->exec_mode == 1 ? 1.0 : -1.0;
@@ -187,7 +189,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
 
 template <int P>
 int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double ra, double rb, double dt_rk,
-                       double *y_out, double *du)
+                       double *y_out, double *du, int e_begin, int e_end)
 {
    HoArgs a;
    a.u = u;
@@ -205,6 +207,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.xe_max = c->d_xe_max;
    a.cg_iters = c->d_cg;
    a.ne_owned = c->ne;
+   a.e_begin = e_begin;
+   a.e_end = e_end;
    a.t = c->t;
    a.move = c->exec_mode == 1;
    a.alpha = c->exec_mode == 1 ? 1.0 : -1.0;
@@ -227,12 +231,12 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    {
       constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
       constexpr int NB = K2Cfg<P4, true, true>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3((c->ne + NB - 1) / NB), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3((e_end - e_begin + NB - 1) / NB), dim3(256), 0, c->stream, a);
    }
    else
    {
       constexpr int NB = K2Cfg<P>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+      hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3((e_end - e_begin + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
    return 0;
@@ -501,12 +505,13 @@ int rmh_limit_fused_lo(rmh_ctx *c, const double *u, const double *du_ho, const d
    return limit_fused_impl(c, u, du_ho, du_lo, dt, du, x_base, a, b, dt_rk, y_out);
 }
 
-int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,
-                    double *y_out, double *du)
+int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b,
+                          double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish)
 {
    if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    if (y_out == u || du == u) { return fail(RMH_ERR_INVALID, "rmh_stage_fused: the output must not alias u"); }
+   if (e_begin < 0 || e_end > c->ne || e_begin > e_end) { return fail(RMH_ERR_INVALID, "rmh_stage_fused_range: bad element range"); }
    if (c->lo_type == 4 && (c->p < 2 || !c->d_subvel))
    {
       return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 4 needs order >= 2 and rmh_layout.subcell_vel");
@@ -519,18 +524,32 @@ int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base
       // left behind by the previous fused stage, whose output is this stage's input)
       rc = rmh_elem_minmax(c, u, c->d_xe_min, c->d_xe_max);
       if (rc) { return rc; }
+      c->xe_of = u;
    }
-   EventPair ep;
-   rc = timer_begin(c, 0, ep);
-   if (rc) { return rc; }
-   RMH_DISPATCH(c, rc = launch_stage_fused<P>(c, u, dt, x_base, a, b, dt_rk, y_out, du));
-   if (rc) { return rc; }
-   rc = timer_end(c, 0, ep);
-   std::swap(c->d_xe_min, c->d_xe_min2);
-   std::swap(c->d_xe_max, c->d_xe_max2);
-   c->xe_of = y_out;
+   if (e_end > e_begin)
+   {
+      EventPair ep;
+      rc = timer_begin(c, 0, ep);
+      if (rc) { return rc; }
+      RMH_DISPATCH(c, rc = launch_stage_fused<P>(c, u, dt, x_base, a, b, dt_rk, y_out, du, e_begin, e_end));
+      if (rc) { return rc; }
+      rc = timer_end(c, 0, ep);
+   }
+   if (finish)
+   {
+      std::swap(c->d_xe_min, c->d_xe_min2);
+      std::swap(c->d_xe_max, c->d_xe_max2);
+      c->xe_of = y_out;
+   }
    c->ho_done = false; // the lumped mass vector is not refreshed by the fused stage
    return rc;
+}
+
+int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,
+                    double *y_out, double *du)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null argument"); }
+   return rmh_stage_fused_range(c, u, dt, x_base, a, b, dt_rk, y_out, du, 0, c->ne, 1);
 }
 
 int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend, double *rows, double *out_min,

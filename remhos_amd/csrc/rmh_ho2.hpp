@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
    double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
 
    const int tid = threadIdx.x;
-   const int e0 = blockIdx.x * NB;
+   const int e0 = a.e_begin + blockIdx.x * NB;
    static_assert(C::N2 <= RMH_TAB_STRIDE, "constant table too small");
    const double *gt = c_tab[P]; // constant memory: compile-time indices become scalar loads
    constexpr int oB = C::oB, oG = C::oG, oL = C::oL, odL = C::odL, oW = C::oW, oBg = C::oBg, oBg2 = C::oBg2,
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       if (k < NB * 6 * D2)
       {
          const int eb = k / (6 * D2), f = (k % (6 * D2)) / D2;
-         nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.ne_owned - 1) * 6 + f];
+         nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.e_end - 1) * 6 + f];
       }
    }
    double gx0[NLX], gv[NLX], gu[NLU], gn[NLN];
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       if (k < NB * 81)
       {
          const int eb = k / 81, i = k % 81;
-         const int e = min(e0 + eb, a.ne_owned - 1);
+         const int e = min(e0 + eb, a.e_end - 1);
          gx0[j] = a.x0[(size_t)e * 81 + i];
          gv[j] = a.vel[(size_t)e * 81 + i];
       }
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       gu[j] = 0.0;
       if (k < NB * D3)
       {
-         const int e = min(e0 + k / D3, a.ne_owned - 1);
+         const int e = min(e0 + k / D3, a.e_end - 1);
          gu[j] = a.u[(size_t)e * D3 + k % D3];
       }
    }
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          const int k = tid + j * NT;
          const double lo = wave_minmax<true>(k < NB * D3 ? gu[j] : INFINITY);
          const double hi = wave_minmax<false>(k < NB * D3 ? gu[j] : -INFINITY);
-         if ((tid & 63) == 63 && k < NB * D3 && e0 + k / D3 < a.ne_owned)
+         if ((tid & 63) == 63 && k < NB * D3 && e0 + k / D3 < a.e_end)
          {
             a.xe_min[e0 + k / D3] = lo;
             a.xe_max[e0 + k / D3] = hi;
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       for (int k = tid; k < NB * 3 * D3; k += NT)
       {
          const int eb = k / (3 * D3), r3 = k % (3 * D3);
-         const size_t g = (size_t)min(e0 + eb, a.ne_owned - 1) * 3 * D3 + r3;
+         const size_t g = (size_t)min(e0 + eb, a.e_end - 1) * 3 * D3 + r3;
          const double xs0 = a.subx0[g];
          RMH_W(eb)[C::oXs + r3] = a.move ? xs0 + a.t * a.subvel[g] : xs0;
       }
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
          const int base = mx + D * my + D2 * mz;
          const double *su_ = RMH_W(eb) + oU, *xs = RMH_W(eb) + C::oXs;
-         const int e = min(e0 + eb, a.ne_owned - 1);
+         const int e = min(e0 + eb, a.e_end - 1);
          double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
          double umax = -INFINITY, umin = INFINITY, usum = 0.0;
 #pragma unroll
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          uu4[r] = 0.0;
          if (t < NB * D3)
          {
-            uu4[r] = a.u[(size_t)min(e0 + t / D3, a.ne_owned - 1) * D3 + t % D3];
+            uu4[r] = a.u[(size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3];
             RMH_W(t / D3)[oSA + t % D3] = uu4[r];
          }
          t0[r] = uu4[r];
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             {
                double *el = RMH_W(t / D3) + oM1;
                el[0] = lo; el[1] = hi;
-               if (!BOTH && e0 + t / D3 < a.ne_owned)
+               if (!BOTH && e0 + t / D3 < a.e_end)
                {
                   a.xe_min[e0 + t / D3] = lo;
                   a.xe_max[e0 + t / D3] = hi;
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          }
          double *el = RMH_W(tid) + oM1;
          el[0] = lo; el[1] = hi;
-         if (!BOTH && e0 + tid < a.ne_owned)
+         if (!BOTH && e0 + tid < a.e_end)
          {
             a.xe_min[e0 + tid] = lo;
             a.xe_max[e0 + tid] = hi;
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             weightN += fmax(aux, 1. / (sumFluctN - eps)) * nwN;
             const double duf = RMH_W(eb)[C::oDuf + i];
             dlo[r] = (duf + weightP * rhoP[r] + weightN * rhoN[r]) / mm[r];
-            if (!BOTH && e0 + eb < a.ne_owned)
+            if (!BOTH && e0 + eb < a.e_end)
             {
                a.du[(size_t)e0 * D3 + t] = dlo[r];
                a.m[(size_t)e0 * D3 + t] = mm[r];
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          uu[r] = 0.0; xb[r] = 0.0;
          if (t < NB * D3)
          {
-            const size_t g = (size_t)min(e0 + t / D3, a.ne_owned - 1) * D3 + t % D3;
+            const size_t g = (size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3;
             uu[r] = a.u[g];
             if (a.x_base) { xb[r] = a.x_base[g]; }
          }
@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          slo[j] = INFINITY; shi[j] = -INFINITY;
          if (k < NB * 27)
          {
-            const int e = min(e0 + k / 27, a.ne_owned - 1);
+            const int e = min(e0 + k / 27, a.e_end - 1);
             const int nb = a.stencil27[(size_t)e * 27 + k % 27];
             if (nb >= 0)
             {
@@ -1236,13 +1236,13 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
-         if (t < NB * D3 && e0 + t / D3 < a.ne_owned)
+         if (t < NB * D3 && e0 + t / D3 < a.e_end)
          {
             a.du[(size_t)e0 * D3 + t] = xg[r];
             a.m[(size_t)e0 * D3 + t] = mm[r];
          }
       }
-      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < a.ne_owned)
+      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < a.e_end)
       {
          a.xe_min[e0 + tid] = my_min;
          a.xe_max[e0 + tid] = my_max;
@@ -1309,7 +1309,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos[r] / sumNeg[r]; }
             const double dui = dlo[r] + fc / mm[r];
             ynew[r] = (a.x_base ? a.rk_a * xb[r] : 0.0) + a.rk_b * (uu[r] + a.dt_rk * dui);
-            if (e0 + t / D3 < a.ne_owned)
+            if (e0 + t / D3 < a.e_end)
             {
                a.y_out[(size_t)e0 * D3 + t] = ynew[r];
                if (a.du) { a.du[(size_t)e0 * D3 + t] = dui; }
@@ -1325,7 +1325,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             const int t = tid + r * NT;
             const double lo = wave_minmax<true>(t < NB * D3 ? ynew[r] : INFINITY);
             const double hi = wave_minmax<false>(t < NB * D3 ? ynew[r] : -INFINITY);
-            if ((tid & 63) == 63 && t < NB * D3 && e0 + t / D3 < a.ne_owned)
+            if ((tid & 63) == 63 && t < NB * D3 && e0 + t / D3 < a.e_end)
             {
                a.xe_min_out[e0 + t / D3] = lo;
                a.xe_max_out[e0 + t / D3] = hi;
@@ -1342,7 +1342,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             if (t < NB * D3) { RMH_W(t / D3)[64 + t % D3] = ynew[r]; }
          }
          __syncthreads();
-         if (tid < NB && e0 + tid < a.ne_owned)
+         if (tid < NB && e0 + tid < a.e_end)
          {
             double lo = INFINITY, hi = -INFINITY;
             for (int i = 0; i < D3; i++)

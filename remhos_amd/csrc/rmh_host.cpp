@@ -490,6 +490,50 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
          }
       }
    }
+   // ---- halo-first element order ----------------------------------------------------------------
+   // Owned elements whose 27-stencil reaches a ghost come first (they form the shell of the box), so
+   // that one stage can run as two element ranges: [ne_halo, ne) while the neighbour exchange is in
+   // flight, [0, ne_halo) after it.  Single-rank cases have no ghosts and keep the lattice order.
+   out.ne_halo = 0;
+   if (out.ne_ghost > 0)
+   {
+      std::vector<int> new_of_old(ne), old_of_new(ne);
+      int nh = 0;
+      std::vector<char> halo(ne, 0);
+      for (int e = 0; e < ne; e++)
+      {
+         for (int s = 0; s < 27; s++) { halo[e] = halo[e] || out.stencil27[(size_t)e * 27 + s] >= ne; }
+         nh += halo[e];
+      }
+      int ih = 0, ii = nh;
+      for (int e = 0; e < ne; e++)
+      {
+         const int k = halo[e] ? ih++ : ii++;
+         new_of_old[e] = k;
+         old_of_new[k] = e;
+      }
+      out.ne_halo = nh;
+      auto permute_rows = [&](auto &v, size_t w)
+      {
+         if (v.empty()) { return; }
+         auto tmp = v;
+         for (int k = 0; k < ne; k++)
+         {
+            std::copy(tmp.begin() + (size_t)old_of_new[k] * w, tmp.begin() + ((size_t)old_of_new[k] + 1) * w,
+                      v.begin() + (size_t)k * w);
+         }
+      };
+      permute_rows(out.x0, 81);
+      permute_rows(out.vel, 81);
+      permute_rows(out.u0, (size_t)out.ndof);
+      permute_rows(out.subcell_vel, (size_t)3 * out.ndof);
+      permute_rows(out.owned_gid, 1);
+      permute_rows(out.stencil27, 27);
+      permute_rows(out.face_nbr, 6);
+      for (int &idx : out.stencil27) { if (idx >= 0 && idx < ne) { idx = new_of_old[idx]; } }
+      for (int &idx : out.face_nbr) { if (idx >= 0 && idx < ne) { idx = new_of_old[idx]; } }
+      for (Peer &pr : out.peers) { for (int &el : pr.send_elems) { el = new_of_old[el]; } }
+   }
    return "";
 }
 

@@ -35,6 +35,7 @@ struct CaseData
 {
    int order = 0, exec_mode = 0, ndof = 0;
    int ne_owned = 0, ne_ghost = 0;
+   int ne_halo = 0;        // owned elements [0, ne_halo) have a ghost in their 27-stencil (ordered first)
    long long ne_global = 0;
    int n[3] = {0, 0, 0};   // global elements per direction
    int lo[3] = {0, 0, 0};  // first owned element per direction

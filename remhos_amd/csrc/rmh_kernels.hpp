@@ -52,6 +52,7 @@ struct HoArgs
    double *xe_min, *xe_max; // [ne]
    int *cg_iters;          // [1] max over elements (atomicMax)
    int ne_owned;
+   int e_begin, e_end;     // elements this launch works on (ho_kernel2; the whole rank: 0, ne_owned)
    double t;               // pseudo-time (remap) -- X = x0 + t*vel
    int move;               // 1: remap (mesh moves), 0: transport (static mesh)
    double alpha;           // ConvectionIntegrator alpha: -1 transport, +1 remap (remhos.cpp:648-657)

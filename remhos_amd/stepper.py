@@ -15,8 +15,9 @@ from .capi import Context
 
 
 class Stepper:
-    def __init__(self, lib, case, device="cuda:0", dist=None, fused=True, one_kernel=True):
+    def __init__(self, lib, case, device="cuda:0", dist=None, fused=True, one_kernel=True, overlap=True):
         self.case = case
+        self.overlap = overlap  # one-kernel stage: interior elements overlap the halo exchange
         self.dev = torch.device(device)
         self.dist = dist if (dist is not None and case.peers) else None
         self.lo = int(case.cfg.lo_type)
@@ -78,8 +79,9 @@ class Stepper:
 
     # -- halo exchange: neighbour all-to-all of [u rows | min | max] ---------------------------------
     def exchange(self, u):
+        """Post the exchange; returns the work handles (wait on them before anything reads the ghosts)."""
         if not self.plan:
-            return
+            return []
         if self.dist is None:
             raise RuntimeError("this rank has neighbour ranks but no torch.distributed group was given")
         d = self.dist
@@ -89,14 +91,24 @@ class Stepper:
             ops += [d.P2POp(d.isend, self.srows[s0:s1], rank), d.P2POp(d.irecv, self.ug[r0:r1], rank),
                     d.P2POp(d.isend, self.smin[s0:s1], rank), d.P2POp(d.irecv, self.gmin[r0:r1], rank),
                     d.P2POp(d.isend, self.smax[s0:s1], rank), d.P2POp(d.irecv, self.gmax[r0:r1], rank)]
-        for w in d.batch_isend_irecv(ops):
-            w.wait()
+        return d.batch_isend_irecv(ops)
 
     # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
     def stage(self, u, t, dt, x_base, a, b, out):
         c = self.ctx
-        self.exchange(u)
+        works = self.exchange(u)
         c.setup(t)
+        if self.one_kernel and works and self.overlap:
+            # elements that reach no ghost run while the exchange is in flight (the RCCL send/recv
+            # kernels live on the process group's own stream), the halo-dependent shell after it
+            nh, ne = self.case.ne_halo, self.case.ne_owned
+            c.stage_fused_range(u, dt, out, nh, ne, False, x_base=x_base, a=a, b=b, dt_rk=dt)
+            for w in works:
+                w.wait()
+            c.stage_fused_range(u, dt, out, 0, nh, True, x_base=x_base, a=a, b=b, dt_rk=dt)
+            return
+        for w in works:
+            w.wait()
         if self.one_kernel:
             c.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt)
             return
