@@ -104,6 +104,13 @@ int rmh_set_ghost_minmax(rmh_ctx *ctx, const double *xe_min_ghost, const double 
 int rmh_halo_pack(rmh_ctx *ctx, const double *u, const int *send_elems, int nsend, double *rows,
                   double *out_min, double *out_max);
 
+/* The same exchange with ONE message per neighbour rank: a ghost record is [ndof values of u | min | max]
+ * (ndof + 2 doubles).  rmh_halo_pack_records writes the records of the send list to rec[nsend][ndof + 2];
+ * the receiver's ghost block is rec[ne_ghost][ndof + 2], announced with rmh_set_ghost_records (replaces
+ * rmh_set_ghost_u + rmh_set_ghost_minmax). */
+int rmh_halo_pack_records(rmh_ctx *ctx, const double *u, const int *send_elems, int nsend, double *rec);
+int rmh_set_ghost_records(rmh_ctx *ctx, const double *rec);
+
 /* HOSolver::CalcHOSolution (remhos_ho.hpp:38, LocalInverseHOSolver remhos_ho.cpp:84-129):
  * du = M^-1 (K_vol + K_face) u with an element-local, tightly converged mass solve.
  * Also refreshes the lumped mass vector (remhos.cpp:1632) and the element extrema of u. */

@@ -16,7 +16,8 @@ SYMBOLS = [
     "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
-    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
+    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range",
+    "rmh_halo_pack_records", "rmh_set_ghost_records", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
     "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_set_lo_type",
 ]
 
@@ -73,6 +74,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_limit_fused.argtypes = [p, p, p, d, p, p, d, d, d, p]
     lib.rmh_limit_fused_lo.argtypes = [p, p, p, p, d, p, p, d, d, d, p]
     lib.rmh_stage_fused.argtypes = [p, p, d, p, d, d, d, p, p]
+    lib.rmh_halo_pack_records.argtypes = [p, p, p, C.c_int, p]
+    lib.rmh_set_ghost_records.argtypes = [p, p]
     lib.rmh_stage_fused_range.argtypes = [p, p, d, p, d, d, d, p, p, C.c_int, C.c_int, C.c_int]
     lib.rmh_timers.argtypes = [p, C.POINTER(d * 4)]
     lib.rmh_reset_timers.argtypes = [p]
@@ -154,6 +157,13 @@ class Context:
     def set_ghost_minmax(self, gmin, gmax):
         self._keep_ref("gmm", (gmin, gmax))
         self._check(self.lib.rmh_set_ghost_minmax(self.h, _ptr(gmin), _ptr(gmax)))
+
+    def set_ghost_records(self, rec):
+        self._keep_ref("rec", rec)
+        self._check(self.lib.rmh_set_ghost_records(self.h, _ptr(rec)))
+
+    def halo_pack_records(self, u, send_elems, nsend, rec):
+        self._check(self.lib.rmh_halo_pack_records(self.h, _ptr(u), _ptr(send_elems), int(nsend), _ptr(rec)))
 
     def _keep_ref(self, key, obj):
         self.__dict__["_ref_" + key] = obj

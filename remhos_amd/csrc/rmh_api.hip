@@ -51,6 +51,7 @@ struct rmh_ctx
    const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold
    int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
    const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
+   int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)
    double rel_tol = 1e-14, abs_tol = 0.0;
    int max_iter = 100;
    bool ho_done = false;
@@ -136,6 +137,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    HoArgs a;
    a.u = u;
    a.u_ghost = c->u_ghost;
+   a.gh_ustride = c->gh_ustride;
+   a.gh_mstride = c->gh_mstride;
    a.x0 = c->d_x0;
    a.vel = c->d_vel;
    a.face_nbr = c->d_nbr;
@@ -194,6 +197,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    HoArgs a;
    a.u = u;
    a.u_ghost = c->u_ghost;
+   a.gh_ustride = c->gh_ustride;
+   a.gh_mstride = c->gh_mstride;
    a.x0 = c->d_x0;
    a.vel = c->d_vel;
    a.face_nbr = c->d_nbr;
@@ -294,6 +299,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->exec_mode = L->exec_mode;
    c->device = L->device;
    c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
+   c->gh_ustride = c->ndof;
    if (const char *v = std::getenv("RMH_HO_KERNEL")) { c->ho_variant = std::atoi(v) == 1 ? 1 : 2; }
    const size_t ne = c->ne;
    int rc = 0;
@@ -360,6 +366,7 @@ int rmh_set_ghost_u(rmh_ctx *c, const double *ug)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
    c->u_ghost = ug;
+   c->gh_ustride = c->ndof;
    return RMH_OK;
 }
 
@@ -368,6 +375,17 @@ int rmh_set_ghost_minmax(rmh_ctx *c, const double *gmin, const double *gmax)
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
    c->gh_min = gmin;
    c->gh_max = gmax;
+   c->gh_mstride = 1;
+   return RMH_OK;
+}
+
+int rmh_set_ghost_records(rmh_ctx *c, const double *rec)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->u_ghost = rec;
+   c->gh_min = rec ? rec + c->ndof : nullptr;
+   c->gh_max = rec ? rec + c->ndof + 1 : nullptr;
+   c->gh_ustride = c->gh_mstride = c->ndof + 2;
    return RMH_OK;
 }
 
@@ -438,7 +456,7 @@ int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u
    if (!c || !xe_min || !xe_max || !u_min || !u_max) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
-                                      (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, u_min,
+                                      (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
                                       u_max));
    RMH_HIP(hipGetLastError());
    return RMH_OK;
@@ -476,6 +494,7 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    la.xe_max = c->d_xe_max;
    la.gh_min = c->gh_min;
    la.gh_max = c->gh_max;
+   la.gh_mstride = c->gh_mstride;
    la.ne_owned = c->ne;
    la.dt = dt;
    la.du = du;
@@ -558,7 +577,18 @@ int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend,
    if (!c || !u || (nsend > 0 && (!send_elems || !rows || !out_min || !out_max))) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (nsend <= 0) { return RMH_OK; }
    RMH_DISPATCH(c, hipLaunchKernelGGL((halo_pack_kernel<P>), dim3(nsend), dim3(KCfg<P>::NT), 0, c->stream, u, send_elems,
-                                      rows, out_min, out_max));
+                                      rows, out_min, out_max, c->ndof, 1));
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_halo_pack_records(rmh_ctx *c, const double *u, const int *send_elems, int nsend, double *rec)
+{
+   if (!c || !u || (nsend > 0 && (!send_elems || !rec))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (nsend <= 0) { return RMH_OK; }
+   const int w = c->ndof + 2;
+   RMH_DISPATCH(c, hipLaunchKernelGGL((halo_pack_kernel<P>), dim3(nsend), dim3(KCfg<P>::NT), 0, c->stream, u, send_elems,
+                                      rec, rec + c->ndof, rec + c->ndof + 1, w, w));
    RMH_HIP(hipGetLastError());
    return RMH_OK;
 }

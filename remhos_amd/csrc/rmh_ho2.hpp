@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
          const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
          const int nb = nbi[j];
-         const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * D3;
+         const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
          gn[j] = un[(side ? 0 : P) * strc + i1 * str1 + i2 * str2]; // the neighbour's opposite face layer
       }
    }
@@ -1019,7 +1019,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             if (nb >= 0)
             {
                if (nb < a.ne_owned) { slo[j] = a.xe_min[nb]; shi[j] = a.xe_max[nb]; }
-               else { slo[j] = a.gh_min[nb - a.ne_owned]; shi[j] = a.gh_max[nb - a.ne_owned]; }
+               else { slo[j] = a.gh_min[(size_t)(nb - a.ne_owned) * a.gh_mstride]; shi[j] = a.gh_max[(size_t)(nb - a.ne_owned) * a.gh_mstride]; }
             }
          }
       }

@@ -39,7 +39,7 @@ __constant__ double c_tab[7][RMH_TAB_STRIDE];
 struct HoArgs
 {
    const double *u;        // [ne_owned][D3]
-   const double *u_ghost;  // [ne_ghost][D3] or null
+   const double *u_ghost;  // [ne_ghost][gh_ustride] or null (gh_ustride = D3, or D3 + 2 for ghost records)
    const double *x0;       // [ne][3][27]
    const double *vel;      // [ne][3][27]
    const int *face_nbr;    // [ne][6]
@@ -61,7 +61,8 @@ struct HoArgs
    int max_iter;
    // fused stage (ho_kernel2<P, true>): LimitMult for -lo 5 -fct 2 and the RK update in the same kernel
    const int *stencil27;            // [ne][27]
-   const double *gh_min, *gh_max;   // ghost element extrema
+   const double *gh_min, *gh_max;   // ghost element extrema, element g at [g * gh_mstride]
+   int gh_ustride, gh_mstride;
    double dt;                       // full time step (LO / FCT)
    const double *x_base;            // y_out = rk_a * x_base + rk_b * (u + dt_rk * du)
    double rk_a, rk_b, dt_rk;
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
          if (nb >= 0)
          {
             const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3
-                               : a.u_ghost + (size_t)(nb - a.ne_owned) * D3;
+                               : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
             const int ic = side ? 0 : P; // the neighbour's opposite face layer
             val = un[ic * strc + i1 * str1 + i2 * str2];
          }
@@ -870,7 +871,7 @@ __device__ inline void dof_bounds(int i, const double *smin, const double *smax,
 }
 
 __device__ inline void load_stencil(int e, int ne_owned, const int *stencil27, const double *xe_min,
-                                    const double *xe_max, const double *gh_min, const double *gh_max,
+                                    const double *xe_max, const double *gh_min, const double *gh_max, int gh_mstride,
                                     double *smin, double *smax)
 {
    const int tid = threadIdx.x;
@@ -881,7 +882,7 @@ __device__ inline void load_stencil(int e, int ne_owned, const int *stencil27, c
       if (nb >= 0)
       {
          if (nb < ne_owned) { lo = xe_min[nb]; hi = xe_max[nb]; }
-         else { lo = gh_min[nb - ne_owned]; hi = gh_max[nb - ne_owned]; }
+         else { lo = gh_min[(size_t)(nb - ne_owned) * gh_mstride]; hi = gh_max[(size_t)(nb - ne_owned) * gh_mstride]; }
       }
       smin[tid] = lo;
       smax[tid] = hi;
@@ -892,12 +893,12 @@ __device__ inline void load_stencil(int e, int ne_owned, const int *stencil27, c
 template <int P>
 __global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(const int *stencil27, int ne_owned, const double *xe_min,
                                                              const double *xe_max, const double *gh_min,
-                                                             const double *gh_max, double *u_min, double *u_max)
+                                                             const double *gh_max, int gh_mstride, double *u_min, double *u_max)
 {
    using C = KCfg<P>;
    __shared__ double smin[27], smax[27];
    const int e = blockIdx.x;
-   load_stencil(e, ne_owned, stencil27, xe_min, xe_max, gh_min, gh_max, smin, smax);
+   load_stencil(e, ne_owned, stencil27, xe_min, xe_max, gh_min, gh_max, gh_mstride, smin, smax);
    __syncthreads();
    for (int i = threadIdx.x; i < C::D3; i += C::NT)
    {
@@ -954,7 +955,8 @@ __global__ void __launch_bounds__(64) subcell_setup_kernel(const double *x0, con
 // reduction (remhos_tools.cpp:461-466) in one pass.
 template <int P>
 __global__ void __launch_bounds__(KCfg<P>::NT) halo_pack_kernel(const double *u, const int *send_elems, double *rows,
-                                                                double *out_min, double *out_max)
+                                                                double *out_min, double *out_max, int row_stride,
+                                                                int mm_stride)
 {
    using C = KCfg<P>;
    __shared__ double s_red[4];
@@ -964,13 +966,13 @@ __global__ void __launch_bounds__(KCfg<P>::NT) halo_pack_kernel(const double *u,
    for (int i = threadIdx.x; i < C::D3; i += C::NT)
    {
       const double v = u[(size_t)e * C::D3 + i];
-      rows[(size_t)k * C::D3 + i] = v;
+      rows[(size_t)k * row_stride + i] = v;
       lmin = fmin(lmin, v);
       lmax = fmax(lmax, v);
    }
    lmin = block_min<C::NW>(lmin, s_red);
    lmax = block_max<C::NW>(lmax, s_red);
-   if (threadIdx.x == 0) { out_min[k] = lmin; out_max[k] = lmax; }
+   if (threadIdx.x == 0) { out_min[(size_t)k * mm_stride] = lmin; out_max[(size_t)k * mm_stride] = lmax; }
 }
 
 // MassBasedAvg::CalcLOSolution (remhos_lo.cpp:247-324): du_lo = (ubar - u)/dt with
@@ -1069,6 +1071,7 @@ struct LimitArgs
    const double *du_lo; // null: mass-based average computed here (lo 5); else the LO rate of another solver (lo 4)
    const int *stencil27;
    const double *xe_min, *xe_max, *gh_min, *gh_max;
+   int gh_mstride;
    int ne_owned;
    double dt;
    double *du;          // may be null when y_out is given
@@ -1085,7 +1088,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
    __shared__ double smin[27], smax[27];
    const int e = blockIdx.x;
    constexpr double eps = 1.0e-15;
-   load_stencil(e, a.ne_owned, a.stencil27, a.xe_min, a.xe_max, a.gh_min, a.gh_max, smin, smax);
+   load_stencil(e, a.ne_owned, a.stencil27, a.xe_min, a.xe_max, a.gh_min, a.gh_max, a.gh_mstride, smin, smax);
    double uu[C::DPT], mm[C::DPT], dh[C::DPT];
    double mass = 0.0, vol = 0.0;
 #pragma unroll

@@ -50,16 +50,12 @@ class Stepper:
             self.m = torch.empty_like(self.x)
         self.t = 0.0
         self.dt = case.dt
-        # ghost storage and exchange plan
-        self.ug = torch.zeros(max(ng, 1), nd, **f64)
-        self.gmin = torch.zeros(max(ng, 1), **f64)
-        self.gmax = torch.zeros(max(ng, 1), **f64)
+        # ghost storage and exchange plan.  A ghost record is [ndof values of u | min | max]; the ghost slots of
+        # a peer are a contiguous range (ghosts are ordered by owner rank, then global id), so ONE message per
+        # peer lands directly in the ghost block; one device pack kernel gathers the records of all peers' send lists
+        self.ghost = torch.zeros(max(ng, 1), nd + 2, **f64)
         if ng:
-            self.ctx.set_ghost_u(self.ug)
-            self.ctx.set_ghost_minmax(self.gmin, self.gmax)
-        # exchange plan: ghost slots of a peer are a contiguous range (ghosts are ordered by owner rank,
-        # then global id), so received rows land directly in the ghost arrays; one device pack kernel
-        # gathers the rows (+ min / max) of all peers' send lists
+            self.ctx.set_ghost_records(self.ghost)
         self.plan = []
         send_all, off = [], 0
         for rank, send, recv in case.peers:
@@ -69,29 +65,26 @@ class Stepper:
             send_all.append(send)
             off += len(send)
         self.nsend = off
+        self.ops = []
         if self.plan:
             import numpy as np
 
             self.send_elems = torch.from_numpy(np.concatenate(send_all).astype("int32")).to(self.dev)
-            self.srows = torch.empty(self.nsend, nd, **f64)
-            self.smin = torch.empty(self.nsend, **f64)
-            self.smax = torch.empty(self.nsend, **f64)
+            self.srec = torch.empty(self.nsend, nd + 2, **f64)
+            if self.dist is not None:
+                d = self.dist
+                for rank, s0, s1, r0, r1 in self.plan:
+                    self.ops += [d.P2POp(d.isend, self.srec[s0:s1], rank), d.P2POp(d.irecv, self.ghost[r0:r1], rank)]
 
-    # -- halo exchange: neighbour all-to-all of [u rows | min | max] ---------------------------------
+    # -- halo exchange: neighbour all-to-all of ghost records ----------------------------------------
     def exchange(self, u):
         """Post the exchange; returns the work handles (wait on them before anything reads the ghosts)."""
         if not self.plan:
             return []
         if self.dist is None:
             raise RuntimeError("this rank has neighbour ranks but no torch.distributed group was given")
-        d = self.dist
-        self.ctx.halo_pack(u, self.send_elems, self.nsend, self.srows, self.smin, self.smax)
-        ops = []
-        for rank, s0, s1, r0, r1 in self.plan:
-            ops += [d.P2POp(d.isend, self.srows[s0:s1], rank), d.P2POp(d.irecv, self.ug[r0:r1], rank),
-                    d.P2POp(d.isend, self.smin[s0:s1], rank), d.P2POp(d.irecv, self.gmin[r0:r1], rank),
-                    d.P2POp(d.isend, self.smax[s0:s1], rank), d.P2POp(d.irecv, self.gmax[r0:r1], rank)]
-        return d.batch_isend_irecv(ops)
+        self.ctx.halo_pack_records(u, self.send_elems, self.nsend, self.srec)
+        return self.dist.batch_isend_irecv(self.ops)
 
     # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
     def stage(self, u, t, dt, x_base, a, b, out):

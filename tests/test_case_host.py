@@ -59,6 +59,11 @@ def test_partition_is_consistent(lib, mesh, rs, part):
         assert np.array_equal(st, g.stencil27[c.owned_gid])
         fn = np.where(c.face_nbr >= 0, gid_of_local[np.maximum(c.face_nbr, 0)], -1)
         assert np.array_equal(fn, g.face_nbr[c.owned_gid])
+        # halo-first order: exactly the first ne_halo elements reach a ghost, and only those are sent
+        halo = (c.stencil27 >= c.ne_owned).any(axis=1)
+        assert halo[:c.ne_halo].all() and not halo[c.ne_halo:].any()
+        for _, send, _ in c.peers:
+            assert (send < c.ne_halo).all()
         # every ghost is filled by exactly one peer
         filled = np.concatenate([r for _, _, r in c.peers]) if c.peers else np.zeros(0, np.int32)
         assert np.array_equal(np.sort(filled), np.arange(c.ne_ghost))

@@ -43,7 +43,10 @@ def _run(tmp_path, mesh, rs, p, prob, steps, part):
 @pytest.mark.parametrize("mesh,rs,p,prob,part", [("cube01_hex", 1, 1, 10, (2, 1, 1)), ("periodic-cube", 0, 2, 10, (1, 2, 1)),
                                                  ("cube01_hex", 1, 1, 10, (2, 2, 1)),
                                                  # p = 3: the wavefront-aligned DPP reductions of the batched kernel, 3 ranks
-                                                 ("periodic-cube", 0, 3, 10, (1, 3, 1))])
+                                                 ("periodic-cube", 0, 3, 10, (1, 3, 1)),
+                                                 # 6^3 elements, 3x6x6 per rank: a non-empty interior range runs while
+                                                 # the exchange is in flight (rmh_stage_fused_range), the shell after it
+                                                 ("periodic-cube", 1, 1, 10, (2, 1, 1))])
 def test_rank_count_invariance(tmp_path, mesh, rs, p, prob, part):
     from oracle.remhos_oracle import Config, Remhos
 

@@ -116,3 +116,64 @@ def test_generic_orders_multi_block_race_free(lib, p):
     for dh, du in outs[1:]:
         assert np.array_equal(dh, outs[0][0]) and np.array_equal(du, outs[0][1])
     ctx.close()
+
+
+def test_two_blocks_manual_exchange_both_ghost_layouts(lib):
+    """Two blocks of one mesh in one process, ghosts filled by hand: the separate-array ghost interface
+    (rmh_halo_pack + rmh_set_ghost_u + rmh_set_ghost_minmax, the shape of MFEM's FaceNbrData) and the
+    record interface (rmh_halo_pack_records + rmh_set_ghost_records) give the same stage, which equals
+    the single-block stage bit for bit -- whole, and as interior / halo element ranges."""
+    from remhos_amd.capi import Context
+    from remhos_amd.case import Case, make_config
+
+    mesh, rs, p, prob, t, dt = "periodic-cube", 1, 1, 10, 0.3, 0.01
+    g = Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5))
+    u_g = perturbed(g.u0)
+
+    def mk(c):
+        return Context(lib, order=p, exec_mode=c.exec_mode, x0=c.x0, vel=c.vel, face_nbr=c.face_nbr,
+                       stencil27=c.stencil27, ne_ghost=c.ne_ghost)
+
+    cg = mk(g)
+    cg.setup(t)
+    y_g = np.zeros_like(u_g)
+    cg.stage_fused(u_g, dt, y_g)
+    cases = [Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5, part=(2, 1, 1), rank=k)) for k in range(2)]
+    nd = g.ndof
+    for layout in ("arrays", "records"):
+        us = [np.ascontiguousarray(u_g[c.owned_gid]) for c in cases]
+        ctxs = [mk(c) for c in cases]
+        ghosts = []
+        for c, ctx in zip(cases, ctxs):
+            if layout == "arrays":
+                gh = (np.zeros((c.ne_ghost, nd)), np.zeros(c.ne_ghost), np.zeros(c.ne_ghost))
+                ctx.set_ghost_u(gh[0])
+                ctx.set_ghost_minmax(gh[1], gh[2])
+            else:
+                gh = np.zeros((c.ne_ghost, nd + 2))
+                ctx.set_ghost_records(gh)
+            ghosts.append(gh)
+        for k, (c, ctx) in enumerate(zip(cases, ctxs)):
+            (rank, send, _), = c.peers
+            recv = [r for rk, _, r in cases[rank].peers if rk == k][0]
+            send = np.ascontiguousarray(send, dtype=np.int32)
+            if layout == "arrays":
+                rows, mn, mx = np.zeros((len(send), nd)), np.zeros(len(send)), np.zeros(len(send))
+                ctx.halo_pack(us[k], send, len(send), rows, mn, mx)
+                ghosts[rank][0][recv], ghosts[rank][1][recv], ghosts[rank][2][recv] = rows, mn, mx
+            else:
+                rec = np.zeros((len(send), nd + 2))
+                ctx.halo_pack_records(us[k], send, len(send), rec)
+                ghosts[rank][recv] = rec
+        for k, (c, ctx) in enumerate(zip(cases, ctxs)):
+            ctx.setup(t)
+            y = np.zeros_like(us[k])
+            assert 0 < c.ne_halo < c.ne_owned
+            if layout == "arrays":
+                ctx.stage_fused(us[k], dt, y)
+            else:
+                ctx.stage_fused_range(us[k], dt, y, c.ne_halo, c.ne_owned, False)
+                ctx.stage_fused_range(us[k], dt, y, 0, c.ne_halo, True)
+            assert np.array_equal(y, y_g[c.owned_gid])
+            ctx.close()
+    cg.close()

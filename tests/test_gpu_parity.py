@@ -205,11 +205,24 @@ def test_one_kernel_stage(gpu, mesh, rs, p, prob, t):
     assert _relerr(du.cpu().numpy(), du_ref) < tol
     assert _relerr(y.cpu().numpy(), y_ref) < tol
     assert _relerr(du2.cpu().numpy(), du2_ref) < 10 * tol
+    # the same stage as three element ranges (rmh_stage_fused_range): not a bit may change, including the
+    # element extrema handed to the following stage
+    ne = x0.shape[0]
+    cuts = [0, ne // 3 + 1, ne - 2, ne]
+    yr, dur, y2r, du2r = (torch.empty_like(u) for _ in range(4))
+    for k in (1, 2, 0):
+        ctx.stage_fused_range(u, cfg.dt, yr, cuts[k], cuts[k + 1], k == 0, x_base=xb, a=0.75, b=0.25, dt_rk=cfg.dt, du=dur)
+    ctx.stage_fused(yr, cfg.dt, y2r, du=du2r)
+    torch.cuda.synchronize()
+    assert torch.equal(yr, y) and torch.equal(dur, du)
+    assert torch.equal(y2r, y2) and torch.equal(du2r, du2)
     # output must not alias the input
     from remhos_amd.capi import RmhError
 
     with pytest.raises(RmhError, match="alias"):
         ctx.stage_fused(u, cfg.dt, u)
+    with pytest.raises(RmhError, match="range"):
+        ctx.stage_fused_range(u, cfg.dt, y, 0, ne + 1, True)
     ctx.close()
 
 
@@ -240,4 +253,10 @@ def test_one_kernel_stage_lo4(gpu, mesh, rs, p, prob, t):
     torch.cuda.synchronize()
     assert _relerr(du.cpu().numpy(), du_ref) < REL[p]
     assert _relerr(y.cpu().numpy(), y_ref) < REL[p]
+    ne = x0.shape[0]
+    yr, dur = torch.empty_like(u), torch.empty_like(u)
+    ctx.stage_fused_range(u, cfg.dt, yr, ne // 2 - 1, ne, False, x_base=xb, a=1.0 / 3.0, b=2.0 / 3.0, dt_rk=cfg.dt, du=dur)
+    ctx.stage_fused_range(u, cfg.dt, yr, 0, ne // 2 - 1, True, x_base=xb, a=1.0 / 3.0, b=2.0 / 3.0, dt_rk=cfg.dt, du=dur)
+    torch.cuda.synchronize()
+    assert torch.equal(yr, y) and torch.equal(dur, du)
     ctx.close()
