@@ -81,7 +81,9 @@ struct K2Cfg : TabLayout<P>
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
    static constexpr int EL0 = W + RF + (BOTH ? RF : 0) + (LO4 ? 6 * NS + D3 : 0);
    static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
-   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + 8 * NB;
+   // partial sums of the generic reductions: chunks of 64 dofs (one wavefront each), 8 chunks for small elements
+   static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + cmax(8, 2 * DOT_CH) * NB;
    static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
    static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 4 ? 4 : (160 * 1024) / LDS_BYTES);
@@ -121,6 +123,18 @@ __device__ inline double wave_minmax(double v)
    return v;
 }
 
+// sum over the 64 lanes of a wavefront in a fixed order; valid in lane 63
+__device__ inline double wave_sum(double v)
+{
+   v = dpp_add<0xB1, 0xF>(v);
+   v = dpp_add<0x4E, 0xF>(v);
+   v = dpp_add<0x141, 0xF>(v);
+   v = dpp_add<0x140, 0xF>(v);
+   v = dpp_add<0x142, 0xA>(v);
+   v = dpp_add<0x143, 0xC>(v);
+   return v;
+}
+
 // Sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r] (the
 // element total, broadcast back to the dof threads).  ONE barrier per call: results go through a
 // ring of three LDS buffers (s_acc3[3][NB]); the buffer of the call before the previous one is
@@ -153,11 +167,12 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
    else
    {
       // generic orders: deterministic two-level sum (no atomics: the result must not depend on the
-      // arrival order -- rank-count invariance of the whole run is checked bit for bit).  Values go to
-      // the sB slot of the element block (free outside phase J), CH chunks per element are summed
-      // serially by one thread each, the chunk sums are added in order.
-      constexpr int CH = 8, CL = (C::D3 + CH - 1) / CH;
+      // arrival order, nor on the slot of the element in the batch -- rank-count invariance of the whole
+      // run is checked bit for bit).  Values go to the sB slot of the element block (free outside phase J);
+      // every 64-dof chunk of an element is summed by one wavefront (DPP row reductions, fixed order),
+      // the chunk sums of an element are added in order.
       (void)old;
+      (void)cur;
 #pragma unroll
       for (int r = 0; r < C::DR; r++)
       {
@@ -166,13 +181,31 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
       }
       __syncthreads();
       double *part = s_acc3 + 4 * C::NB + 8 + C::N2; // [NB][CH], behind the table copy
-      for (int k = tid; k < C::NB * CH; k += C::NT)
+      constexpr int CH = C::DOT_CH;
+      if (C::D3 >= 64)
       {
-         const double *src = lds + (k / CH) * C::EL + C::oSB;
-         const int i0 = (k % CH) * CL;
-         double acc = 0.0;
-         for (int i = i0; i < i0 + CL && i < C::D3; i++) { acc += src[i]; }
-         part[k] = acc;
+         // CH chunks of 64 dofs per element, one wavefront each
+         const int lane = tid & 63, wave = tid >> 6;
+         for (int k = wave; k < C::NB * CH; k += C::NT / 64)
+         {
+            const int i = (k % CH) * 64 + lane;
+            double x = (i < C::D3) ? (lds + (k / CH) * C::EL)[C::oSB + i] : 0.0;
+            x = wave_sum(x);
+            if (lane == 63) { part[k] = x; }
+         }
+      }
+      else
+      {
+         // small elements (p = 1, 2): CH chunks per element are summed serially by one thread each
+         constexpr int CL = (C::D3 + CH - 1) / CH;
+         for (int k = tid; k < C::NB * CH; k += C::NT)
+         {
+            const double *src = lds + (k / CH) * C::EL + C::oSB;
+            const int i0 = (k % CH) * CL;
+            double acc = 0.0;
+            for (int i = i0; i < i0 + CL && i < C::D3; i++) { acc += src[i]; }
+            part[k] = acc;
+         }
       }
       __syncthreads();
 #pragma unroll
@@ -1342,7 +1375,34 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             if (t < NB * D3) { RMH_W(t / D3)[64 + t % D3] = ynew[r]; }
          }
          __syncthreads();
-         if (tid < NB && e0 + tid < a.e_end)
+         if (D3 >= 64)
+         {
+            // one wavefront per 64-dof chunk, then the chunks of an element
+            constexpr int CH = C::DOT_CH;
+            double *part = s_acc + 4 * NB + 8 + C::N2; // [NB][CH][2]
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int k = wave; k < NB * CH; k += NT / 64)
+            {
+               const int i = (k % CH) * 64 + lane;
+               const double x = RMH_W(k / CH)[64 + min(i, D3 - 1)];
+               const double lo = wave_minmax<true>(x), hi = wave_minmax<false>(x);
+               if (lane == 63) { part[2 * k] = lo; part[2 * k + 1] = hi; }
+            }
+            __syncthreads();
+            if (tid < NB && e0 + tid < a.e_end)
+            {
+               double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+               for (int c = 0; c < CH; c++)
+               {
+                  lo = fmin(lo, part[2 * (tid * CH + c)]);
+                  hi = fmax(hi, part[2 * (tid * CH + c) + 1]);
+               }
+               a.xe_min_out[e0 + tid] = lo;
+               a.xe_max_out[e0 + tid] = hi;
+            }
+         }
+         else if (tid < NB && e0 + tid < a.e_end)
          {
             double lo = INFINITY, hi = -INFINITY;
             for (int i = 0; i < D3; i++)
