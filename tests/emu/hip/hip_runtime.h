@@ -38,6 +38,7 @@ namespace hipemu
 {
 inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 inline std::barrier<> *g_barrier = nullptr;
+inline std::barrier<> *g_wave_barrier[16] = {nullptr}; // one per wavefront: cross-lane operations only meet their own 64 lanes
 inline unsigned long long g_xchg[1024];
 } // namespace hipemu
 
@@ -47,15 +48,16 @@ inline unsigned long long g_xchg[1024];
 #define gridDim (hipemu::t_gridDim)
 
 inline void __syncthreads() { hipemu::g_barrier->arrive_and_wait(); }
+inline void hipemu_wave_sync() { hipemu::g_wave_barrier[hipemu::t_threadIdx.x >> 6]->arrive_and_wait(); }
 
 inline double __shfl_xor(double v, int off)
 {
    const unsigned t = threadIdx.x;
    std::memcpy(&hipemu::g_xchg[t], &v, 8);
-   __syncthreads();
+   hipemu_wave_sync();
    double r;
    std::memcpy(&r, &hipemu::g_xchg[t ^ (unsigned)off], 8);
-   __syncthreads();
+   hipemu_wave_sync();
    return r;
 }
 
@@ -74,7 +76,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 {
    const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane;
    hipemu::g_xchg[t] = (unsigned)src;
-   __syncthreads();
+   hipemu_wave_sync();
    const unsigned row = lane >> 4, inrow = lane & 15u;
    int srclane = -1;
    if (ctrl >= 0 && ctrl <= 0xFF) { srclane = (int)((lane & ~3u) + ((ctrl >> (2 * (lane & 3u))) & 3)); } // quad_perm
@@ -84,7 +86,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
    else if (ctrl == 0x143) { srclane = (row >= 2) ? 31 : -1; }                                            // row_bcast:31
    int r = old;
    if (((row_mask >> row) & 1) && srclane >= 0) { r = (int)hipemu::g_xchg[base + srclane]; }
-   __syncthreads();
+   hipemu_wave_sync();
    return r;
 }
 
@@ -141,6 +143,12 @@ inline void hipemu_launch(K kernel, dim3 grid, dim3 block, Args... args)
 {
    std::barrier<> bar(block.x);
    hipemu::g_barrier = &bar;
+   std::vector<std::unique_ptr<std::barrier<>>> wbar;
+   for (unsigned w = 0; w * 64 < block.x; w++)
+   {
+      wbar.emplace_back(new std::barrier<>(std::min(64u, block.x - w * 64)));
+      hipemu::g_wave_barrier[w] = wbar.back().get();
+   }
    std::vector<std::thread> pool;
    for (unsigned t = 0; t < block.x; t++)
    {

@@ -105,7 +105,7 @@ def test_generic_orders_multi_block_race_free(lib, p):
     r.stage(u, 0.3, cfg.dt, keep)
     ctx.setup(0.3)
     outs = []
-    for _ in range(3):
+    for _ in range(2):
         dh, y, du = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
         ctx.ho_apply(u, dh)
         ctx.stage_fused(u, cfg.dt, y, du=du)
