@@ -229,6 +229,11 @@ public:
    }
    void MultUnlimited(const Vector &x, Vector &y) const override;
    void LimitMult(const Vector &x, Vector &y) const override;
+   // -dtc 1 (remhos.cpp:166-186, 1968-1998): the running minimum lives on the device (rmh_set_dt_control);
+   // the fused limiter folds it in by itself, the granular sequence calls UpdateTimeStepEstimate
+   void UpdateTimeStepEstimate(const Vector &x, const Vector &dx, const Vector &x_min, const Vector &x_max) const;
+   void ResetTimeStepRatio() const;
+   real_t GetTimeStepRatio() const;
    TimingData &Timer() const { return timer; }
 };
 

@@ -171,9 +171,31 @@ int rmh_stage_fused(rmh_ctx *ctx, const double *u, double dt, const double *x_ba
 int rmh_stage_fused_range(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
                           double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish);
 
+/* rmh_stage_fused keeps the element extrema of y_out and reuses them when the next call's input IS that vector
+ * (same pointer).  A caller that changes the contents of that vector in between (e.g. restores a saved state
+ * when a step is repeated, remhos.cpp:1181-1193) must announce it here; the next stage then recomputes them. */
+int rmh_invalidate_extrema(rmh_ctx *ctx);
+
 /* Which LOSolver rmh_stage_fused runs inside the stage kernel: 5 = MassBasedAvg (default), 4 =
  * PAResidualDistributionSubcell (-lo, remhos.cpp:268-276); lo 4 needs rmh_layout.subcell_vel. */
 int rmh_set_lo_type(rmh_ctx *ctx, int lo_type);
+
+/* DofInfo bounds type (-bt, remhos.cpp:289; DofInfo::ComputeBounds, remhos_tools.hpp:168-182) used by rmh_bounds,
+ * rmh_limit_fused, rmh_limit_fused_lo and rmh_stage_fused: 0 = overlap bounds (default), 1 = the element and its
+ * face neighbours, one interval per element (ComputeMatrixSparsityBounds, remhos_tools.cpp:381-430). */
+int rmh_set_bounds_type(rmh_ctx *ctx, int bounds_type);
+
+/* Time step control -dtc 1 (TimeStepControl::LOBoundsError; requires bounds type 1, remhos.cpp:617-620).
+ * While on, every limiter pass (rmh_limit_fused, rmh_limit_fused_lo, rmh_stage_fused) also folds
+ * AdvectionOperator::UpdateTimeStepEstimate(u, du_LO, u_min, u_max) (remhos.cpp:1968-1998, called at :1839-1842)
+ * into a device scalar: the largest dt with u_min <= u + dt * du_LO <= u_max over all dofs seen since
+ * rmh_dt_estimate_reset (AdvectionOperator::SetDt resets it before each step, remhos.cpp:176-182).
+ * rmh_dt_estimate_update does the same for the granular call sequence; rmh_dt_estimate_get synchronises and
+ * returns the rank-local minimum (the caller min-reduces over ranks, as remhos.cpp:1993 does). */
+int rmh_set_dt_control(rmh_ctx *ctx, int on);
+int rmh_dt_estimate_reset(rmh_ctx *ctx);
+int rmh_dt_estimate_update(rmh_ctx *ctx, const double *x, const double *dx, const double *x_min, const double *x_max);
+int rmh_dt_estimate_get(rmh_ctx *ctx, double *dt);
 
 /* Stopwatch buckets of TimingData (remhos_tools.hpp:52-64; printed by
  * AdvectionOperator::PrintTimingData, remhos.cpp:1918-1966): seconds in

@@ -28,6 +28,8 @@ typedef struct {
    int fused;         /* 1: LimitMult through rmh_limit_fused, 0: the reference's call sequence */
    int px, py, pz;    /* box partition of the element lattice                                 */
    int rank;          /* which block this process owns                                        */
+   int bounds_type;   /* -bt : 0 overlap bounds, 1 face-neighbour bounds                        */
+   int dt_control;    /* -dtc: 0 fixed dt, 1 LOBoundsError (needs -bt 1; remhos.cpp:1178-1197)  */
 } rmhd_config;
 
 typedef struct {
@@ -68,6 +70,7 @@ typedef struct {
    double fom_rhs, fom_inv, fom_lo, fom_fct, fom; /* remhos.cpp:1947-1951 (fom omits INV) */
    double wall, fom_wall;                     /* whole stage loop, everything included    */
    int cg_iters_max;
+   int repeats;                               /* steps repeated by the dt control         */
 } rmhd_result;
 
 /* remhos() on one GPU (px = py = pz = 1): setup, RK3-SSP loop, report.  0 on success. */

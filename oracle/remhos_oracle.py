@@ -509,7 +509,9 @@ class Config:
     max_steps: int = -1
     ho: int = 3  # 3: local inverse
     lo: int = 4  # 4: subcell RD, 5: mass-based average
-    fct: int = 2  # 2: clip+scale
+    fct: int = 2  # 2: clip+scale, 4: element FCT projection (only to pin -bt 1 -dtc 1 with the reference's KATs)
+    bounds_type: int = 0  # -bt: 0 overlap of the CG-node patches, 1 face-neighbour elements (remhos_tools.hpp:168-182)
+    dt_control: int = 0  # -dtc: 0 fixed step, 1 LOBoundsError (remhos.cpp:1968-1998, 1178-1197)
     ho_solve: str = "exact"  # 'exact' (remhos_ho.cpp:90-118) or 'cg' (DGMassInverse semantics)
 
 
@@ -834,6 +836,15 @@ class Remhos:
         xe_max = u.max(-1)
         p = T.p
         dim = self.dim
+        if self.cfg.bounds_type == 1:
+            # ComputeMatrixSparsityBounds (remhos_tools.cpp:381-430): the element and its face neighbours,
+            # one interval per element
+            lo, hi = xe_min.copy(), xe_max.copy()
+            for f in range(self.nbr.shape[1]):
+                nb = self.nbr[:, f]
+                lo = np.minimum(lo, np.where(nb >= 0, xe_min[np.maximum(nb, 0)], INF))
+                hi = np.maximum(hi, np.where(nb >= 0, xe_max[np.maximum(nb, 0)], -INF))
+            return np.repeat(lo[:, None], T.ndof, 1), np.repeat(hi[:, None], T.ndof, 1)
         umin = np.full_like(u, INF)
         umax = np.full_like(u, -INF)
         import itertools
@@ -872,6 +883,51 @@ class Remhos:
         f = np.where((new_mass < -eps)[:, None], f2, f)
         return du_lo + f / m
 
+    @staticmethod
+    def element_fct_projection(u, M, du_ho, du_lo, umin, umax, dt):
+        """ElementFCTProjection::CalcFCTSolution (remhos_fct.cpp:613-735): Zalesak-type limiting of the
+        element's antidiffusive fluxes F_ij.  Test infrastructure only: the reference's -bt 1 -dtc 1 known
+        answers (autotest/out_baseline.dat:203-210) use this FCT solver."""
+        ne, s = u.shape
+        du = du_lo.copy()
+        dmax = (umax - u) / dt
+        dmin = (umin - u) / dt
+        il, jl = np.tril_indices(s, -1)  # i > j, row-major order of the reference's double loop
+        for k in range(ne):
+            Mk = M[k]
+            ML = Mk.sum(1)
+            rhs = Mk @ du_ho[k]
+            beta = ML / ML.sum()
+            z = rhs - ML * du_lo[k]
+            F = Mk[il, jl] * (du_ho[k][il] - du_ho[k][jl]) + (beta[jl] * z[il] - beta[il] * z[jl])
+            gp = np.zeros(s)
+            gm = np.zeros(s)
+            pos = F >= 0.0
+            np.add.at(gp, il[pos], F[pos])
+            np.add.at(gm, jl[pos], -F[pos])
+            np.add.at(gm, il[~pos], F[~pos])
+            np.add.at(gp, jl[~pos], -F[~pos])
+            rp = np.maximum(ML * (dmax[k] - du[k]), 0.0)
+            rm = np.minimum(ML * (dmin[k] - du[k]), 0.0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                gp = np.where(rp < gp, rp / gp, 1.0)
+                gm = np.where(rm > gm, rm / gm, 1.0)
+            a = np.where(pos, np.minimum(gp[il], gm[jl]), np.minimum(gm[il], gp[jl]))
+            Fa = F * a
+            # the reference adds the limited fluxes one by one; the order only matters at round-off
+            np.add.at(du[k], il, Fa / ML[il])
+            np.add.at(du[k], jl, -Fa / ML[jl])
+        return du
+
+    def update_dt_estimate(self, x, dx, xmin, xmax):
+        """AdvectionOperator::UpdateTimeStepEstimate (remhos.cpp:1968-1998)."""
+        eps = 1e-12
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = np.where(dx > eps, (xmax - x) / dx, np.where(dx < -eps, (xmin - x) / dx, INF))
+        dt = float(c.min())
+        self.dt_est = min(self.dt_est, dt)
+        self.dt_ratio = min(self.dt_ratio, dt / self.cur_dt if self.cur_dt != 0.0 else 0.0)
+
     # ---- the stage = AdvectionOperator::Mult ---------------------------------------------
     def stage(self, u, t, dt, keep=None):
         """MultUnlimited + LimitMult (remhos.cpp:1596-1916).  dt is the full step."""
@@ -886,7 +942,12 @@ class Remhos:
         else:
             du_lo = self.calc_lo_rd(u)
         umin, umax = self.compute_bounds(u)
-        du = self.clip_scale(u, self.m, du_ho, du_lo, umin, umax, dt)
+        if cfg.fct == 4:
+            du = self.element_fct_projection(u, self.mass_matrices(), du_ho, du_lo, umin, umax, dt)
+        else:
+            du = self.clip_scale(u, self.m, du_ho, du_lo, umin, umax, dt)
+        if cfg.dt_control == 1:
+            self.update_dt_estimate(u, du_lo, umin, umax)  # remhos.cpp:1839-1842
         if keep is not None:
             keep.update(du_ho=du_ho, du_lo=du_lo, umin=umin, umax=umax, du=du, m=self.m.copy(), rhs=self.last_rhs)
         return du
@@ -911,10 +972,26 @@ class Remhos:
         t_final = 1.0 if self.exec_mode == 1 else cfg.t_final
         ti = 0
         done = False
+        self.repeats = 0
         while not done:
             dt_real = min(self.dt, t_final - self.t)
+            self.cur_dt = self.dt_est = dt_real  # AdvectionOperator::SetDt, remhos.cpp:176-182
+            self.dt_ratio = INF                  # ResetTimeStepRatio
+            u_old, t_old = self.u, self.t
             self.step(dt_real)
             ti += 1
+            if cfg.dt_control != 0:
+                # remhos.cpp:1178-1197
+                if self.dt_ratio < 1.0:
+                    ti -= 1
+                    self.u, self.t = u_old, t_old
+                    self.dt = 0.85 * self.dt
+                    self.repeats += 1
+                    if self.dt < 1e-12:
+                        raise RuntimeError("The time step crashed!")
+                    continue
+                if self.dt_ratio > 1.25:
+                    self.dt *= 1.02
             done = self.t >= t_final - 1e-8 * self.dt
             if ti == cfg.max_steps:
                 done = True

@@ -18,7 +18,8 @@ SYMBOLS = [
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range",
     "rmh_halo_pack_records", "rmh_set_ghost_records", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
-    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_set_lo_type",
+    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
+    "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
 ]
 
 
@@ -83,6 +84,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_last_cg_iters.argtypes = [p, C.POINTER(i)]
     lib.rmh_set_mass_tol.argtypes = [p, d, d, i]
     lib.rmh_set_lo_type.argtypes = [p, i]
+    lib.rmh_set_bounds_type.argtypes = [p, i]
+    lib.rmh_invalidate_extrema.argtypes = [p]
+    lib.rmh_set_dt_control.argtypes = [p, i]
+    lib.rmh_dt_estimate_reset.argtypes = [p]
+    lib.rmh_dt_estimate_update.argtypes = [p, p, p, p, p]
+    lib.rmh_dt_estimate_get.argtypes = [p, C.POINTER(d)]
     return lib
 
 
@@ -232,6 +239,26 @@ class Context:
 
     def set_lo_type(self, lo_type):
         self._check(self.lib.rmh_set_lo_type(self.h, int(lo_type)))
+
+    def invalidate_extrema(self):
+        self._check(self.lib.rmh_invalidate_extrema(self.h))
+
+    def set_bounds_type(self, bt):
+        self._check(self.lib.rmh_set_bounds_type(self.h, int(bt)))
+
+    def set_dt_control(self, on=True):
+        self._check(self.lib.rmh_set_dt_control(self.h, 1 if on else 0))
+
+    def dt_estimate_reset(self):
+        self._check(self.lib.rmh_dt_estimate_reset(self.h))
+
+    def dt_estimate_update(self, x, dx, x_min, x_max):
+        self._check(self.lib.rmh_dt_estimate_update(self.h, _ptr(x), _ptr(dx), _ptr(x_min), _ptr(x_max)))
+
+    def dt_estimate_get(self):
+        v = C.c_double()
+        self._check(self.lib.rmh_dt_estimate_get(self.h, C.byref(v)))
+        return v.value
 
     def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
         self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))

@@ -55,6 +55,9 @@ struct rmh_ctx
    double rel_tol = 1e-14, abs_tol = 0.0;
    int max_iter = 100;
    bool ho_done = false;
+   int bounds_type = 0; // DofInfo bounds type (-bt): 0 overlap, 1 face neighbours
+   double *d_dt_est = nullptr; // running minimum of UpdateTimeStepEstimate; null while dt control is off
+   bool dt_control = false;
    int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
    int ho_variant = 2; // 2: batched kernel (rmh_ho2.hpp), 1: one element per workgroup (rmh_kernels.hpp)
    // stopwatches (TimingData, remhos_tools.hpp:52-64)
@@ -154,6 +157,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.ne_owned = c->ne;
    a.e_begin = 0;
    a.e_end = c->ne;
+   a.bounds_type = 0;
+   a.dt_est = nullptr;
    a.t = t;
    a.move = c->exec_mode == 1;
    a.alpha = c->exec_mode == 1 ? 1.0 : -1.0;
@@ -232,6 +237,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.y_out = y_out;
    a.xe_min_out = c->d_xe_min2;
    a.xe_max_out = c->d_xe_max2;
+   a.bounds_type = c->bounds_type;
+   a.dt_est = c->dt_control ? c->d_dt_est : nullptr;
    if (c->lo_type == 4)
    {
       constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
@@ -337,7 +344,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
 void rmh_destroy(rmh_ctx *c)
 {
    if (!c) { return; }
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {
@@ -456,7 +463,7 @@ int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u
    if (!c || !xe_min || !xe_max || !u_min || !u_max) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
-                                      (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
+                                      c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
                                       u_max));
    RMH_HIP(hipGetLastError());
    return RMH_OK;
@@ -495,6 +502,8 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    la.gh_min = c->gh_min;
    la.gh_max = c->gh_max;
    la.gh_mstride = c->gh_mstride;
+   la.bounds_type = c->bounds_type;
+   la.dt_est = c->dt_control ? c->d_dt_est : nullptr;
    la.ne_owned = c->ne;
    la.dt = dt;
    la.du = du;
@@ -630,6 +639,62 @@ int rmh_set_lo_type(rmh_ctx *c, int lo_type)
    if (!c || (lo_type != 4 && lo_type != 5)) { return fail(RMH_ERR_INVALID, "lo_type must be 4 or 5"); }
    if (lo_type == 4 && (c->p < 2 || !c->d_subvel)) { return fail(RMH_ERR_STATE, "lo 4 needs order >= 2 and rmh_layout.subcell_vel"); }
    c->lo_type = lo_type;
+   return RMH_OK;
+}
+
+int rmh_invalidate_extrema(rmh_ctx *c)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   c->xe_of = nullptr;
+   return RMH_OK;
+}
+
+int rmh_set_bounds_type(rmh_ctx *c, int bounds_type)
+{
+   if (!c || (bounds_type != 0 && bounds_type != 1)) { return fail(RMH_ERR_INVALID, "Wrong option for bounds computation."); }
+   c->bounds_type = bounds_type;
+   return RMH_OK;
+}
+
+namespace
+{
+__global__ void set_scalar_kernel(double *p, double v) { *p = v; }
+} // namespace
+
+int rmh_dt_estimate_reset(rmh_ctx *c)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   if (!c->d_dt_est) { RMH_HIP(hipMalloc((void **)&c->d_dt_est, sizeof(double))); }
+   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_dt_est, (double)INFINITY);
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_set_dt_control(rmh_ctx *c, int on)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   if (on && c->bounds_type != 1) { return fail(RMH_ERR_STATE, "Error: -dtc 1 requires -bt 1."); }
+   c->dt_control = on != 0;
+   return on ? rmh_dt_estimate_reset(c) : RMH_OK;
+}
+
+int rmh_dt_estimate_update(rmh_ctx *c, const double *x, const double *dx, const double *x_min, const double *x_max)
+{
+   if (!c || !x || !dx || !x_min || !x_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (!c->dt_control) { return RMH_OK; } // TimeStepControl::FixedTimeStep: nothing to do (remhos.cpp:1973)
+   const size_t n = (size_t)c->ne * c->ndof;
+   const int nblk = (int)std::min<size_t>((n + 255) / 256, 4096);
+   hipLaunchKernelGGL((dt_estimate_kernel<0>), dim3(nblk), dim3(256), 0, c->stream, x, dx, x_min, x_max, n, c->d_dt_est);
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_dt_estimate_get(rmh_ctx *c, double *dt)
+{
+   if (!c || !dt) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (!c->d_dt_est) { return fail(RMH_ERR_STATE, "dt control is off"); }
+   RMH_HIP(hipStreamSynchronize(c->stream));
+   RMH_HIP(hipMemcpy(dt, c->d_dt_est, sizeof(double), hipMemcpyDeviceToHost));
    return RMH_OK;
 }
 

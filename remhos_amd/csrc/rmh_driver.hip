@@ -194,6 +194,20 @@ void AdvectionOperator::LimitMult(const Vector &X, Vector &Y) const
    dofs.ComputeElementsMinMax(u, dofs.xe_min, dofs.xe_max);
    dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
    fct_solver->CalcFCTSolution(u, lumpedM, du_HO, du_LO, dofs.xi_min, dofs.xi_max, d_u);
+   UpdateTimeStepEstimate(u, du_LO, dofs.xi_min, dofs.xi_max); // remhos.cpp:1839-1842 (no-op with a fixed dt)
+}
+
+void AdvectionOperator::UpdateTimeStepEstimate(const Vector &x, const Vector &dx, const Vector &x_min,
+                                               const Vector &x_max) const
+{
+   RMH_CALL(rmh_dt_estimate_update(pfes.Ctx(), x.Read(), dx.Read(), x_min.Read(), x_max.Read()));
+}
+void AdvectionOperator::ResetTimeStepRatio() const { RMH_CALL(rmh_dt_estimate_reset(pfes.Ctx())); }
+real_t AdvectionOperator::GetTimeStepRatio() const
+{
+   double est = 0.0;
+   RMH_CALL(rmh_dt_estimate_get(pfes.Ctx(), &est));
+   return (dt != 0.) ? est / dt : 0.; // remhos.cpp:1997
 }
 
 // ---- RK3 SSP [MFEM RK3SSPSolver::Step] -------------------------------------------------------------
@@ -256,6 +270,13 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
    rmh_ctx *ctx = nullptr;
    if (rmh_create(&L, &ctx) != 0) { g_driver_error = rmh_last_error(); return -1; }
    rmh_enable_timers(ctx, 1);
+   if (rmh_set_bounds_type(ctx, cfg->bounds_type) != 0 || (cfg->dt_control && rmh_set_dt_control(ctx, 1) != 0))
+   {
+      g_driver_error = rmh_last_error();
+      rmh_destroy(ctx);
+      return -1;
+   }
+   const bool dtc = cfg->dt_control != 0;
 
    const int vsize = cd.ne_owned * cd.ndof;
    int rc = 0;
@@ -292,10 +313,18 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       HIP_CALL(hipDeviceSynchronize());
       const auto w0 = std::chrono::steady_clock::now();
       Vector y1(fused ? vsize : 0), y2(fused ? vsize : 0);
+      Vector Sold(dtc ? vsize : 0);
+      int repeats = 0;
       while (!done)
       {
          double dt_real = std::min(dt, t_final - t);
+         // This also resets the time step estimate when automatic dt is on (remhos.cpp:1150-1152)
          adv.SetDt(dt_real);
+         if (dtc)
+         {
+            adv.ResetTimeStepRatio();
+            Sold = u;
+         }
          if (fused)
          {
             // one kernel per RK stage (rmh_stage_fused): same stage times and combinations as
@@ -310,6 +339,24 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
          }
          else { ode_solver.Step(u, t, dt_real); }
          ti++;
+         if (dtc)
+         {
+            // remhos.cpp:1178-1197
+            const double dt_ratio = adv.GetTimeStepRatio();
+            if (dt_ratio < 1.)
+            {
+               // Repeat with the proper time step.
+               ti--;
+               t -= dt_real;
+               u = Sold;
+               RMH_CALL(rmh_invalidate_extrema(ctx)); // the fused stage cached the extrema of the rejected state
+               dt = 0.85 * dt;
+               repeats++;
+               RMH_VERIFY(dt >= 1e-12, "The time step crashed!");
+               continue;
+            }
+            else if (dt_ratio > 1.25) { dt *= 1.02; }
+         }
          done = (t >= t_final - 1.e-8 * dt);
          if (ti == cc.max_steps) { done = true; }
       }
@@ -356,6 +403,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       int it = 0;
       rmh_last_cg_iters(ctx, &it);
       res->cg_iters_max = it;
+      res->repeats = repeats;
       delete fct_solver;
       delete lo_solver;
       delete ho_solver;

@@ -135,6 +135,23 @@ __device__ inline double wave_sum(double v)
    return v;
 }
 
+// A fresh view of the constant table of order P.  Entries read through one view cannot be merged with (or
+// hoisted next to) reads through another.  At p >= 5 the compiler otherwise keeps every table entry of the
+// kernel live in scalar registers from its first use to its last and spills them to VGPR lanes (p = 6: more
+// v_readlane than FMA instructions); views are taken per unrolled quadrature plane.  At p <= 4 the table fits
+// the scalar registers and re-loading costs more than the few spills (measured: p = 3 -8 %), so the view is
+// the table itself.
+template <int P>
+__device__ inline const double *tab_view()
+{
+   int z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+   if (P >= 5) { asm volatile("" : "+s"(z)); }
+#endif
+   return c_tab[P] + z;
+}
+#define RMH_TAB() tab_view<P>()
+
 // Sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r] (the
 // element total, broadcast back to the dof threads).  ONE barrier per call: results go through a
 // ring of three LDS buffers (s_acc3[3][NB]); the buffer of the call before the previous one is
@@ -421,6 +438,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
       for (int q = 0; q < Q; q++)
       {
+         const double *gt = RMH_TAB();
          double ub = 0.0, ug = 0.0;
 #pragma unroll
          for (int ix = 0; ix < D; ix++)
@@ -503,6 +521,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
       for (int q2 = 0; q2 < Q; q2++)
       {
+         const double *gt = RMH_TAB();
          double t1[3], t2[3], vf[3];
 #pragma unroll
          for (int comp = 0; comp < 3; comp++)
@@ -703,6 +722,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
+            const double *gt = RMH_TAB();
             double J[3][3], v[3];
 #pragma unroll
             for (int comp = 0; comp < 3; comp++)
@@ -759,6 +779,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
+         const double *gt = RMH_TAB();
          double gx = 0, gy = 0, gz = 0;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
@@ -814,6 +835,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
+            const double *gt = RMH_TAB();
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
@@ -1109,6 +1131,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
          for (int q = 0; q < Q; q++)
          {
+            const double *gt = RMH_TAB();
             double acc = 0.0;
 #pragma unroll
             for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
@@ -1135,6 +1158,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
+            const double *gt = RMH_TAB();
             double acc = 0.0;
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
@@ -1161,6 +1185,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
+            const double *gt = RMH_TAB();
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
@@ -1303,6 +1328,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       batch_dot<C>(tmp, mass, lds, s_acc, ring);
       batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
       double fcl[DR], pos[DR], neg[DR];
+      double dtc = INFINITY; // UpdateTimeStepEstimate(u, du_LO, u_min, u_max), remhos.cpp:1839-1842
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -1312,9 +1338,10 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          {
             const int eb = t / D3, i = t % D3;
             double lo, hi;
-            dof_bounds<P>(i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
+            dof_bounds_bt<P>(a.bounds_type, i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
             const double ubar = mass[r] / vol[r];
             if (!BOTH) { dlo[r] = (ubar - uu[r]) / a.dt; } // MassBasedAvg; with RD dlo is already there
+            dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi));
             const double u_new_lo = uu[r] + a.dt * dlo[r];
             const double f_clip_min = mm[r] / a.dt * (lo - u_new_lo);
             const double f_clip_max = mm[r] / a.dt * (hi - u_new_lo);
@@ -1324,6 +1351,11 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             neg[r] = fmin(fc, 0.0);
             pos[r] = fmax(fc, 0.0);
          }
+      }
+      if (a.dt_est)
+      {
+         dtc = wave_minmax<true>(dtc);
+         if ((tid & 63) == 63) { atomic_min_nonneg(a.dt_est, dtc); }
       }
       double sumPos[DR], sumNeg[DR];
       batch_dot<C>(pos, sumPos, lds, s_acc, ring);

@@ -68,6 +68,8 @@ struct HoArgs
    double rk_a, rk_b, dt_rk;
    double *y_out;
    double *xe_min_out, *xe_max_out; // extrema of y_out (input extrema of the next stage)
+   int bounds_type;                 // 0 overlap bounds, 1 face-neighbour bounds
+   double *dt_est;                  // null, or the running minimum of UpdateTimeStepEstimate
 };
 
 // ---------------------------------------------------------------------------------------
@@ -870,6 +872,44 @@ __device__ inline void dof_bounds(int i, const double *smin, const double *smax,
    }
 }
 
+// DofInfo::ComputeBounds (remhos_tools.hpp:168-182): bounds type 0 = overlap bounds above, 1 = the element
+// and its face neighbours (ComputeMatrixSparsityBounds, remhos_tools.cpp:381-430), one interval per element
+template <int P>
+__device__ inline void dof_bounds_bt(int bt, int i, const double *smin, const double *smax, double &lo, double &hi)
+{
+   if (bt == 0) { dof_bounds<P>(i, smin, smax, lo, hi); return; }
+   constexpr int fs[7] = {13, 12, 14, 10, 16, 4, 22};
+   lo = INFINITY;
+   hi = -INFINITY;
+#pragma unroll
+   for (int k = 0; k < 7; k++)
+   {
+      lo = fmin(lo, smin[fs[k]]);
+      hi = fmax(hi, smax[fs[k]]);
+   }
+}
+
+// AdvectionOperator::UpdateTimeStepEstimate (remhos.cpp:1968-1998) for one dof: the largest dt with
+// x_min <= x + dt*dx <= x_max (+inf when |dx| <= 1e-12)
+__device__ inline double dt_candidate(double x, double dx, double xmin, double xmax)
+{
+   constexpr double eps = 1e-12;
+   double c = INFINITY;
+   if (dx > eps) { c = (xmax - x) / dx; }
+   else if (dx < -eps) { c = (xmin - x) / dx; }
+   return c + 0.0; // -0.0 -> +0.0: the minimum below orders the bit patterns
+}
+
+// min into a device scalar that only ever decreases; candidates are >= 0, whose bit patterns order like
+// the values.  Guarded like the PCG iteration counter: the atomic is issued only when it can lower the value.
+__device__ inline void atomic_min_nonneg(double *p, double v)
+{
+   if (v < __builtin_nontemporal_load(p))
+   {
+      atomicMin((unsigned long long *)p, (unsigned long long)__double_as_longlong(v));
+   }
+}
+
 __device__ inline void load_stencil(int e, int ne_owned, const int *stencil27, const double *xe_min,
                                     const double *xe_max, const double *gh_min, const double *gh_max, int gh_mstride,
                                     double *smin, double *smax)
@@ -891,7 +931,7 @@ __device__ inline void load_stencil(int e, int ne_owned, const int *stencil27, c
 
 // DofInfo::ComputeBounds -> ComputeOverlapBounds (remhos_tools.cpp:432-495)
 template <int P>
-__global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(const int *stencil27, int ne_owned, const double *xe_min,
+__global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(int bt, const int *stencil27, int ne_owned, const double *xe_min,
                                                              const double *xe_max, const double *gh_min,
                                                              const double *gh_max, int gh_mstride, double *u_min, double *u_max)
 {
@@ -903,7 +943,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(const int *stencil2
    for (int i = threadIdx.x; i < C::D3; i += C::NT)
    {
       double lo, hi;
-      dof_bounds<P>(i, smin, smax, lo, hi);
+      dof_bounds_bt<P>(bt, i, smin, smax, lo, hi);
       u_min[(size_t)e * C::D3 + i] = lo;
       u_max[(size_t)e * C::D3 + i] = hi;
    }
@@ -1078,7 +1118,24 @@ struct LimitArgs
    const double *x_base; // RK: y_out = a*x_base + b*(u + dt_rk*du)
    double a, b, dt_rk;
    double *y_out;       // may be null
+   int bounds_type;     // 0 overlap, 1 face neighbours
+   double *dt_est;      // null, or the running minimum of UpdateTimeStepEstimate(u, du_LO, u_min, u_max)
 };
+
+// UpdateTimeStepEstimate for the granular call sequence: min over the dofs into *dt_est
+template <int P>
+__global__ void __launch_bounds__(256) dt_estimate_kernel(const double *x, const double *dx, const double *xmin,
+                                                          const double *xmax, size_t n, double *dt_est)
+{
+   __shared__ double s_red[4];
+   double c = INFINITY;
+   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+   {
+      c = fmin(c, dt_candidate(x[i], dx[i], xmin[i], xmax[i]));
+   }
+   c = block_min<4>(c, s_red);
+   if (threadIdx.x == 0) { atomic_min_nonneg(dt_est, c); }
+}
 
 template <int P>
 __global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
@@ -1111,7 +1168,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
    vol = block_sum<C::NW>(vol, s_red);
    const double ubar = mass / vol;
    double f[C::DPT], dl[C::DPT];
-   double sumPos = 0.0, sumNeg = 0.0;
+   double sumPos = 0.0, sumNeg = 0.0, dtc = INFINITY;
 #pragma unroll
    for (int k = 0; k < C::DPT; k++)
    {
@@ -1120,8 +1177,9 @@ __global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
       if (i < C::D3)
       {
          double lo, hi;
-         dof_bounds<P>(i, smin, smax, lo, hi);
+         dof_bounds_bt<P>(a.bounds_type, i, smin, smax, lo, hi);
          dl[k] = a.du_lo ? a.du_lo[(size_t)e * C::D3 + i] : (ubar - uu[k]) / a.dt;
+         dtc = fmin(dtc, dt_candidate(uu[k], dl[k], lo, hi));
          const double u_new_lo = uu[k] + a.dt * dl[k];
          const double f_clip_min = mm[k] / a.dt * (lo - u_new_lo);
          const double f_clip_max = mm[k] / a.dt * (hi - u_new_lo);
@@ -1134,6 +1192,11 @@ __global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
    }
    sumNeg = block_sum<C::NW>(sumNeg, s_red);
    sumPos = block_sum<C::NW>(sumPos, s_red);
+   if (a.dt_est)
+   {
+      dtc = block_min<C::NW>(dtc, s_red);
+      if (threadIdx.x == 0) { atomic_min_nonneg(a.dt_est, dtc); }
+   }
    const double new_mass = sumNeg + sumPos;
 #pragma unroll
    for (int k = 0; k < C::DPT; k++)

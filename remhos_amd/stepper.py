@@ -33,6 +33,12 @@ class Stepper:
             self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         if self.lo == 4:
             self.ctx.set_lo_type(4)
+        self.dtc = bool(getattr(case.cfg, "dt_control", 0))
+        if getattr(case.cfg, "bounds_type", 0):
+            self.ctx.set_bounds_type(case.cfg.bounds_type)
+        if self.dtc:
+            self.ctx.set_dt_control(True)
+        self.repeats = 0
         ne, nd, ng = case.ne_owned, case.ndof, case.ne_ghost
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.x = torch.from_numpy(case.u0).to(self.dev).contiguous()
@@ -123,6 +129,7 @@ class Stepper:
         c.bounds(self.xe_min, self.xe_max, self.umin, self.umax)
         du = torch.empty_like(u)
         c.fct_clipscale(u, m, self.k, self.du_lo, self.umin, self.umax, dt, du)
+        c.dt_estimate_update(u, self.du_lo, self.umin, self.umax)  # remhos.cpp:1839-1842 (no-op with a fixed dt)
         y = u + dt * du
         if x_base is None:
             out.copy_(b * y)
@@ -152,8 +159,35 @@ class Stepper:
         ti, done = 0, False
         while not done:
             dt_real = min(self.dt, t_final - self.t)
+            if self.dtc:
+                # AdvectionOperator::SetDt + ResetTimeStepRatio (remhos.cpp:1150-1152); Sold = S (:1171)
+                self.ctx.dt_estimate_reset()
+                if not hasattr(self, "x_old"):
+                    self.x_old = torch.empty_like(self.x)
+                self.x_old.copy_(self.x)
+                t_old = self.t
             self.step(dt_real)
             ti += 1
+            if self.dtc:
+                est = self.ctx.dt_estimate_get()
+                if self.dist is not None:
+                    red = torch.tensor([est], dtype=torch.float64, device=self.dev)
+                    self.dist.all_reduce(red, op=self.dist.ReduceOp.MIN)  # MPI_Allreduce MIN, remhos.cpp:1993
+                    est = float(red[0])
+                ratio = est / dt_real if dt_real != 0.0 else 0.0
+                if ratio < 1.0:
+                    # repeat with the proper time step (remhos.cpp:1181-1193)
+                    ti -= 1
+                    self.t = t_old
+                    self.x.copy_(self.x_old)
+                    self.ctx.invalidate_extrema()
+                    self.dt = 0.85 * self.dt
+                    self.repeats += 1
+                    if self.dt < 1e-12:
+                        raise RuntimeError("The time step crashed!")
+                    continue
+                if ratio > 1.25:
+                    self.dt *= 1.02
             done = self.t >= t_final - 1e-8 * self.dt
             if ti == max_steps:
                 done = True

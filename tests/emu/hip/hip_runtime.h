@@ -109,6 +109,15 @@ inline double atomicAdd(double *p, double v)
    return o;
 }
 
+inline long long __double_as_longlong(double v) { long long b; std::memcpy(&b, &v, 8); return b; }
+
+inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
+{
+   unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+   while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+   return old;
+}
+
 inline int atomicMax(int *p, int v)
 {
    int old = __atomic_load_n(p, __ATOMIC_RELAXED);

@@ -177,3 +177,35 @@ def test_two_blocks_manual_exchange_both_ghost_layouts(lib):
             assert np.array_equal(y, y_g[c.owned_gid])
             ctx.close()
     cg.close()
+
+
+def test_bounds_type_1_and_dt_control(lib):
+    """-bt 1 -dtc 1 (remhos.cpp:1178-1197, 1968-1998; remhos_tools.cpp:381-430) through the stepper and the C++
+    driver, fused and granular: same accepted steps, same repeated steps, same final dt and field as the oracle
+    (which is pinned for these options by autotest/out_baseline.dat:203-210).  lo 4: with the mass-based average
+    the LO update never leaves the bounds and the controller never repeats a step."""
+    from remhos_amd.case import Case, RmhdResult, make_config
+    from remhos_amd.stepper import Stepper
+
+    mesh, rs, p, prob, dt, tf = "periodic-cube", 0, 2, 0, 0.06, 0.12
+    r = Remhos(Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=dt, t_final=tf, lo=4, fct=2, bounds_type=1, dt_control=1))
+    out = r.run()
+    assert r.repeats == 3 and out["steps"] == 4
+    # (the GPU suite runs all four combinations on a longer case; here: driver granular, stepper fused)
+    cfg = make_config(mesh, rs, p, prob, dt, tf, lo_type=4, fused=0, bounds_type=1, dt_control=1)
+    res = RmhdResult()
+    assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0
+    assert (res.steps, res.repeats) == (out["steps"], r.repeats)
+    assert abs(res.dt - out["dt"]) < 1e-12 * out["dt"]
+    assert abs(res.final_mass - out["mass"]) < 1e-13 and abs(res.max_value - out["max"]) < 1e-12
+    cfg = make_config(mesh, rs, p, prob, dt, tf, lo_type=4, fused=1, bounds_type=1, dt_control=1)
+    st = Stepper(lib, Case(lib, cfg), device="cpu", fused=True)
+    steps = st.run()
+    assert (steps, st.repeats) == (out["steps"], r.repeats)
+    assert abs(st.dt - out["dt"]) < 1e-12 * out["dt"]
+    assert np.abs(st.x.numpy() - r.u).max() < 1e-12
+    st.close()
+    # -dtc 1 without -bt 1 is refused like remhos.cpp:617-620
+    res = RmhdResult()
+    assert lib.rmhd_run(C.byref(make_config(mesh, rs, p, prob, dt, tf, lo_type=4, dt_control=1)), C.byref(res)) != 0
+    assert b"requires -bt 1" in lib.rmhd_last_error()

@@ -31,6 +31,17 @@ AUTOTEST = [
 ]
 
 
+def test_bounds_type_1_and_dt_control():
+    """-bt 1 (face-neighbour bounds) and -dtc 1 (LO bounds-error time step control) are pinned through the two
+    reference runs that use them (autotest/out_baseline.dat:203-210; they run -fct 4, which the oracle
+    restates for this purpose only)."""
+    o = _run(mesh="periodic-square", rs=3, order=3, problem=5, dt=0.01, t_final=0.8, lo=5, fct=4, bounds_type=1, dt_control=1)
+    assert _r10(o["mass"]) == 0.1623263888 and _r10(o["max"]) == 0.2863317261
+    o = _run(mesh="inline-quad", rs=1, order=3, problem=14, dt=-1.0, t_final=0.75, lo=5, fct=4, bounds_type=1, dt_control=1)
+    assert _r10(o["mass"]) == 0.08479612805 and float(f"{o['mass_loss']:.6g}") == 6.61247e-07
+    assert o["dt"] > 0.03  # the controller grew the CFL step (1.02 per accepted step with ratio > 1.25)
+
+
 @pytest.mark.parametrize("name,kw,mass,umax", AUTOTEST, ids=[a[0] for a in AUTOTEST])
 def test_autotest_baseline(name, kw, mass, umax):
     out = _run(**kw)
