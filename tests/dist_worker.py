@@ -23,16 +23,21 @@ def main():
     from remhos_amd.stepper import Stepper
 
     lib = bind_driver(load_library(os.path.join(ROOT, "tests", "emu", "librmh_emu.so")))
-    case = Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5, part=part, rank=rank))
+    # optional: LO solver, bounds type / dt control, dt and t_final (RMH_TEST_OPTS="lo,bt,dtc,dt,tf")
+    lo, bt, dtc, dt, tf = 5, 0, 0, -1.0, 0.5
+    if os.environ.get("RMH_TEST_OPTS"):
+        a = os.environ["RMH_TEST_OPTS"].split(",")
+        lo, bt, dtc, dt, tf = int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4])
+    case = Case(lib, make_config(mesh, rs, p, prob, dt, tf, lo_type=lo, part=part, rank=rank, bounds_type=bt, dt_control=dtc))
     st = Stepper(lib, case, device="cpu", dist=dist, fused=True)
-    st.run(max_steps=steps)
+    nsteps = st.run(max_steps=steps)
     mass, umax = st.local_mass_and_max()
     red = torch.tensor([mass], dtype=torch.float64)
     dist.all_reduce(red, op=dist.ReduceOp.SUM)  # MPI_Allreduce of remhos.cpp:1412
     mx = torch.tensor([umax], dtype=torch.float64)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)  # remhos.cpp:1415
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gid=case.owned_gid, u=st.x.numpy(), mass=red.numpy(),
-             umax=mx.numpy())
+             umax=mx.numpy(), info=np.array([nsteps, st.repeats, st.dt]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -21,13 +21,13 @@ def _free_port():
     return port
 
 
-def _run(tmp_path, mesh, rs, p, prob, steps, part):
+def _run(tmp_path, mesh, rs, p, prob, steps, part, opts=""):
     world = part[0] * part[1] * part[2]
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", RMH_TEST_OPTS=opts)
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mesh, str(rs), str(p),
              str(prob), str(steps)] + [str(k) for k in part], env=env))
@@ -37,6 +37,7 @@ def _run(tmp_path, mesh, rs, p, prob, steps, part):
     gid = np.concatenate([d["gid"] for d in parts])
     u = np.concatenate([d["u"] for d in parts])
     order = np.argsort(gid)
+    _run.info = [tuple(d["info"]) for d in parts]
     return u[order], float(parts[0]["mass"][0]), float(parts[0]["umax"][0])
 
 
@@ -66,3 +67,21 @@ def test_rank_count_invariance(tmp_path, mesh, rs, p, prob, part):
     out = r.run()
     assert np.abs(un - r.u).max() < 1e-13
     assert abs(massn - out["mass"]) < 1e-14
+
+
+def test_subcell_rd_and_dt_control_two_ranks(tmp_path):
+    """-lo 4 (ghost traces in the lumped face fluxes of the RD solver) with -bt 1 -dtc 1 on two ranks: the
+    controller sees the MIN over the ranks (all_reduce, MPI_Allreduce of remhos.cpp:1993), so both ranks repeat
+    the same steps; field, step counts and the final dt equal the oracle's."""
+    from oracle.remhos_oracle import Config, Remhos
+
+    mesh, rs, p, prob, dt, tf = "periodic-cube", 0, 2, 0, 0.06, 0.12
+    un, massn, maxn = _run(tmp_path, mesh, rs, p, prob, -1, (1, 2, 1), opts=f"4,1,1,{dt},{tf}")
+    r = Remhos(Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=dt, t_final=tf, lo=4, fct=2, bounds_type=1, dt_control=1))
+    out = r.run()
+    assert r.repeats == 3
+    for nsteps, repeats, dt_end in _run.info:
+        assert (int(nsteps), int(repeats)) == (out["steps"], r.repeats)
+        assert abs(dt_end - out["dt"]) < 1e-12 * out["dt"]
+    assert np.abs(un - r.u).max() < 1e-12
+    assert abs(massn - out["mass"]) < 1e-13
