@@ -103,6 +103,16 @@ public:
    void CalcHOSolution(const Vector &u, Vector &du) const override;
 };
 
+// remhos_ho.hpp:44-54, remhos_ho.cpp:30-70: du = M^-1 K u by Jacobi-preconditioned CG to a relative tolerance of
+// 1e-12 (abs 0, at most 500 iterations).  M is block diagonal, so the element-local PCG of the HO kernel run to
+// that relative tolerance PER ELEMENT satisfies the reference's global stopping test a fortiori.
+class CGHOSolver : public HOSolver
+{
+public:
+   CGHOSolver(ParFiniteElementSpace &space) : HOSolver(space) {}
+   void CalcHOSolution(const Vector &u, Vector &du) const override;
+};
+
 // Low-Order Solver (remhos_lo.hpp:28-44)
 class LOSolver
 {
@@ -129,6 +139,14 @@ protected:
 public:
    MassBasedAvg(ParFiniteElementSpace &space, HOSolver &hos) : LOSolver(space), ho_solver(hos) {}
    void SetHOSolution(Vector &du) { du_HO = &du; }
+   void CalcLOSolution(const Vector &u, Vector &du) const override;
+};
+
+// remhos_lo.hpp:111-140 (-lo 3)
+class PAResidualDistribution : public LOSolver
+{
+public:
+   PAResidualDistribution(ParFiniteElementSpace &space) : LOSolver(space) {}
    void CalcLOSolution(const Vector &u, Vector &du) const override;
 };
 

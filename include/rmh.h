@@ -128,6 +128,11 @@ int rmh_compute_lumped_mass(rmh_ctx *ctx, double t, double *m);
 int rmh_lo_massavg(rmh_ctx *ctx, const double *u, const double *du_ho, double dt, double *du_lo);
 int rmh_lo_rdsubcell(rmh_ctx *ctx, const double *u, double *du_lo);
 
+/* LOSolver::CalcLOSolution of PAResidualDistribution (-lo 3, remhos_lo.hpp:111-140, remhos_lo.cpp:965-1034):
+ * the same element residual distribution and lumped upwind face fluxes without the subcell fluctuations
+ * (no rmh_layout.subcell_vel needed).  Same kernel as rmh_lo_rdsubcell; orders >= 2. */
+int rmh_lo_rd(rmh_ctx *ctx, const double *u, double *du_lo);
+
 /* DofInfo::ComputeElementsMinMax (remhos_tools.cpp:497-523) and DofInfo::ComputeBounds ->
  * ComputeOverlapBounds (remhos_tools.cpp:432-495).  rmh_bounds uses the element extrema of
  * the last rmh_elem_minmax / rmh_ho_apply call plus the ghost extrema. */
@@ -177,7 +182,8 @@ int rmh_stage_fused_range(rmh_ctx *ctx, const double *u, double dt, const double
 int rmh_invalidate_extrema(rmh_ctx *ctx);
 
 /* Which LOSolver rmh_stage_fused runs inside the stage kernel: 5 = MassBasedAvg (default), 4 =
- * PAResidualDistributionSubcell (-lo, remhos.cpp:268-276); lo 4 needs rmh_layout.subcell_vel. */
+ * PAResidualDistributionSubcell, 3 = PAResidualDistribution (-lo, remhos.cpp:268-276); lo 4 needs
+ * rmh_layout.subcell_vel. */
 int rmh_set_lo_type(rmh_ctx *ctx, int lo_type);
 
 /* DofInfo bounds type (-bt, remhos.cpp:289; DofInfo::ComputeBounds, remhos_tools.hpp:168-182) used by rmh_bounds,
@@ -213,6 +219,7 @@ int rmh_last_cg_iters(rmh_ctx *ctx, int *max_iters);
  * Default: rel_tol 1e-14, abs_tol 0, max_iter 100 -- see DESIGN.md for why this is tighter than
  * the reference's abs 1e-8. */
 int rmh_set_mass_tol(rmh_ctx *ctx, double rel_tol, double abs_tol, int max_iter);
+int rmh_get_mass_tol(rmh_ctx *ctx, double *rel_tol, double *abs_tol, int *max_iter);
 
 #ifdef __cplusplus
 }

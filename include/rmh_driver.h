@@ -24,12 +24,13 @@ typedef struct {
    double dt;         /* -dt (< 0: CFL rule remhos.cpp:538-553)                               */
    double t_final;    /* -tf                                                                  */
    int max_steps;     /* -ms (< 0: none)                                                      */
-   int lo_type;       /* -lo : 4 subcell RD, 5 mass-based average                             */
+   int lo_type;       /* -lo : 3 RD, 4 subcell RD, 5 mass-based average                       */
    int fused;         /* 1: LimitMult through rmh_limit_fused, 0: the reference's call sequence */
    int px, py, pz;    /* box partition of the element lattice                                 */
    int rank;          /* which block this process owns                                        */
    int bounds_type;   /* -bt : 0 overlap bounds, 1 face-neighbour bounds                        */
    int dt_control;    /* -dtc: 0 fixed dt, 1 LOBoundsError (needs -bt 1; remhos.cpp:1178-1197)  */
+   int ho_type;       /* -ho : 3 local inverse (0 means 3), 2 CG to rel. tolerance 1e-12        */
 } rmhd_config;
 
 typedef struct {

@@ -15,10 +15,10 @@ LIB_PATH = os.path.join(_HERE, "librmh.so")
 SYMBOLS = [
     "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
-    "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_elem_minmax", "rmh_bounds",
+    "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_lo_rd", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range",
     "rmh_halo_pack_records", "rmh_set_ghost_records", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
-    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
+    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
 ]
 
@@ -69,6 +69,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_compute_lumped_mass.argtypes = [p, d, p]
     lib.rmh_lo_massavg.argtypes = [p, p, p, d, p]
     lib.rmh_lo_rdsubcell.argtypes = [p, p, p]
+    lib.rmh_lo_rd.argtypes = [p, p, p]
     lib.rmh_elem_minmax.argtypes = [p, p, p, p]
     lib.rmh_bounds.argtypes = [p, p, p, p, p]
     lib.rmh_fct_clipscale.argtypes = [p, p, p, p, p, p, p, d, p]
@@ -83,6 +84,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_enable_timers.argtypes = [p, i]
     lib.rmh_last_cg_iters.argtypes = [p, C.POINTER(i)]
     lib.rmh_set_mass_tol.argtypes = [p, d, d, i]
+    lib.rmh_get_mass_tol.argtypes = [p, C.POINTER(d), C.POINTER(d), C.POINTER(i)]
     lib.rmh_set_lo_type.argtypes = [p, i]
     lib.rmh_set_bounds_type.argtypes = [p, i]
     lib.rmh_invalidate_extrema.argtypes = [p]
@@ -193,6 +195,9 @@ class Context:
 
     def lo_rdsubcell(self, u, du_lo):
         self._check(self.lib.rmh_lo_rdsubcell(self.h, _ptr(u), _ptr(du_lo)))
+
+    def lo_rd(self, u, du_lo):
+        self._check(self.lib.rmh_lo_rd(self.h, _ptr(u), _ptr(du_lo)))
 
     def elem_minmax(self, u, xe_min, xe_max):
         self._check(self.lib.rmh_elem_minmax(self.h, _ptr(u), _ptr(xe_min), _ptr(xe_max)))

@@ -23,7 +23,7 @@ class RmhdConfig(C.Structure):
         ("mesh", C.c_char * 32), ("rs", C.c_int), ("order", C.c_int), ("problem", C.c_int),
         ("dt", C.c_double), ("t_final", C.c_double), ("max_steps", C.c_int), ("lo_type", C.c_int),
         ("fused", C.c_int), ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int), ("rank", C.c_int),
-        ("bounds_type", C.c_int), ("dt_control", C.c_int),
+        ("bounds_type", C.c_int), ("dt_control", C.c_int), ("ho_type", C.c_int),
     ]
 
 
@@ -48,14 +48,14 @@ class RmhdResult(C.Structure):
 
 
 def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=-1, lo_type=5,
-                fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0) -> RmhdConfig:
+                fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0, ho_type=3) -> RmhdConfig:
     c = RmhdConfig()
     c.mesh = mesh.encode()
     c.rs, c.order, c.problem = rs, order, problem
     c.dt, c.t_final, c.max_steps, c.lo_type, c.fused = dt, t_final, max_steps, lo_type, fused
     c.px, c.py, c.pz = part
     c.rank = rank
-    c.bounds_type, c.dt_control = bounds_type, dt_control
+    c.bounds_type, c.dt_control, c.ho_type = bounds_type, dt_control, ho_type
     return c
 
 

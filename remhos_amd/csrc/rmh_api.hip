@@ -159,6 +159,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.e_end = c->ne;
    a.bounds_type = 0;
    a.dt_est = nullptr;
+   a.rd_subcell = c->lo_type == 3 ? 0 : 1;
    a.t = t;
    a.move = c->exec_mode == 1;
    a.alpha = c->exec_mode == 1 ? 1.0 : -1.0;
@@ -239,7 +240,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.xe_max_out = c->d_xe_max2;
    a.bounds_type = c->bounds_type;
    a.dt_est = c->dt_control ? c->d_dt_est : nullptr;
-   if (c->lo_type == 4)
+   a.rd_subcell = c->lo_type == 3 ? 0 : 1;
+   if (c->lo_type == 4 || c->lo_type == 3)
    {
       constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
       constexpr int NB = K2Cfg<P4, true, true>::NB;
@@ -434,19 +436,38 @@ int rmh_lo_massavg(rmh_ctx *c, const double *u, const double *du_ho, double dt, 
    return timer_end(c, 2, ep);
 }
 
+namespace
+{
+int lo_rd(rmh_ctx *c, const double *u, double *du_lo, int lo_type)
+{
+   EventPair ep;
+   int rc = timer_begin(c, 2, ep);
+   if (rc) { return rc; }
+   const int keep = c->lo_type;
+   c->lo_type = lo_type;
+   RMH_DISPATCH(c, rc = (launch_ho<P, 2>(c, u, du_lo, c->d_m, c->t)));
+   c->lo_type = keep;
+   if (rc) { return rc; }
+   c->ho_done = true; // lumped mass and element extrema are current
+   return timer_end(c, 2, ep);
+}
+} // namespace
+
 int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 {
    if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (c->p < 2) { return fail(RMH_ERR_INVALID, "Subcell schemes require FE order > 2."); } // remhos.cpp:612-616
    if (!c->d_subvel) { return fail(RMH_ERR_STATE, "rmh_lo_rdsubcell needs rmh_layout.subcell_vel"); }
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
-   EventPair ep;
-   int rc = timer_begin(c, 2, ep);
-   if (rc) { return rc; }
-   RMH_DISPATCH(c, rc = (launch_ho<P, 2>(c, u, du_lo, c->d_m, c->t)));
-   if (rc) { return rc; }
-   c->ho_done = true; // lumped mass and element extrema are current
-   return timer_end(c, 2, ep);
+   return lo_rd(c, u, du_lo, 4);
+}
+
+int rmh_lo_rd(rmh_ctx *c, const double *u, double *du_lo)
+{
+   if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (c->p < 2 || c->ho_variant != 2) { return fail(RMH_ERR_INVALID, "rmh_lo_rd: the batched RD kernel is built for orders >= 2"); }
+   if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
+   return lo_rd(c, u, du_lo, 3);
 }
 
 int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)
@@ -544,6 +565,7 @@ int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *
    {
       return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 4 needs order >= 2 and rmh_layout.subcell_vel");
    }
+   if (c->lo_type == 3 && c->p < 2) { return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 3 needs order >= 2"); }
    if (c->ng > 0 && (!c->u_ghost || !c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost data not set"); }
    int rc = 0;
    if (c->xe_of != u)
@@ -636,7 +658,8 @@ int rmh_last_cg_iters(rmh_ctx *c, int *max_iters)
 
 int rmh_set_lo_type(rmh_ctx *c, int lo_type)
 {
-   if (!c || (lo_type != 4 && lo_type != 5)) { return fail(RMH_ERR_INVALID, "lo_type must be 4 or 5"); }
+   if (!c || (lo_type != 3 && lo_type != 4 && lo_type != 5)) { return fail(RMH_ERR_INVALID, "lo_type must be 3, 4 or 5"); }
+   if (lo_type == 3 && c->p < 2) { return fail(RMH_ERR_STATE, "lo 3: the batched RD kernel is built for orders >= 2"); }
    if (lo_type == 4 && (c->p < 2 || !c->d_subvel)) { return fail(RMH_ERR_STATE, "lo 4 needs order >= 2 and rmh_layout.subcell_vel"); }
    c->lo_type = lo_type;
    return RMH_OK;
@@ -695,6 +718,15 @@ int rmh_dt_estimate_get(rmh_ctx *c, double *dt)
    if (!c->d_dt_est) { return fail(RMH_ERR_STATE, "dt control is off"); }
    RMH_HIP(hipStreamSynchronize(c->stream));
    RMH_HIP(hipMemcpy(dt, c->d_dt_est, sizeof(double), hipMemcpyDeviceToHost));
+   return RMH_OK;
+}
+
+int rmh_get_mass_tol(rmh_ctx *c, double *rel_tol, double *abs_tol, int *max_iter)
+{
+   if (!c || !rel_tol || !abs_tol || !max_iter) { return fail(RMH_ERR_INVALID, "null argument"); }
+   *rel_tol = c->rel_tol;
+   *abs_tol = c->abs_tol;
+   *max_iter = c->max_iter;
    return RMH_OK;
 }
 

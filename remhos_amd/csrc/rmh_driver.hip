@@ -110,6 +110,17 @@ void LocalInverseHOSolver::CalcHOSolution(const Vector &u, Vector &du) const
    RMH_CALL(rmh_ho_apply(pfes.Ctx(), u.Read(), du.Write()));
 }
 
+void CGHOSolver::CalcHOSolution(const Vector &u, Vector &du) const
+{
+   RMH_VERIFY(timer, "Timer not set.");
+   double rel, abs;
+   int maxit;
+   RMH_CALL(rmh_get_mass_tol(pfes.Ctx(), &rel, &abs, &maxit));
+   RMH_CALL(rmh_set_mass_tol(pfes.Ctx(), 1e-12, 0.0, 500)); // remhos_ho.cpp:60-63
+   RMH_CALL(rmh_ho_apply(pfes.Ctx(), u.Read(), du.Write()));
+   RMH_CALL(rmh_set_mass_tol(pfes.Ctx(), rel, abs, maxit));
+}
+
 void MassBasedAvg::CalcLOSolution(const Vector &u, Vector &du) const
 {
    // remhos_lo.cpp:247-324
@@ -124,6 +135,11 @@ void MassBasedAvg::CalcLOSolution(const Vector &u, Vector &du) const
       ho_solver.CalcHOSolution(u, du_HO_tmp);
       RMH_CALL(rmh_lo_massavg(pfes.Ctx(), u.Read(), du_HO_tmp.Read(), dt, du.Write()));
    }
+}
+
+void PAResidualDistribution::CalcLOSolution(const Vector &u, Vector &du) const
+{
+   RMH_CALL(rmh_lo_rd(pfes.Ctx(), u.Read(), du.Write()));
 }
 
 void PAResidualDistributionSubcell::CalcLOSolution(const Vector &u, Vector &du) const
@@ -283,14 +299,24 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
    {
       ParFiniteElementSpace pfes(ctx, cd.ne_owned, cd.ndof, (long long)cd.ne_global * cd.ndof);
       DofInfo dofs(pfes);
-      HOSolver *ho_solver = new LocalInverseHOSolver(pfes);
+      // solver factory of remhos.cpp:912-925, 927-995 for the options on the path
+      HOSolver *ho_solver = nullptr;
+      if (cfg->ho_type == 2) { ho_solver = new CGHOSolver(pfes); }
+      else { ho_solver = new LocalInverseHOSolver(pfes); }
       LOSolver *lo_solver = nullptr;
       if (cc.lo_type == 5) { lo_solver = new MassBasedAvg(pfes, *ho_solver); }
+      else if (cc.lo_type == 3) { lo_solver = new PAResidualDistribution(pfes); }
       else { lo_solver = new PAResidualDistributionSubcell(pfes); }
       double dt = cd.dt;
       FCTSolver *fct_solver = new ClipScaleSolver(pfes, dt);
-      const bool fused = cfg->fused && cc.lo_type == 5;
-      AdvectionOperator adv(pfes, dofs, ho_solver, lo_solver, fct_solver, fused);
+      // fused = 1: one kernel per RK stage (rmh_stage_fused with the LO solver and the mass tolerance of the options)
+      const bool fused = cfg->fused != 0;
+      if (fused)
+      {
+         RMH_CALL(rmh_set_lo_type(ctx, cc.lo_type));
+         if (cfg->ho_type == 2) { RMH_CALL(rmh_set_mass_tol(ctx, 1e-12, 0.0, 500)); }
+      }
+      AdvectionOperator adv(pfes, dofs, ho_solver, lo_solver, fct_solver, false);
 
       Vector u(vsize);
       u.CopyFromHost(cd.u0.data());

@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       }
    }
    RMH_STAMP(1);
-   if (LO4)
+   if (LO4 && a.rd_subcell)
    {
       // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
       for (int k = tid; k < NB * 3 * D3; k += NT)
@@ -597,14 +597,16 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 #pragma unroll
             for (int comp = 0; comp < 3; comp++)
             {
-               const double x = xs[comp * D3 + i];
+               // plain residual distribution (lo 3, remhos_lo.cpp:965-1034) = the subcell scheme with
+               // zero subcell fluctuations: the sub-mesh is not loaded and contributes nothing
+               const double x = a.rd_subcell ? xs[comp * D3 + i] : 0.0;
                J[comp][0] += ((j & 1) ? 0.25 : -0.25) * x;
                J[comp][1] += ((j & 2) ? 0.25 : -0.25) * x;
                J[comp][2] += ((j & 4) ? 0.25 : -0.25) * x;
             }
          }
 #pragma unroll
-         for (int comp = 0; comp < 3; comp++) { vm[comp] = a.subvmid[((size_t)e * 3 + comp) * NS + m]; }
+         for (int comp = 0; comp < 3; comp++) { vm[comp] = a.rd_subcell ? a.subvmid[((size_t)e * 3 + comp) * NS + m] : 0.0; }
          const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
          const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
          const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];

@@ -195,7 +195,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    if (cfg.px < 1 || cfg.py < 1 || cfg.pz < 1) { return "bad partition"; }
    const int nranks = cfg.px * cfg.py * cfg.pz;
    if (cfg.rank < 0 || cfg.rank >= nranks) { return "bad rank"; }
-   if (cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 4 or 5"; }
+   if (cfg.lo_type != 3 && cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 3, 4 or 5"; }
 
    const std::vector<double> verts = refine(md.coarse, cfg.rs);
    const int N = (int)verts.size() - 1;

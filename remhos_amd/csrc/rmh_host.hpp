@@ -18,7 +18,7 @@ struct CaseConfig
    double dt = -1.0;                   // -dt  (< 0: CFL rule, remhos.cpp:538-553)
    double t_final = 0.5;               // -tf
    int max_steps = -1;                 // -ms
-   int lo_type = 5;                    // -lo  (4 or 5)
+   int lo_type = 5;                    // -lo  (3, 4 or 5)
    int px = 1, py = 1, pz = 1;         // box partition of the element lattice
    int rank = 0;
 };

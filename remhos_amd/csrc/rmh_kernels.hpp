@@ -69,6 +69,7 @@ struct HoArgs
    double *y_out;
    double *xe_min_out, *xe_max_out; // extrema of y_out (input extrema of the next stage)
    int bounds_type;                 // 0 overlap bounds, 1 face-neighbour bounds
+   int rd_subcell;                  // RD solver: 1 subcell fluctuations (lo 4), 0 plain PAResidualDistribution (lo 3)
    double *dt_est;                  // null, or the running minimum of UpdateTimeStepEstimate
 };
 

@@ -21,7 +21,7 @@ class Stepper:
         self.dev = torch.device(device)
         self.dist = dist if (dist is not None and case.peers) else None
         self.lo = int(case.cfg.lo_type)
-        self.fused_lo4 = fused and self.lo == 4  # lo 4: HO kernel + RD kernel + fused limiter/RK kernel
+        self.fused_lo4 = fused and self.lo in (3, 4)  # lo 3 / 4: HO kernel + RD kernel + fused limiter/RK kernel
         self.fused = fused and self.lo == 5
         fused = self.fused
         self.one_kernel = one_kernel and (self.fused or self.fused_lo4)  # whole stage in one kernel (rmh_stage_fused)
@@ -31,8 +31,10 @@ class Stepper:
                            subcell_vel=case.subcell_vel, device=dev_index if self.dev.type == "cuda" else 0)
         if self.dev.type == "cuda":
             self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
-        if self.lo == 4:
-            self.ctx.set_lo_type(4)
+        if self.lo in (3, 4):
+            self.ctx.set_lo_type(self.lo)
+        if getattr(case.cfg, "ho_type", 3) == 2:
+            self.ctx.set_mass_tol(1e-12, 0.0, 500)  # CGHOSolver (-ho 2, remhos_ho.cpp:60-63): see solvers.hpp
         self.dtc = bool(getattr(case.cfg, "dt_control", 0))
         if getattr(case.cfg, "bounds_type", 0):
             self.ctx.set_bounds_type(case.cfg.bounds_type)
@@ -113,7 +115,7 @@ class Stepper:
             return
         c.ho_apply(u, self.k)
         if self.fused_lo4:
-            c.lo_rdsubcell(u, self.du_lo)
+            (c.lo_rd if self.lo == 3 else c.lo_rdsubcell)(u, self.du_lo)
             c.limit_fused_lo(u, self.k, self.du_lo, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
             return
         if self.fused:
@@ -123,6 +125,8 @@ class Stepper:
         m = c.lumped_mass_ptr()  # refreshed by rmh_ho_apply at this stage's mesh position (remhos.cpp:1632)
         if self.lo == 4:
             c.lo_rdsubcell(u, self.du_lo)
+        elif self.lo == 3:
+            c.lo_rd(u, self.du_lo)
         else:
             c.lo_massavg(u, self.k, dt, self.du_lo)
         c.elem_minmax(u, self.xe_min, self.xe_max)

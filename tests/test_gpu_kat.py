@@ -87,13 +87,26 @@ AUTOTEST_LO4 = [
 ]
 
 
-@pytest.mark.parametrize("name,kw,mass,umax,steps", AUTOTEST_LO4, ids=[k[0] for k in AUTOTEST_LO4])
-def test_autotest_baseline_lo4(lib, name, kw, mass, umax, steps):
-    """Subcell residual distribution (lo 4) + HO + ClipScale over the whole run: the reference's
-    own printed 'Final mass u' / 'Max value u' (10 digits)."""
+# "-ho 2 -lo 3 -fct 2 -pa" (out_baseline.dat:100-103, :83-86): CG HO solver + plain residual distribution
+AUTOTEST_LO3 = [
+    ("periodic-cube transport -ho 2 -lo 3", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo_type=3, ho_type=2),
+     0.9607429525, 0.9202929163, 134),
+    ("cube01_hex remap -ho 2 -lo 3", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo_type=3, ho_type=2),
+     0.1197300033, 0.9997879406, 50),
+    ("cube01_hex remap -ho 2 -lo 4", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo_type=4, ho_type=2),
+     0.1197299801, 0.9997499683, 50),
+]
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("name,kw,mass,umax,steps", AUTOTEST_LO4 + AUTOTEST_LO3, ids=[k[0] for k in AUTOTEST_LO4 + AUTOTEST_LO3])
+def test_autotest_baseline_lo4(lib, name, kw, mass, umax, steps, fused):
+    """Residual distribution LO solvers (lo 4 subcell, lo 3 plain) + HO (local inverse or -ho 2) + ClipScale over
+    the whole run: the reference's own printed 'Final mass u' / 'Max value u' (10 digits); granular solver
+    classes (fused = 0) and one kernel per stage (fused = 1)."""
     from remhos_amd.case import RmhdResult, make_config
 
-    cfg = make_config(fused=0, **kw)
+    cfg = make_config(fused=fused, **kw)
     res = RmhdResult()
     assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, lib.rmhd_last_error()
     assert res.steps == steps

@@ -19,6 +19,11 @@ def _r10(x):
 
 
 AUTOTEST = [
+    # -lo 3 (plain residual distribution; the reference ran these with -ho 2 = CG to 1e-12, out_baseline.dat:76-111)
+    ("periodic-cube transport -lo 3 (:100-103)", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo=3),
+     0.9607429525, 0.9202929163),
+    ("cube01_hex remap -lo 3 (:83-86)", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo=3),
+     0.1197300033, 0.9997879406),
     # name, kwargs, Final mass u, Max value u  (autotest/out_baseline.dat)
     ("periodic-cube transport (:66-69)", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo=4),
      0.9607429525, 0.9334903111),
