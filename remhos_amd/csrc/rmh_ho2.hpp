@@ -49,9 +49,11 @@ struct K2Cfg : TabLayout<P>
    // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
    // footprint would otherwise limit the CU to one workgroup (measured per order)
    static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : NT / Q2));
-   // HO + RD in one kernel carries more LDS per element: one element less keeps two workgroups per CU
+   // HO + RD in one kernel carries more LDS per element.  p = 3, -rs 5, MDOFs*stage/s by elements per workgroup:
+   // 7 (1 workgroup/CU) 4.1 k, 6 (2/CU) 6.5 k, 5 (2/CU) 5.8 k, 4 (3/CU, 168 VGPRs without spills) 7.4 k --
+   // occupancy beats lane utilisation of the column phases (4 x 36 of 256 lanes).
 #ifndef RMH_BOTH_DROP
-#define RMH_BOTH_DROP 1
+#define RMH_BOTH_DROP (P == 3 ? 3 : 1)
 #endif
    static constexpr int NB = (BOTH && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0;
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
