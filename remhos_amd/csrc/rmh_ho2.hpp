@@ -48,12 +48,16 @@ struct K2Cfg : TabLayout<P>
 #endif
    // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
    // footprint would otherwise limit the CU to one workgroup (measured per order)
-   static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : NT / Q2));
-   // HO + RD in one kernel carries more LDS per element.  p = 3, -rs 5, MDOFs*stage/s by elements per workgroup:
-   // 7 (1 workgroup/CU) 4.1 k, 6 (2/CU) 6.5 k, 5 (2/CU) 5.8 k, 4 (3/CU, 168 VGPRs without spills) 7.4 k --
-   // occupancy beats lane utilisation of the column phases (4 x 36 of 256 lanes).
+#ifndef RMH_NB3
+#define RMH_NB3 (NT / Q2)
+#endif
+   static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : (P == 3 ? RMH_NB3 : NT / Q2)));
+   // HO + RD in one kernel carries more LDS per element: one element less.  p = 3, -rs 5, MDOFs*stage/s by
+   // elements per workgroup and workgroups per CU (round 1, before / after the LDS diet of the RD extras):
+   // 7 @ 1: 4.1 k; 6 @ 2: 6.5 k; 5 @ 2: 5.8 k; 4 @ 3: 7.4 k; 5 @ 3: 7.7 k; 6 @ 3: 8.6 k -- occupancy first, then
+   // lane utilisation of the column phases (NB x 36 of 256 lanes).
 #ifndef RMH_BOTH_DROP
-#define RMH_BOTH_DROP (P == 3 ? 3 : 1)
+#define RMH_BOTH_DROP 1
 #endif
    static constexpr int NB = (BOTH && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0;
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
@@ -65,31 +69,38 @@ struct K2Cfg : TabLayout<P>
    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
    static constexpr int S2 = D2 + 1; // padded row stride of U1 / M1 (bank conflicts)
    static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
-   // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal,
-   // 3 z = K_vol u in the Bernstein basis (only when HO and RD run in the same kernel)
-   static constexpr int NR = BOTH ? 4 : 3;
+   // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
+   // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
+   // volume rhs by the 1-D change of test basis Cf in each direction (phi^B_i = sum_k C[k][i] l_k), not by a
+   // fourth tensor through phases C-G.
+   static constexpr int NR = 3;
    static constexpr int oR3 = 0, oR2 = NR * Q2 * D, PF = oR2 + NR * Q * D2;
    static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
    // lo 4 (subcell residual distribution) extras: sub-mesh node positions behind the phase A-C data,
-   // subcell data [6][NS] and the lumped face flux per dof behind the face buffer
+   // subcell data [4][NS] and the lumped face flux per dof behind the face buffer
    static constexpr int NS = P * P * P;
    static constexpr int oXs = PA;
-   static constexpr int W = cmax(PA + (LO4 ? 3 * D3 : 0), cmax(PF, PCG));
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
+   // the sub-mesh nodes are consumed by the subcell pass before the face rows are formed: the
+   // Bernstein-tested s rows of the RD solver take their place when HO and RD share the kernel
+   static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, PCG));
    static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
-   static constexpr int oF2 = BOTH ? oF + RF : oF;    // s rows (Bernstein basis) of the RD solver
-   static constexpr int oSub = oF2 + RF, oDuf = oSub + 6 * NS;
+   static constexpr int oF2 = BOTH ? oXs : oF;        // s rows (Bernstein basis) of the RD solver
+   static constexpr int oSub = oF + RF, oDuf = oSub + 4 * NS;
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
-   static constexpr int EL0 = W + RF + (BOTH ? RF : 0) + (LO4 ? 6 * NS + D3 : 0);
+   static constexpr int EL0 = W + RF + (LO4 ? 4 * NS + D3 : 0);
    static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
    // partial sums of the generic reductions: chunks of 64 dofs (one wavefront each), 8 chunks for small elements
    static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
-   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + cmax(8, 2 * DOT_CH) * NB;
-   static constexpr int LDS_BYTES = 8 * LDS_DOUBLES;
+   static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
+   static constexpr int PART = (WAVE_ALIGNED && DR <= 2) ? 0 : cmax(8, 2 * DOT_CH) * NB; // (the DPP paths need none)
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART;
+   // LDS allocation granule: a 54 096-byte kernel ran two workgroups per CU, a 52 560-byte one three (measured:
+   // 6.3 k vs 8.6 k MDOFs*stage/s); 2 KiB granules are consistent with that
+   static constexpr int LDS_BYTES = (8 * LDS_DOUBLES + 2047) / 2048 * 2048;
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
    static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 4 ? 4 : (160 * 1024) / LDS_BYTES);
-   static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
@@ -182,6 +193,12 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
       x = dpp_add<0x142, 0xA>(x); // row_bcast:15 into rows 1 and 3: half-wave totals
       if (lane == 31) { cur[wave] = x; }
       if (lane == 63 && (C::NT / C::D3 + wave) < C::NB) { cur[C::NT / C::D3 + wave] = x; }
+   }
+   else if (C::WAVE_ALIGNED && C::DR == 1)
+   {
+      // one round: every wavefront holds one element
+      const double x = wave_sum((tid < C::NB * C::D3) ? v[0] : 0.0);
+      if ((tid & 63) == 63 && (tid >> 6) < C::NB) { cur[tid >> 6] = x; }
    }
    else
    {
@@ -307,6 +324,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
    const int e0 = a.e_begin + blockIdx.x * NB;
    static_assert(C::N2 <= RMH_TAB_STRIDE, "constant table too small");
    const double *gt = c_tab[P]; // constant memory: compile-time indices become scalar loads
+   (void)gt;
    constexpr int oB = C::oB, oG = C::oG, oL = C::oL, odL = C::odL, oW = C::oW, oBg = C::oBg, oBg2 = C::oBg2,
                  oCi = C::oCi;
 
@@ -396,6 +414,17 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       const int k = tid + j * NT;
       if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
    }
+   if (LO4 && a.rd_subcell)
+   {
+      // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
+      for (int k = tid; k < NB * 3 * D3; k += NT)
+      {
+         const int eb = k / (3 * D3), r3 = k % (3 * D3);
+         const size_t g = (size_t)min(e0 + eb, a.e_end - 1) * 3 * D3 + r3;
+         const double xs0 = a.subx0[g];
+         RMH_W(eb)[C::oXs + r3] = a.move ? xs0 + a.t * a.subvel[g] : xs0;
+      }
+   }
    __syncthreads();
 
    RMH_STAMP(0);
@@ -453,17 +482,74 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       }
    }
    RMH_STAMP(1);
-   if (LO4 && a.rd_subcell)
+   if (LO4)
    {
-      // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
-      for (int k = tid; k < NB * 3 * D3; k += NT)
+      // (before the face rows: their Bernstein-tested rows reuse the LDS of the sub-mesh nodes)
+      constexpr int NS = C::NS;
+      const double eps = 1.E-15;
+      // subcell fluctuations with the 1-point rule on the trilinear subcells and subcell extrema
+      // (SetupSubCellPA3D / ApplySubCellWeights remhos_lo.cpp:1137-1192, 1313-1618; :1733-1757)
+      for (int k = tid; k < NB * NS; k += NT)
       {
-         const int eb = k / (3 * D3), r3 = k % (3 * D3);
-         const size_t g = (size_t)min(e0 + eb, a.e_end - 1) * 3 * D3 + r3;
-         const double xs0 = a.subx0[g];
-         RMH_W(eb)[C::oXs + r3] = a.move ? xs0 + a.t * a.subvel[g] : xs0;
+         const int eb = k / NS, m = k % NS;
+         const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
+         const int base = mx + D * my + D2 * mz;
+         const double *su_ = RMH_W(eb) + oU, *xs = RMH_W(eb) + C::oXs;
+         const int e = min(e0 + eb, a.e_end - 1);
+         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
+         double umax = -INFINITY, umin = INFINITY, usum = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+         {
+            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
+            const double uj = su_[i];
+            umax = fmax(umax, uj);
+            umin = fmin(umin, uj);
+            usum += uj;
+#pragma unroll
+            for (int comp = 0; comp < 3; comp++)
+            {
+               // plain residual distribution (lo 3, remhos_lo.cpp:965-1034) = the subcell scheme with
+               // zero subcell fluctuations: the sub-mesh is not loaded and contributes nothing
+               const double x = a.rd_subcell ? xs[comp * D3 + i] : 0.0;
+               J[comp][0] += ((j & 1) ? 0.25 : -0.25) * x;
+               J[comp][1] += ((j & 2) ? 0.25 : -0.25) * x;
+               J[comp][2] += ((j & 4) ? 0.25 : -0.25) * x;
+            }
+         }
+#pragma unroll
+         for (int comp = 0; comp < 3; comp++) { vm[comp] = a.rd_subcell ? a.subvmid[((size_t)e * 3 + comp) * NS + m] : 0.0; }
+         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
+         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
+         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
+         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
+         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+         const double q0 = a.alpha * (A11 * vm[0] + A12 * vm[1] + A13 * vm[2]);
+         const double q1v = a.alpha * (A21 * vm[0] + A22 * vm[1] + A23 * vm[2]);
+         const double q2v = a.alpha * (A31 * vm[0] + A32 * vm[1] + A33 * vm[2]);
+         double fluct = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+         {
+            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
+            const double w = ((j & 1) ? 0.25 : -0.25) * q0 + ((j & 2) ? 0.25 : -0.25) * q1v + ((j & 4) ? 0.25 : -0.25) * q2v;
+            fluct += w * su_[i];
+         }
+         double *fl = RMH_W(eb) + C::oSub;
+         // [fluct | umax | umin | ratio]: fluct^+ = max(0, fluct), fluct^- = min(0, fluct) are re-formed by the
+         // readers; eqs. (58)-(59): the ratio fluct^+- / sumWeightsSubcell^+- is formed once per subcell, and
+         // only the one of the two with a non-zero numerator is kept (the other contributes exactly zero)
+         fl[0 * NS + m] = fluct;
+         fl[1 * NS + m] = umax;
+         fl[2 * NS + m] = umin;
+         fl[3 * NS + m] = (fluct > 0.) ? fluct / (8 * umax - usum + eps) : fmin(0., fluct) / (8 * umin - usum - eps);
       }
    }
+   if (LO4) { __syncthreads(); }
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
@@ -575,69 +661,6 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
 
    if (LO4)
    {
-      constexpr int NS = C::NS;
-      const double eps = 1.E-15;
-      // subcell fluctuations with the 1-point rule on the trilinear subcells and subcell extrema
-      // (SetupSubCellPA3D / ApplySubCellWeights remhos_lo.cpp:1137-1192, 1313-1618; :1733-1757)
-      for (int k = tid; k < NB * NS; k += NT)
-      {
-         const int eb = k / NS, m = k % NS;
-         const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
-         const int base = mx + D * my + D2 * mz;
-         const double *su_ = RMH_W(eb) + oU, *xs = RMH_W(eb) + C::oXs;
-         const int e = min(e0 + eb, a.e_end - 1);
-         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
-         double umax = -INFINITY, umin = INFINITY, usum = 0.0;
-#pragma unroll
-         for (int j = 0; j < 8; j++)
-         {
-            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
-            const double uj = su_[i];
-            umax = fmax(umax, uj);
-            umin = fmin(umin, uj);
-            usum += uj;
-#pragma unroll
-            for (int comp = 0; comp < 3; comp++)
-            {
-               // plain residual distribution (lo 3, remhos_lo.cpp:965-1034) = the subcell scheme with
-               // zero subcell fluctuations: the sub-mesh is not loaded and contributes nothing
-               const double x = a.rd_subcell ? xs[comp * D3 + i] : 0.0;
-               J[comp][0] += ((j & 1) ? 0.25 : -0.25) * x;
-               J[comp][1] += ((j & 2) ? 0.25 : -0.25) * x;
-               J[comp][2] += ((j & 4) ? 0.25 : -0.25) * x;
-            }
-         }
-#pragma unroll
-         for (int comp = 0; comp < 3; comp++) { vm[comp] = a.rd_subcell ? a.subvmid[((size_t)e * 3 + comp) * NS + m] : 0.0; }
-         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
-         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
-         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
-         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
-         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
-         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
-         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-         const double q0 = a.alpha * (A11 * vm[0] + A12 * vm[1] + A13 * vm[2]);
-         const double q1v = a.alpha * (A21 * vm[0] + A22 * vm[1] + A23 * vm[2]);
-         const double q2v = a.alpha * (A31 * vm[0] + A32 * vm[1] + A33 * vm[2]);
-         double fluct = 0.0;
-#pragma unroll
-         for (int j = 0; j < 8; j++)
-         {
-            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
-            const double w = ((j & 1) ? 0.25 : -0.25) * q0 + ((j & 2) ? 0.25 : -0.25) * q1v + ((j & 4) ? 0.25 : -0.25) * q2v;
-            fluct += w * su_[i];
-         }
-         double *fl = RMH_W(eb) + C::oSub;
-         fl[0 * NS + m] = fmax(0., fluct);
-         fl[1 * NS + m] = fmin(0., fluct);
-         fl[2 * NS + m] = umax;
-         fl[3 * NS + m] = umin;
-         // eqs. (58)-(59): the ratio fluct^+- / sumWeightsSubcell^+- is formed once per subcell
-         fl[4 * NS + m] = fmax(0., fluct) / (8 * umax - usum + eps);
-         fl[5 * NS + m] = fmin(0., fluct) / (8 * umin - usum - eps);
-      }
       // lumped upwind face fluxes (ApplyFaceTerms3D, remhos_lo.cpp:795-871), gathered per dof:
       // (B^T D B 1)_i (u_nbr,i - u_i) with the face rows already tested along q2
       for (int t = tid; t < NB * D3; t += NT)
@@ -672,9 +695,9 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
    const int qx = cc % Q, qy = cc / Q;
    double wd[Q];
    double Bgy[D]; // GL basis row of this thread's qy (mass apply)
-   double r0[D], r1[D], r2[D], r3[D];
+   double r0[D], r1[D], r2[D];
 #pragma unroll
-   for (int iz = 0; iz < D; iz++) { r0[iz] = 0; r1[iz] = 0; r2[iz] = 0; r3[iz] = 0; Bgy[iz] = 0; }
+   for (int iz = 0; iz < D; iz++) { r0[iz] = 0; r1[iz] = 0; r2[iz] = 0; Bgy[iz] = 0; }
 #pragma unroll
    for (int qz = 0; qz < Q; qz++) { wd[qz] = 0; }
    if (col)
@@ -803,7 +826,6 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             r0[iz] += gt[(HAS_HO ? oBg : oB) + qz * D + iz] * g;
             r1[iz] += gt[oB + qz * D + iz] * wdq;
             if (HAS_HO) { r2[iz] += gt[oBg2 + qz * D + iz] * wdq; }
-            if (BOTH) { r3[iz] += gt[oB + qz * D + iz] * g; }
          }
       }
    }
@@ -817,7 +839,6 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          R3[(0 * Q2 + cc) * D + iz] = r0[iz];
          R3[(1 * Q2 + cc) * D + iz] = r1[iz];
          R3[(2 * Q2 + cc) * D + iz] = r2[iz];
-         if (BOTH) { R3[(3 * Q2 + cc) * D + iz] = r3[iz]; }
       }
    }
    __syncthreads();
@@ -870,7 +891,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
          const int ix = i % D, i2 = i / D;
          const int idx[3] = {ix, i2 % D, i2 / D};
          const double *R2 = RMH_W(eb) + oR2;
-         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+         double a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
          for (int jx = 0; jx < Q; jx++)
          {
@@ -879,8 +900,8 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             a0 += cBg[r][jx] * R2[(0 * Q + jx) * D2 + i2];
             a1 += bx * R2[(1 * Q + jx) * D2 + i2];
             if (HAS_HO) { a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * D2 + i2]; }
-            if (BOTH) { a3 += bx * R2[(3 * Q + jx) * D2 + i2]; }
          }
+         const double a0vol = a0;
          // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
 #pragma unroll
          for (int c = 0; c < (HAS_HO ? 3 : 0); c++)
@@ -898,7 +919,7 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             }
          }
          rg[r] = a0; mm[r] = a1; dg[r] = a2;
-         zb[r] = BOTH ? a3 : a0; // z = K_vol u in the Bernstein basis (RD)
+         zb[r] = BOTH ? a0vol : a0; // z = K_vol u: Bernstein-tested in the RD-only kernel, GL-tested (converted below) otherwise
       }
    }
 
@@ -913,6 +934,39 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
       double uu4[DR], t0[DR], t1[DR], t2[DR], xSum[DR], rhoP[DR], rhoN[DR];
       int ring4 = 0;
       __syncthreads(); // R2 has been consumed: the front of W is free
+      if (BOTH)
+      {
+         // z (GL-tested) -> z (Bernstein-tested): Cf (x) Cf (x) Cf through the sA / sB slots
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = zb[r]; }
+         }
+         __syncthreads();
+         for (int dir = 0; dir < 3; dir++)
+         {
+            const int oin = (dir & 1) ? oSB : oSA, oout = (dir & 1) ? oSA : oSB;
+            const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
+#pragma unroll
+            for (int r = 0; r < DR; r++)
+            {
+               const int t = tid + r * NT;
+               if (t < NB * D3)
+               {
+                  const int eb = t / D3, i = t % D3;
+                  const int k = (i / stride) % D;
+                  const double *src = RMH_W(eb) + oin + i - k * stride;
+                  double acc = 0.0;
+#pragma unroll
+                  for (int j = 0; j < D; j++) { acc += stab[C::oCf + k * D + j] * src[j * stride]; }
+                  if (dir == 2) { zb[r] = acc; }
+                  else { RMH_W(eb)[oout + i] = acc; }
+               }
+            }
+            __syncthreads();
+         }
+      }
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -977,8 +1031,8 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
             double sp = 0.0, sn = 0.0;
             for (int m = m0; m < m0 + CL && m < NS; m++)
             {
-               sp += fl[m];
-               sn += fl[NS + m];
+               sp += fmax(0., fl[m]);
+               sn += fmin(0., fl[m]);
             }
             double *el = RMH_W(k / CH) + oM1;
             el[2 + k % CH] = sp;
@@ -1015,8 +1069,9 @@ __global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_P
                      if (mx >= 0 && mx < P && my >= 0 && my < P && mz >= 0 && mz < P)
                      {
                         const int m = mx + P * (my + P * mz);
-                        nwP += fl[4 * NS + m] * (fl[2 * NS + m] - ui); // eq. (58)
-                        nwN += fl[5 * NS + m] * (fl[3 * NS + m] - ui); // eq. (59)
+                        const double ratio = fl[3 * NS + m];
+                        if (fl[m] > 0.) { nwP += ratio * (fl[1 * NS + m] - ui); } // eq. (58)
+                        else { nwN += ratio * (fl[2 * NS + m] - ui); }            // eq. (59)
                      }
                   }
                }

@@ -34,7 +34,8 @@ struct TabLayout
    static constexpr int N = oCi + D * D;
    static constexpr int oBgE = N;           // BgE[side*D+k] GL nodal basis at xi = 0 / 1
    static constexpr int oLcu = oBgE + 2 * D; // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
-   static constexpr int N2 = oLcu + 3 * D;  // extended table
+   static constexpr int oCf = oLcu + 3 * D; // Cf[i*D+k] = C[k][i]: GL-tested -> Bernstein-tested moments (phi^B_i = sum_k C[k][i] l_k)
+   static constexpr int N2 = oCf + D * D;   // extended table
 };
 
 inline void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
@@ -190,6 +191,10 @@ inline std::vector<double> make_tables()
    for (int k = 0; k < D; k++)
    {
       for (int i = 0; i < D; i++) { C[k * D + i] = bernstein(P, i, xg[k]); }
+   }
+   for (int i = 0; i < D; i++)
+   {
+      for (int k = 0; k < D; k++) { tab[T::oCf + i * D + k] = C[k * D + i]; }
    }
    invert(D, C);
    for (int i = 0; i < D; i++)
