@@ -59,7 +59,7 @@ struct K2Cfg : TabLayout<P>
 #ifndef RMH_BOTH_DROP
 #define RMH_BOTH_DROP 1
 #endif
-   static constexpr int NB = (BOTH && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0;
+   static constexpr int NB = (LO4 && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0; // (the RD-only kernel carries the same extras)
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
