@@ -113,6 +113,35 @@ __device__ inline double dpp_add(double v)
    return v + __hiloint2double(hi2, lo2);
 }
 
+// the same for controls that give every lane a valid source (quad_perm, row mirrors over all rows): no
+// "old" value, hence no zero-initialisation of the destination
+template <int CTRL>
+__device__ inline double dpp_add_all(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   const int lo = __double2loint(v), hi = __double2hiint(v);
+   const int lo2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+   const int hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+   return v + __hiloint2double(hi2, lo2);
+#else
+   return dpp_add<CTRL, 0xF>(v);
+#endif
+}
+
+// v_permlane32_swap (gfx950): the upper 32 lanes of a are exchanged with the lower 32 lanes of b; afterwards
+// a = {a[0..31], b[0..31]} and b = {a[32..63], b[32..63]}
+__device__ inline void swap32(double &a, double &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+   const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+   a = __hiloint2double((int)r1[0], (int)r0[0]);
+   b = __hiloint2double((int)r1[1], (int)r0[1]);
+#elif defined(HIPEMU)
+   hipemu_permlane32_swap(a, b);
+#endif
+}
+
 template <int CTRL, int ROW_MASK, bool IS_MIN>
 __device__ inline double dpp_minmax(double v)
 {
@@ -139,10 +168,10 @@ __device__ inline double wave_minmax(double v)
 // sum over the 64 lanes of a wavefront in a fixed order; valid in lane 63
 __device__ inline double wave_sum(double v)
 {
-   v = dpp_add<0xB1, 0xF>(v);
-   v = dpp_add<0x4E, 0xF>(v);
-   v = dpp_add<0x141, 0xF>(v);
-   v = dpp_add<0x140, 0xF>(v);
+   v = dpp_add_all<0xB1>(v);
+   v = dpp_add_all<0x4E>(v);
+   v = dpp_add_all<0x141>(v);
+   v = dpp_add_all<0x140>(v);
    v = dpp_add<0x142, 0xA>(v);
    v = dpp_add<0x143, 0xC>(v);
    return v;
@@ -181,15 +210,16 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
    if (C::WAVE_ALIGNED && C::DR == 2)
    {
       const int lane = tid & 63, wave = tid >> 6;
-      const bool lo = lane < 32;
-      const double v0 = v[0];
-      const double v1 = (tid + C::NT < C::NB * C::D3) ? v[1] : 0.0;
-      // lanes 0..31 gather round 0, lanes 32..63 round 1; then DPP row reductions (VALU, no LDS)
-      double x = (lo ? v0 : v1) + __shfl_xor(lo ? v1 : v0, 32);
-      x = dpp_add<0xB1, 0xF>(x);  // quad_perm [1,0,3,2]
-      x = dpp_add<0x4E, 0xF>(x);  // quad_perm [2,3,0,1]
-      x = dpp_add<0x141, 0xF>(x); // row_half_mirror
-      x = dpp_add<0x140, 0xF>(x); // row_mirror: every lane of a row holds the row total
+      double v0 = v[0];
+      double v1 = (tid + C::NT < C::NB * C::D3) ? v[C::DR == 2 ? 1 : 0] : 0.0;
+      // lanes 0..31 gather round 0, lanes 32..63 round 1 (one half-wave swap); then DPP row reductions
+      // (VALU only, no LDS)
+      swap32(v0, v1);
+      double x = v0 + v1;
+      x = dpp_add_all<0xB1>(x);  // quad_perm [1,0,3,2]
+      x = dpp_add_all<0x4E>(x);  // quad_perm [2,3,0,1]
+      x = dpp_add_all<0x141>(x); // row_half_mirror
+      x = dpp_add_all<0x140>(x); // row_mirror: every lane of a row holds the row total
       x = dpp_add<0x142, 0xA>(x); // row_bcast:15 into rows 1 and 3: half-wave totals
       if (lane == 31) { cur[wave] = x; }
       if (lane == 63 && (C::NT / C::D3 + wave) < C::NB) { cur[C::NT / C::D3 + wave] = x; }

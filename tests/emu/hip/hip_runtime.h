@@ -5,6 +5,7 @@
 // A workgroup is emulated by blockDim.x OS threads that meet at a std::barrier for
 // __syncthreads(); workgroups run one after another.
 #pragma once
+#define HIPEMU 1
 #include <algorithm>
 #include <barrier>
 #include <cmath>
@@ -39,7 +40,7 @@ namespace hipemu
 inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 inline std::barrier<> *g_barrier = nullptr;
 inline std::barrier<> *g_wave_barrier[16] = {nullptr}; // one per wavefront: cross-lane operations only meet their own 64 lanes
-inline unsigned long long g_xchg[1024];
+inline unsigned long long g_xchg[1024], g_xchg2[1024];
 } // namespace hipemu
 
 #define threadIdx (hipemu::t_threadIdx)
@@ -88,6 +89,21 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
    if (((row_mask >> row) & 1) && srclane >= 0) { r = (int)hipemu::g_xchg[base + srclane]; }
    hipemu_wave_sync();
    return r;
+}
+
+// v_permlane32_swap: a = {a[0..31], b[0..31]}, b = {a[32..63], b[32..63]}
+inline void hipemu_permlane32_swap(double &a, double &b)
+{
+   const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane;
+   std::memcpy(&hipemu::g_xchg[t], &a, 8);
+   std::memcpy(&hipemu::g_xchg2[t], &b, 8);
+   hipemu_wave_sync();
+   double na = a, nb = b;
+   if (lane >= 32) { std::memcpy(&na, &hipemu::g_xchg2[base + lane - 32], 8); }
+   else { std::memcpy(&nb, &hipemu::g_xchg[base + lane + 32], 8); }
+   hipemu_wave_sync();
+   a = na;
+   b = nb;
 }
 
 template <typename T>
