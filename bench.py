@@ -15,7 +15,7 @@ itself allows on a device, remhos.cpp:391-397), refined to --rs levels (default 
 56.6 M dofs).  For N > 1 the SAME global mesh is box-partitioned over the ranks (strong scaling);
 each stage does one RCCL neighbour exchange of ghost-element values.
 
-The same JSON line carries `roofline` for the dominant kernel (ho_kernel2, duration from HIP events
+The same JSON line carries `roofline` for the dominant kernel (ho_kernel2<p, 1>, duration from HIP events
 on the kernel's own stream inside the timed region) and `cpu_baseline` (the C++/OpenMP CPU port of
 oracle/ timed on the host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
 """
@@ -160,10 +160,10 @@ def main():
         if st.one_kernel:
             # the dominant kernel is the whole stage: SURVEY 8(d) matrix-free per-dof figure
             ho_bytes = int(stage_alg_bytes_per_dof(args.order) * case.ne_owned * case.ndof)
-            kname = f"ho_kernel2<{args.order},true> (whole RK stage)"
+            kname = f"rmh::ho_kernel2<{args.order}, {3 if args.lo in (3, 4) else 1}> (whole RK stage)"
         else:
             ho_bytes = ho_alg_bytes_per_element(args.order) * case.ne_owned
-            kname = f"ho_kernel2<{args.order},false>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"ho_kernel<{args.order},0>"
+            kname = f"rmh::ho_kernel2<{args.order}, 0>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"rmh::ho_kernel<{args.order}, 0>"
         achieved = ho_bytes / ho_avg_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
