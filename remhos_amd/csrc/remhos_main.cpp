@@ -1,7 +1,7 @@
 // remhos_amd -- command-line front end of the single-GPU driver (rmhd_run), accepting the subset of
 // the reference's flags that select the hot path (remhos.cpp:249-334) and printing the same report
 // lines (remhos.cpp:1423-1428, 1938-1952):
-//   remhos_amd -m periodic-cube -p 10 -rs 4 -o 3 -dt -1 -tf 0.5 -ms 20 -ho 3 -lo 5 -fct 2 -pa
+//   remhos_amd -m periodic-cube -p 10 -rs 4 -o 3 -dt -1 -tf 0.5 -ms 20 -ho 3 -lo 5 -fct 2 -pa [-bt 1 -dtc 1]
 #include "../../include/rmh_driver.h"
 
 #include <cstdio>
@@ -40,16 +40,19 @@ int main(int argc, char **argv)
       else if (a == "-lo") { c.lo_type = std::atoi(next()); }
       else if (a == "-ho") { ho = std::atoi(next()); }
       else if (a == "-fct") { fct = std::atoi(next()); }
+      else if (a == "-bt") { c.bounds_type = std::atoi(next()); }
+      else if (a == "-dtc") { c.dt_control = std::atoi(next()); }
       else if (a == "-unfused") { c.fused = 0; }
       else if (a == "-pa" || a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { if (std::atoi(next()) != 3) { std::fprintf(stderr, "only -s 3 (RK3 SSP)\n"); return 3; } }
       else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
    }
-   if (ho != 3 || fct != 2 || (c.lo_type != 4 && c.lo_type != 5))
+   if ((ho != 2 && ho != 3) || fct != 2 || c.lo_type < 3 || c.lo_type > 5)
    {
-      std::fprintf(stderr, "remhos_amd implements -ho 3, -lo 4|5, -fct 2 (the hot path of SURVEY.md section 8)\n");
+      std::fprintf(stderr, "remhos_amd implements -ho 2|3, -lo 3|4|5, -fct 2, -bt 0|1, -dtc 0|1 (the hot path of SURVEY.md section 8)\n");
       return 1;
    }
+   c.ho_type = ho;
    rmhd_result r;
    if (rmhd_run(&c, &r) != 0)
    {
@@ -58,6 +61,7 @@ int main(int argc, char **argv)
    }
    std::printf("Number of unknowns: %lld\n", r.global_dofs);
    std::printf("time step: %d, time: %.8g, dt: %.8g\n", r.steps, r.t_end, r.dt);
+   if (c.dt_control) { std::printf("Total time steps: %d (%d repeated).\n", r.steps + r.repeats, r.repeats); } // remhos.cpp:1350-1354
    std::printf("---\nRHS   kernel time: %.8g\nL2inv kernel time: %.8g\nLO    kernel time: %.8g\nFCT   kernel time: %.8g\n"
                "Total kernel time: %.8g\n---\n", r.t_rhs, r.t_inv, r.t_lo, r.t_fct, r.t_total);
    std::printf("FOM RHS: %.8g\nFOM INV: %.8g\nFOM LO:  %.8g\nFOM FCT: %.8g\nFOM:     %.8g\n"
