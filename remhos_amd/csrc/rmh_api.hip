@@ -181,7 +181,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    if (MODE == 2 && c->ho_variant == 2 && P >= 2)
    {
       constexpr int NB = K2Cfg<P, true>::NB;
-      hipLaunchKernelGGL((ho_kernel2<(P >= 2 ? P : 2), 2>), dim3((c->ne + NB - 1) / NB), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((ho_kernel2<(P >= 2 ? P : 2), 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P, true>::NT), 0, c->stream, a);
    }
    else if (MODE == 0 && c->ho_variant == 2)
    {
@@ -245,7 +245,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    {
       constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
       constexpr int NB = K2Cfg<P4, true, true>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3((e_end - e_begin + NB - 1) / NB), dim3(256), 0, c->stream, a);
+      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3((e_end - e_begin + NB - 1) / NB), dim3(K2Cfg<P4, true, true>::NT), 0, c->stream, a);
    }
    else
    {

@@ -36,15 +36,27 @@ struct K2Cfg : TabLayout<P>
    using T = TabLayout<P>;
    static constexpr int D = T::D, Q = T::Q;
    static constexpr int D2 = D * D, D3 = D * D * D, Q2 = Q * Q;
-   static constexpr int NT = 256;
+   // threads per workgroup: 256 (4 wavefronts, one per SIMD) -- 128 where the registers allow only 2 wavefronts per
+   // SIMD anyway (p = 6: 233 VGPRs): twice as many, half as large workgroups synchronise 2 instead of 4 wavefronts at
+   // each barrier (p = 6, -rs 4: 6.45 k -> 6.9 k MDOFs*stage/s; p = 4: 9.7 k -> 10.1 k; p = 5: no change, kept at 256)
+#ifndef RMH_NT6
+#define RMH_NT6 128
+#endif
+#ifndef RMH_NT5
+#define RMH_NT5 256
+#endif
+#ifndef RMH_NT4
+#define RMH_NT4 128
+#endif
+   static constexpr int NT = (P == 6) ? RMH_NT6 : (P == 5 ? RMH_NT5 : (P == 4 ? RMH_NT4 : 256));
 #ifndef RMH_NB6
-#define RMH_NB6 2
+#define RMH_NB6 1
 #endif
 #ifndef RMH_NB5
 #define RMH_NB5 4
 #endif
 #ifndef RMH_NB4
-#define RMH_NB4 4
+#define RMH_NB4 2
 #endif
    // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
    // footprint would otherwise limit the CU to one workgroup (measured per order)
@@ -100,7 +112,9 @@ struct K2Cfg : TabLayout<P>
    // 6.3 k vs 8.6 k MDOFs*stage/s); 2 KiB granules are consistent with that
    static constexpr int LDS_BYTES = (8 * LDS_DOUBLES + 2047) / 2048 * 2048;
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
-   static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 4 ? 4 : (160 * 1024) / LDS_BYTES);
+   static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 1024 / NT ? 1024 / NT : (160 * 1024) / LDS_BYTES);
+   // launch bound: wavefronts per SIMD that the LDS budget admits (a workgroup has NT / 64 wavefronts on 4 SIMDs)
+   static constexpr int WAVES_PER_SIMD = cmax(1, WG_PER_CU * (NT / 64) / 4);
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
@@ -329,7 +343,7 @@ __device__ unsigned long long g_stamps[32];
 template <int P, int MODE>
 // MODE 3        : the whole RK stage for -ho 3 -lo 4 -fct 2: MODE 0 + MODE 2 + overlap bounds + ClipScale + RK
 //                 update in one kernel (geometry, face data and u-contractions shared by HO and RD).
-__global__ void __launch_bounds__(256, (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WG_PER_CU)) ho_kernel2(HoArgs a)
+__global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WAVES_PER_SIMD)) ho_kernel2(HoArgs a)
 {
    constexpr bool FUSED = MODE == 1 || MODE == 3; // limiter + RK update at the end
    constexpr bool LO4 = MODE >= 2;                // subcell residual distribution pieces
