@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6  # vendor FP64 vector peak of MI355X (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz); tools/ubench_fp64.hip sustains 60.5
 PART = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 
 
@@ -165,15 +166,23 @@ def main():
             ho_bytes = ho_alg_bytes_per_element(args.order) * case.ne_owned
             kname = f"rmh::ho_kernel2<{args.order}, 0>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"rmh::ho_kernel<{args.order}, 0>"
         achieved = ho_bytes / ho_avg_s / 1e9
-        traffic = None
+        traffic, fp64 = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.mesh}-rs{args.rs}-o{args.order}-n{args.gpus}" + ("-stage" if st.one_kernel else "")
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                ent = tj.get(key, {}) if args.lo == 5 else {}
+                traffic = ent.get("hbm_bytes_per_launch")
+                wi = ent.get("fp64_wave_insts_per_launch")
+                if wi:
+                    # the kernel's real bound: FP64 VALU.  Issued lane-flops = wave64 instructions x 64 lanes x (2 for FMA)
+                    flops = 64.0 * (2.0 * wi["fma"] + wi["mul"] + wi["add"])
+                    fp64 = {"bound": "fp64 valu", "flops_per_launch": flops, "achieved": flops / ho_avg_s / 1e12,
+                            "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / ho_avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                            "fp64_share_of_valu_insts": (wi["fma"] + wi["mul"] + wi["add"]) / wi["all_valu"]}
             except Exception:
-                traffic = None
+                traffic, fp64 = None, None
         out = {
             "metric": "MDOFs*RK-stage/s, 3D hex remap",
             "value": value,
@@ -212,6 +221,7 @@ def main():
                 "alg_bytes_per_launch": ho_bytes,
                 "note": "FP64 VALU / latency bound at p=3 in matrix-free form (geometry recomputed per stage), not HBM bound; see DESIGN.md 3.1",
             },
+            "roofline_fp64": fp64,
             "buckets_s": {"ho_rhs_plus_inv_or_stage": tim[0], "lo": tim[2], "fct_or_fused_limiter": tim[3]},
             "stage_roofline": {
                 "alg_bytes_per_dof": stage_alg_bytes_per_dof(args.order),

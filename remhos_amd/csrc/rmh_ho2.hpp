@@ -48,7 +48,10 @@ struct K2Cfg : TabLayout<P>
 #ifndef RMH_NT4
 #define RMH_NT4 128
 #endif
-   static constexpr int NT = (P == 6) ? RMH_NT6 : (P == 5 ? RMH_NT5 : (P == 4 ? RMH_NT4 : 256));
+#ifndef RMH_NT3
+#define RMH_NT3 256
+#endif
+   static constexpr int NT = (P == 6) ? RMH_NT6 : (P == 5 ? RMH_NT5 : (P == 4 ? RMH_NT4 : (P == 3 ? RMH_NT3 : 256)));
 #ifndef RMH_NB6
 #define RMH_NB6 1
 #endif
@@ -114,7 +117,11 @@ struct K2Cfg : TabLayout<P>
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
    static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 1024 / NT ? 1024 / NT : (160 * 1024) / LDS_BYTES);
    // launch bound: wavefronts per SIMD that the LDS budget admits (a workgroup has NT / 64 wavefronts on 4 SIMDs)
-   static constexpr int WAVES_PER_SIMD = cmax(1, WG_PER_CU * (NT / 64) / 4);
+#ifndef RMH_MAXW
+#define RMH_MAXW 8
+#endif
+   static constexpr int WAVES_PER_SIMD0 = cmax(1, WG_PER_CU * (NT / 64) / 4);
+   static constexpr int WAVES_PER_SIMD = WAVES_PER_SIMD0 > RMH_MAXW ? RMH_MAXW : WAVES_PER_SIMD0;
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
