@@ -31,6 +31,7 @@ typedef struct {
    int bounds_type;   /* -bt : 0 overlap bounds, 1 face-neighbour bounds                        */
    int dt_control;    /* -dtc: 0 fixed dt, 1 LOBoundsError (needs -bt 1; remhos.cpp:1178-1197)  */
    int ho_type;       /* -ho : 3 local inverse (0 means 3), 2 CG to rel. tolerance 1e-12        */
+   int save;          /* -save: write meshHO_init/final.mesh and sltn_init/final.gf (cwd)        */
 } rmhd_config;
 
 typedef struct {
@@ -61,6 +62,12 @@ const long long *rmhd_case_ghost_gid(const rmhd_case *c);
 /* k-th neighbour rank of the halo exchange: owned elements it needs / ghost slots it fills */
 int rmhd_case_peer(const rmhd_case *c, int k, int *rank, int *nsend, const int **send_elems,
                    int *nrecv, const int **recv_slots);
+
+/* -save (remhos.cpp:1015-1030, 1365-1380): write the mesh at pseudo-time t (remap: x0 + t * v) as an "MFEM mesh
+ * v1.0" file with L2 Gauss-Lobatto order-2 nodes and, when u (HOST pointer, [ne][ndof]) and gf_path are given, the
+ * field as an MFEM GridFunction file (L2_T2_3D_P<order>, the positive basis of remhos.cpp:588-590).  Elements are
+ * written in lattice order (global id).  Single-rank cases only (PrintAsOne / SaveAsOne).  0 on success. */
+int rmhd_case_save(const rmhd_case *c, double t, const double *u, const char *mesh_path, const char *gf_path);
 
 typedef struct {
    double final_mass, max_value, mass0, mass_loss; /* remhos.cpp:1423-1428 */

@@ -23,7 +23,7 @@ class RmhdConfig(C.Structure):
         ("mesh", C.c_char * 32), ("rs", C.c_int), ("order", C.c_int), ("problem", C.c_int),
         ("dt", C.c_double), ("t_final", C.c_double), ("max_steps", C.c_int), ("lo_type", C.c_int),
         ("fused", C.c_int), ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int), ("rank", C.c_int),
-        ("bounds_type", C.c_int), ("dt_control", C.c_int), ("ho_type", C.c_int),
+        ("bounds_type", C.c_int), ("dt_control", C.c_int), ("ho_type", C.c_int), ("save", C.c_int),
     ]
 
 
@@ -48,14 +48,14 @@ class RmhdResult(C.Structure):
 
 
 def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=-1, lo_type=5,
-                fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0, ho_type=3) -> RmhdConfig:
+                fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0, ho_type=3, save=0) -> RmhdConfig:
     c = RmhdConfig()
     c.mesh = mesh.encode()
     c.rs, c.order, c.problem = rs, order, problem
     c.dt, c.t_final, c.max_steps, c.lo_type, c.fused = dt, t_final, max_steps, lo_type, fused
     c.px, c.py, c.pz = part
     c.rank = rank
-    c.bounds_type, c.dt_control, c.ho_type = bounds_type, dt_control, ho_type
+    c.bounds_type, c.dt_control, c.ho_type, c.save = bounds_type, dt_control, ho_type, save
     return c
 
 
@@ -67,6 +67,7 @@ def bind_driver(lib: C.CDLL) -> C.CDLL:
     lib.rmhd_case_destroy.restype = None
     lib.rmhd_last_error.restype = C.c_char_p
     lib.rmhd_case_get_info.argtypes = [p, C.POINTER(RmhdCaseInfo)]
+    lib.rmhd_case_save.argtypes = [p, C.c_double, p, C.c_char_p, C.c_char_p]
     for name in ("x0", "vel", "u0", "subcell_vel", "face_nbr", "stencil27", "owned_gid", "ghost_gid"):
         f = getattr(lib, "rmhd_case_" + name)
         f.argtypes = [p]
@@ -127,3 +128,17 @@ class Case:
             lib.rmhd_case_peer(h, k, C.byref(rank), C.byref(ns), C.byref(ps), C.byref(nr), C.byref(pr))
             self.peers.append((rank.value, _view(ps.value, (ns.value,), np.int32), _view(pr.value, (nr.value,), np.int32)))
         lib.rmhd_case_destroy(h)
+        self._lib = lib
+
+    def save(self, t, u, mesh_path, gf_path=None):
+        """-save (remhos.cpp:1015-1030, 1365-1380): MFEM mesh at pseudo-time t (+ GridFunction of the host array u)."""
+        lib = self._lib
+        h = lib.rmhd_case_create(C.byref(self.cfg))
+        try:
+            uu = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+            rc = lib.rmhd_case_save(h, float(t), None if uu is None else uu.ctypes.data, str(mesh_path).encode(),
+                                    None if gf_path is None else str(gf_path).encode())
+            if rc != 0:
+                raise RuntimeError("rmhd_case_save: " + lib.rmhd_last_error().decode())
+        finally:
+            lib.rmhd_case_destroy(h)

@@ -42,6 +42,7 @@ int main(int argc, char **argv)
       else if (a == "-fct") { fct = std::atoi(next()); }
       else if (a == "-bt") { c.bounds_type = std::atoi(next()); }
       else if (a == "-dtc") { c.dt_control = std::atoi(next()); }
+      else if (a == "-save") { c.save = 1; }
       else if (a == "-unfused") { c.fused = 0; }
       else if (a == "-pa" || a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { if (std::atoi(next()) != 3) { std::fprintf(stderr, "only -s 3 (RK3 SSP)\n"); return 3; } }

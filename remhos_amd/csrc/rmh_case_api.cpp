@@ -3,6 +3,7 @@
 #include "rmh_host.hpp"
 
 #include <cstring>
+#include <cstdio>
 #include <string>
 
 struct rmhd_case
@@ -99,6 +100,19 @@ int rmhd_case_peer(const rmhd_case *c, int k, int *rank, int *nsend, const int *
    *send_elems = p.send_elems.data();
    *nrecv = (int)p.recv_slots.size();
    *recv_slots = p.recv_slots.data();
+   return 0;
+}
+
+// -save (remhos.cpp:1015-1030, 1365-1380): the mesh at pseudo-time t and a DG field in MFEM's text formats
+// ("MFEM mesh v1.0" with a nodal GridFunction, and a GridFunction file), so that a run can be opened in GLVis
+// or diffed against meshHO_*.mesh / sltn_*.gf of a Remhos run elsewhere.  The mesh nodes are written as an L2
+// (element-wise, Gauss-Lobatto = closed uniform at order 2) vector field for both meshes -- what the reference
+// itself uses for the periodic ones (remhos.cpp:505-519); elements keep the lattice numbering (x fastest).
+int rmhd_case_save(const rmhd_case *c, double t, const double *u, const char *mesh_path, const char *gf_path)
+{
+   if (!c) { return -1; }
+   const std::string err = remhos::save_mfem(c->d, t, u, mesh_path, gf_path);
+   if (!err.empty()) { remhos::g_driver_error = err; return -1; }
    return 0;
 }
 

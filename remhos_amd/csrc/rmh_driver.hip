@@ -328,6 +328,12 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       double mass0 = 0.0;
       for (int i = 0; i < vsize; i++) { mass0 += h_m[i] * cd.u0[i]; }
 
+      // Print the starting mesh and initial condition (remhos.cpp:1015-1030)
+      if (cfg->save)
+      {
+         const std::string e = save_mfem(cd, 0.0, cd.u0.data(), "meshHO_init.mesh", "sltn_init.gf");
+         RMH_VERIFY(e.empty(), e.c_str());
+      }
       RK3SSPSolver ode_solver;
       double t = 0.0;
       adv.SetTime(t);
@@ -396,6 +402,12 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
          masses.CopyToHost(h_m.data());
       }
       u.CopyToHost(h_u.data());
+      // Print the final mesh and solution (remhos.cpp:1365-1380)
+      if (cfg->save)
+      {
+         const std::string e = save_mfem(cd, t, h_u.data(), "meshHO_final.mesh", "sltn_final.gf");
+         RMH_VERIFY(e.empty(), e.c_str());
+      }
       double mass = 0.0, umax = -INFINITY;
       for (int i = 0; i < vsize; i++)
       {

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <functional>
 #include <cstring>
 #include <map>
@@ -536,5 +537,84 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    }
    return "";
 }
+
+// -save (remhos.cpp:1015-1030, 1365-1380): see include/rmh_driver.h (rmhd_case_save)
+std::string save_mfem(const CaseData &d, double t, const double *u, const char *mesh_path, const char *gf_path)
+{
+   if (!mesh_path) { return "null mesh path"; }
+   if ((long long)d.ne_owned != d.ne_global)
+   {
+      return "rmhd_case_save writes the mesh of a single-rank case (PrintAsOne / SaveAsOne)";
+   }
+   const int N[3] = {d.n[0], d.n[1], d.n[2]};
+   const bool per = d.periodic;
+   const int nv1[3] = {per ? N[0] : N[0] + 1, per ? N[1] : N[1] + 1, per ? N[2] : N[2] + 1};
+   auto vid = [&](int ix, int iy, int iz)
+   {
+      if (per) { ix %= N[0]; iy %= N[1]; iz %= N[2]; }
+      return ix + nv1[0] * (iy + (long long)nv1[1] * iz);
+   };
+   FILE *f = std::fopen(mesh_path, "w");
+   if (!f) { return std::string("cannot open ") + mesh_path; }
+   std::fprintf(f, "MFEM mesh v1.0\n\ndimension\n3\n\nelements\n%d\n", d.ne_owned);
+   for (int e = 0; e < d.ne_owned; e++)
+   {
+      const long long g = d.owned_gid[e];
+      const int ex = (int)(g % N[0]), ey = (int)((g / N[0]) % N[1]), ez = (int)(g / ((long long)N[0] * N[1]));
+      // geometry 5 = CUBE; vertex order of mfem::Hexahedron
+      std::fprintf(f, "1 5 %lld %lld %lld %lld %lld %lld %lld %lld\n", vid(ex, ey, ez), vid(ex + 1, ey, ez),
+                   vid(ex + 1, ey + 1, ez), vid(ex, ey + 1, ez), vid(ex, ey, ez + 1), vid(ex + 1, ey, ez + 1),
+                   vid(ex + 1, ey + 1, ez + 1), vid(ex, ey + 1, ez + 1));
+   }
+   if (per) { std::fprintf(f, "\nboundary\n0\n"); }
+   else
+   {
+      std::fprintf(f, "\nboundary\n%d\n", 2 * (N[0] * N[1] + N[1] * N[2] + N[0] * N[2]));
+      // geometry 3 = SQUARE, attributes 1..6 by side (-x, +x, -y, +y, -z, +z), outward orientation
+      for (int j = 0; j < N[2]; j++) { for (int i = 0; i < N[1]; i++) {
+         std::fprintf(f, "1 3 %lld %lld %lld %lld\n", vid(0, i, j), vid(0, i, j + 1), vid(0, i + 1, j + 1), vid(0, i + 1, j));
+         std::fprintf(f, "2 3 %lld %lld %lld %lld\n", vid(N[0], i, j), vid(N[0], i + 1, j), vid(N[0], i + 1, j + 1), vid(N[0], i, j + 1)); } }
+      for (int j = 0; j < N[2]; j++) { for (int i = 0; i < N[0]; i++) {
+         std::fprintf(f, "3 3 %lld %lld %lld %lld\n", vid(i, 0, j), vid(i + 1, 0, j), vid(i + 1, 0, j + 1), vid(i, 0, j + 1));
+         std::fprintf(f, "4 3 %lld %lld %lld %lld\n", vid(i, N[1], j), vid(i, N[1], j + 1), vid(i + 1, N[1], j + 1), vid(i + 1, N[1], j)); } }
+      for (int j = 0; j < N[1]; j++) { for (int i = 0; i < N[0]; i++) {
+         std::fprintf(f, "5 3 %lld %lld %lld %lld\n", vid(i, j, 0), vid(i, j + 1, 0), vid(i + 1, j + 1, 0), vid(i + 1, j, 0));
+         std::fprintf(f, "6 3 %lld %lld %lld %lld\n", vid(i, j, N[2]), vid(i + 1, j, N[2]), vid(i + 1, j + 1, N[2]), vid(i, j + 1, N[2])); } }
+   }
+   std::fprintf(f, "\nvertices\n%lld\n\nnodes\nFiniteElementSpace\nFiniteElementCollection: L2_T1_3D_P2\nVDim: 3\nOrdering: 0\n\n",
+                (long long)nv1[0] * nv1[1] * nv1[2]);
+   // Ordering 0 = byNODES: all x components (element by element, 27 nodes, x fastest), then y, then z.
+   // Elements are written in lattice order: position k of the file is the element with global id k.
+   std::vector<int> local_of_gid(d.ne_owned);
+   for (int e = 0; e < d.ne_owned; e++) { local_of_gid[d.owned_gid[e]] = e; }
+   for (int comp = 0; comp < 3; comp++)
+   {
+      for (int g = 0; g < d.ne_owned; g++)
+      {
+         const int e = local_of_gid[g];
+         for (int a = 0; a < 27; a++)
+         {
+            const size_t k = (size_t)e * 81 + comp * 27 + a;
+            std::fprintf(f, "%.14g\n", d.x0[k] + (d.exec_mode == 1 ? t * d.vel[k] : 0.0));
+         }
+      }
+   }
+   std::fclose(f);
+   if (u && gf_path)
+   {
+      f = std::fopen(gf_path, "w");
+      if (!f) { return std::string("cannot open ") + gf_path; }
+      // DG_FECollection(order, dim, BasisType::Positive) (remhos.cpp:588-590): basis type 2
+      std::fprintf(f, "FiniteElementSpace\nFiniteElementCollection: L2_T2_3D_P%d\nVDim: 1\nOrdering: 0\n\n", d.order);
+      for (int g = 0; g < d.ne_owned; g++)
+      {
+         const int e = local_of_gid[g];
+         for (int i = 0; i < d.ndof; i++) { std::fprintf(f, "%.14g\n", u[(size_t)e * d.ndof + i]); }
+      }
+      std::fclose(f);
+   }
+   return "";
+}
+
 
 } // namespace remhos

@@ -59,5 +59,7 @@ double u0_function(int problem, const double *bb_min, const double *bb_max, cons
 
 // returns an empty string on success, an error message otherwise
 std::string build_case(const CaseConfig &cfg, CaseData &out);
+// MFEM text formats of the mesh at pseudo-time t and of a DG field (host pointer); "" on success
+std::string save_mfem(const CaseData &d, double t, const double *u, const char *mesh_path, const char *gf_path);
 
 } // namespace remhos

@@ -82,3 +82,46 @@ def test_bad_config_is_reported(lib):
         Case(lib, make_config("star-q2", 1, 2, 10))
     with pytest.raises(RuntimeError, match="order"):
         Case(lib, make_config("cube01_hex", 1, 9, 10))
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob", [("periodic-cube", 0, 2, 0), ("cube01_hex", 1, 3, 10)])
+def test_save_writes_mfem_mesh_and_gridfunction(lib, tmp_path, mesh, rs, p, prob):
+    """-save: the MFEM mesh v1.0 / GridFunction text files parse back to the case's topology, node positions at
+    pseudo-time t and field values (what remhos.cpp:1015-1030 writes with PrintAsOne / SaveAsOne)."""
+    c = Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5))
+    t = 0.25
+    mp, gp = tmp_path / "meshHO.mesh", tmp_path / "sltn.gf"
+    c.save(t, c.u0, mp, gp)
+    tok = mp.read_text().split()
+    assert tok[:3] == ["MFEM", "mesh", "v1.0"] and tok[tok.index("dimension") + 1] == "3"
+    ie = tok.index("elements")
+    ne = int(tok[ie + 1])
+    assert ne == c.ne_owned
+    el = np.array(tok[ie + 2: ie + 2 + 10 * ne], dtype=np.int64).reshape(ne, 10)
+    assert (el[:, 1] == 5).all()  # Geometry::CUBE
+    ib = tok.index("boundary")
+    nb = int(tok[ib + 1])
+    periodic = mesh.startswith("periodic")
+    n1 = round(ne ** (1 / 3))
+    assert nb == (0 if periodic else 6 * n1 * n1)
+    iv = tok.index("vertices")
+    nv = int(tok[iv + 1])
+    assert nv == (n1 ** 3 if periodic else (n1 + 1) ** 3)
+    assert el[:, 2:].min() == 0 and el[:, 2:].max() == nv - 1
+    # each element has 8 distinct vertices; every vertex is used by 8 elements (periodic) / at most 8
+    assert all(len(set(r)) == 8 for r in el[:, 2:])
+    counts = np.bincount(el[:, 2:].ravel(), minlength=nv)
+    assert counts.max() == 8 and (counts.min() == 8 if periodic else counts.min() == 1)
+    inod = tok.index("nodes")
+    assert tok[inod + 1: inod + 8] == ["FiniteElementSpace", "FiniteElementCollection:", "L2_T1_3D_P2", "VDim:", "3", "Ordering:", "0"]
+    vals = np.array(tok[inod + 8:], dtype=np.float64).reshape(3, ne, 27)
+    x_t = c.x0 + (t * c.vel if c.exec_mode == 1 else 0.0)  # [ne][3][27]
+    order = np.argsort(c.owned_gid)
+    assert np.allclose(vals, x_t[order].transpose(1, 0, 2), rtol=1e-13, atol=1e-13)
+    g = gp.read_text().split()
+    assert g[:7] == ["FiniteElementSpace", "FiniteElementCollection:", f"L2_T2_3D_P{p}", "VDim:", "1", "Ordering:", "0"]
+    assert np.allclose(np.array(g[7:], dtype=np.float64).reshape(ne, -1), c.u0[order], rtol=1e-13, atol=1e-13)
+    # multi-rank blocks are refused
+    c2 = Case(lib, make_config(mesh, max(rs, 1), p, prob, -1.0, 0.5, part=(2, 1, 1), rank=0))
+    with pytest.raises(RuntimeError, match="single-rank"):
+        c2.save(t, None, tmp_path / "x.mesh")
