@@ -4,6 +4,9 @@ Sources (paths in the reference checkout):
   autotest/out_baseline.dat:41-69   (-ho 3 -lo 4 -fct 2; mass and max at 10 digits)
   remhos_tests.cpp:38-107           (-ho 3 -lo 5 -fct 2; final mass at 17 digits, AlmostEq 10 eps)
 """
+import json
+import os
+
 import pytest
 
 from oracle.remhos_oracle import Config, Remhos
@@ -18,22 +21,17 @@ def _r10(x):
     return float(f"{x:.10g}")
 
 
-AUTOTEST = [
-    # -lo 3 (plain residual distribution; the reference ran these with -ho 2 = CG to 1e-12, out_baseline.dat:76-111)
-    ("periodic-cube transport -lo 3 (:100-103)", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo=3),
-     0.9607429525, 0.9202929163),
-    ("cube01_hex remap -lo 3 (:83-86)", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo=3),
-     0.1197300033, 0.9997879406),
-    # name, kwargs, Final mass u, Max value u  (autotest/out_baseline.dat)
-    ("periodic-cube transport (:66-69)", dict(mesh="periodic-cube", rs=1, order=2, problem=0, dt=0.015, t_final=2.0, lo=4),
-     0.9607429525, 0.9334903111),
-    ("cube01_hex remap (:46-49)", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo=4),
-     0.1197299801, 0.9997499683),
-    ("periodic-square balls-jacks (:61-64)", dict(mesh="periodic-square", rs=3, order=3, problem=5, dt=0.004, t_final=0.8, lo=4),
-     0.1623263888, 0.7145371968),
-    ("inline-quad remap pacman (:41-44)", dict(mesh="inline-quad", rs=1, order=3, problem=14, dt=0.0015, t_final=0.75, lo=4),
-     0.0847954729, 0.7581364675),
-]
+KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kat.json")))
+
+
+def _kw(e):
+    """fixture entry -> oracle Config arguments (-ho 2 = CG to 1e-12 equals the oracle's exact local solve to its tolerance)"""
+    kw = {k: e[k] for k in ("mesh", "rs", "order", "problem", "dt", "t_final", "lo", "fct", "bounds_type", "dt_control", "max_steps") if k in e}
+    return kw
+
+
+AUTOTEST = [(e["name"] + " (" + e["source"].split(":")[-1] + ")", _kw(e), e["mass"], e["max"])
+            for e in KAT["autotest"] if e.get("fct", 2) == 2 and (e["ho"] == 3 or e["lo"] == 3)]  # (-ho 2 -lo 4 repeats -ho 3 -lo 4 here)
 
 
 def test_bounds_type_1_and_dt_control():
@@ -55,21 +53,8 @@ def test_autotest_baseline(name, kw, mass, umax):
     assert _r10(out["max"]) == umax
 
 
-CTEST = [
-    ("ctest0 inline-quad rs1 o2", dict(mesh="inline-quad", rs=1, order=2, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
-     0.09711395400387984, 1e-14),
-    ("ctest1 inline-quad rs4 o3", dict(mesh="inline-quad", rs=4, order=3, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
-     0.0930984399257905, 1e-14),
-    ("ctest2 inline-quad rs4 o4", dict(mesh="inline-quad", rs=4, order=4, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
-     0.09237630484178257, 1e-14),
-    ("ctest3 cube01_hex rs1 o2", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
-     0.11972857593296446, 1e-14),
-    ("ctest5 inline-quad -pa rs4 o2", dict(mesh="inline-quad", rs=4, order=2, problem=14, dt=-1.0, t_final=0.5, lo=5, max_steps=5),
-     0.09185717760402806, 1e-14),
-    # the PA reference solves the local mass systems by CG; the oracle's exact solve agrees to 1.4e-14
-    ("ctest7 cube01_hex -pa rs3 o3", dict(mesh="cube01_hex", rs=3, order=3, problem=10, dt=-1.0, t_final=0.5, lo=5, max_steps=1),
-     0.11601536511552431, 5e-13),
-]
+# the PA reference solves the local mass systems by CG; the oracle's exact solve agrees to 1.4e-14 (ctest7)
+CTEST = [(e["name"], _kw(e), e["mass"], 5e-13 if e["name"].startswith("ctest7") else 1e-14) for e in KAT["ctest"]]
 
 
 @pytest.mark.parametrize("name,kw,mass,rtol", CTEST, ids=[c[0] for c in CTEST])
