@@ -1395,6 +1395,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       __syncthreads();
    }
+   RMH_STAMP(16);
    int itmax = 0;
 #pragma unroll
    for (int r = 0; r < DR; r++) { itmax = max(itmax, its[r]); }
@@ -1431,12 +1432,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             RMH_W(k / 27)[27 + k % 27] = shi[j];
          }
       }
+      RMH_STAMP(21);
       // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
       double mass[DR], vol[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + a.dt * xg[r]); }
       batch_dot<C>(tmp, mass, lds, s_acc, ring);
+      RMH_STAMP(22);
       batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
+      RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];
       double dtc = INFINITY; // UpdateTimeStepEstimate(u, du_LO, u_min, u_max), remhos.cpp:1839-1842
 #pragma unroll
@@ -1467,9 +1471,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          dtc = wave_minmax<true>(dtc);
          if ((tid & 63) == 63) { atomic_min_nonneg(a.dt_est, dtc); }
       }
+      RMH_STAMP(18);
       double sumPos[DR], sumNeg[DR];
       batch_dot<C>(pos, sumPos, lds, s_acc, ring);
       batch_dot<C>(neg, sumNeg, lds, s_acc, ring);
+      RMH_STAMP(19);
       double ynew[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -1491,6 +1497,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
          }
       }
+      RMH_STAMP(20);
       // element extrema of the new state
       if (C::WAVE_ALIGNED)
       {

@@ -10,7 +10,7 @@ lib = bind_driver(load_library(os.path.join("remhos_amd", "librmh_stamps.so")))
 rs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 maxit = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-nb = {1: 32, 2: 16, 3: 7, 4: 4, 5: 4, 6: 2}[order]
+nb = {1: 32, 2: 16, 3: 7, 4: 2, 5: 4, 6: 1}[order]
 st = Stepper(lib, Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5)), device="cuda:0")
 st.ctx.set_mass_tol(1e-14, 0.0, maxit) if maxit > 0 else st.ctx.set_mass_tol(1.0)
 for _ in range(2): st.step(st.dt)
@@ -20,9 +20,9 @@ lib.rmh_debug_stamps(buf, 1)
 for _ in range(4): st.step(st.dt)
 torch.cuda.synchronize()
 lib.rmh_debug_stamps(buf, 0)
-names = {10: "I: sA write+barrier+flag", 11: "I: x-leg", 12: "I: column", 13: "I: y-back", 14: "I: dot1+update", 15: "I: dot2", 0: "A loads", 1: "B T1+U1 pencils", 2: "B face rows", 3: "C column", 4: "F y-leg", 5: "G dof x-leg+faces", 6: "I PCG total(excl. split)", 7: "J back+stores", 8: "I: x-back", 9: "I: tail update/loop"}
-tot = sum(buf[k] for k in range(16))
+names = {10: "I: sA write+barrier+flag", 11: "I: x-leg", 12: "I: column", 13: "I: y-back", 14: "I: dot1+update", 15: "I: dot2", 0: "A loads", 1: "B T1+U1 pencils", 2: "B face rows", 3: "C column", 4: "F y-leg", 5: "G dof x-leg+faces", 6: "I PCG total(excl. split)", 7: "J back+stores", 8: "I: x-back", 9: "I: tail update/loop", 16: "J: back-transform", 21: "K: stencil -> LDS", 22: "K: mass dot", 17: "K: vol dot", 18: "K: bounds + clip", 19: "K: pos/neg dots", 20: "K: scale + stores", 7: "K: extrema + end"}
+tot = sum(buf[k] for k in range(24))
 nblk = 12 * ((st.case.ne_owned + nb - 1) // nb)
-for k in range(16):
+for k in [k for k in range(24) if k in names]:
     print(f"{names[k]:28s} {buf[k]/nblk:10.0f} cycles/WG  {100.0*buf[k]/tot:5.1f}%")
 print("total per WG", tot / nblk)
