@@ -197,8 +197,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.mesh} -rs {args.rs} -o {args.order} -p {args.problem} remap, -pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP "
-                            f"(BASELINE configs[1]); {case.ne_global} hex, {global_dofs} dofs",
+                "workload": f"{args.mesh} -rs {args.rs} -o {args.order} -p {args.problem} {'remap' if args.problem >= 10 else 'transport'}, "
+                            f"-pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP"
+                            + (" (BASELINE configs[1])" if (args.mesh, args.order, args.problem, args.lo) == ("periodic-cube", 3, 10, 5) else "")
+                            + f"; {case.ne_global} hex, {global_dofs} dofs",
                 "global_dofs": global_dofs,
                 "elements": case.ne_global,
                 "partition": "x".join(str(k) for k in PART[args.gpus]),
