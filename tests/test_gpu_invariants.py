@@ -1,5 +1,6 @@
 """Size-independent properties of the stage at BASELINE.json's full single-GPU size (configs[1]:
-periodic-cube remap, p = 3, -rs 4: 110 592 hex, 7.08 M dofs) and degenerate inputs.
+periodic-cube remap, p = 3, -rs 4: 110 592 hex, 7.08 M dofs; the bench's -rs 5: 56.6 M dofs; p = 6 -rs 3) and
+degenerate inputs.
 
 The oracle cannot run this size in seconds, so the checks are the invariants the scheme guarantees
 (remhos_fct.hpp:69-72): bounds preservation  u_min_i <= u_i + dt du_i <= u_max_i  and conservation
@@ -23,7 +24,9 @@ def env():
     return torch, bind_driver(load_library())
 
 
-@pytest.mark.parametrize("mesh,rs,p,prob", [("periodic-cube", 4, 3, 10), ("cube01_hex", 4, 2, 10), ("periodic-cube", 3, 3, 0)])
+@pytest.mark.parametrize("mesh,rs,p,prob", [("periodic-cube", 4, 3, 10), ("cube01_hex", 4, 2, 10), ("periodic-cube", 3, 3, 0),
+                                            ("periodic-cube", 5, 3, 10),  # the bench workload itself: 884 736 hex, 56.6 M dofs
+                                            ("periodic-cube", 3, 6, 10)])
 def test_full_size_invariants(env, mesh, rs, p, prob):
     torch, lib = env
     from remhos_amd.case import Case, make_config
