@@ -294,6 +294,24 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    if (L->mesh_order != 2) { return fail(RMH_ERR_INVALID, "mesh_order must be 2"); }
    if (L->ne_owned <= 0 || L->ne_ghost < 0) { return fail(RMH_ERR_INVALID, "bad element counts"); }
    if (!L->x0 || !L->vel || !L->face_nbr || !L->stencil27) { return fail(RMH_ERR_INVALID, "null mesh array"); }
+   // the kernels index u, the ghost block and the element extrema with these tables: reject anything out of range
+   {
+      const long long ntot = (long long)L->ne_owned + L->ne_ghost;
+      for (long long e = 0; e < L->ne_owned; e++)
+      {
+         for (int f = 0; f < 6; f++)
+         {
+            const int nb = L->face_nbr[e * 6 + f];
+            if (nb < -1 || nb >= ntot) { return fail(RMH_ERR_INVALID, "face_nbr entry out of range"); }
+         }
+         for (int k = 0; k < 27; k++)
+         {
+            const int nb = L->stencil27[e * 27 + k];
+            if (nb < -1 || nb >= ntot) { return fail(RMH_ERR_INVALID, "stencil27 entry out of range"); }
+         }
+         if (L->stencil27[e * 27 + 13] != e) { return fail(RMH_ERR_INVALID, "stencil27[e][13] must be the element itself"); }
+      }
+   }
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
    {

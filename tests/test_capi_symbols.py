@@ -60,6 +60,35 @@ def test_no_device_is_an_error_not_a_fallback(built):
 
     lib = load_library()
     x0 = np.zeros((1, 3, 27))
+    st = -np.ones((1, 27), np.int32)
+    st[0, 13] = 0
     with pytest.raises(RmhError, match="no HIP device|hip"):
-        Context(lib, order=2, exec_mode=1, x0=x0, vel=x0, face_nbr=-np.ones((1, 6), np.int32),
-                stencil27=-np.ones((1, 27), np.int32))
+        Context(lib, order=2, exec_mode=1, x0=x0, vel=x0, face_nbr=-np.ones((1, 6), np.int32), stencil27=st)
+
+
+def test_layout_tables_are_validated(built):
+    """rmh_create rejects neighbour tables that would index outside u / the ghost block (checked before any
+    device work, so this runs without a GPU)."""
+    import numpy as np
+
+    from remhos_amd.capi import Context, RmhError, load_library
+
+    lib = load_library()
+    x0 = np.zeros((1, 3, 27))
+    nbr = -np.ones((1, 6), np.int32)
+    st = -np.ones((1, 27), np.int32)
+    st[0, 13] = 0
+    bad = nbr.copy()
+    bad[0, 2] = 1  # only element 0 exists, no ghosts
+    with pytest.raises(RmhError, match="face_nbr entry out of range"):
+        Context(lib, order=2, exec_mode=1, x0=x0, vel=x0, face_nbr=bad, stencil27=st)
+    bad = st.copy()
+    bad[0, 5] = 7
+    with pytest.raises(RmhError, match="stencil27 entry out of range"):
+        Context(lib, order=2, exec_mode=1, x0=x0, vel=x0, face_nbr=nbr, stencil27=bad)
+    bad = st.copy()
+    bad[0, 13] = -1
+    with pytest.raises(RmhError, match="must be the element itself"):
+        Context(lib, order=2, exec_mode=1, x0=x0, vel=x0, face_nbr=nbr, stencil27=bad)
+    with pytest.raises(RmhError, match="order must be in 1..6"):
+        Context(lib, order=7, exec_mode=1, x0=x0, vel=x0, face_nbr=nbr, stencil27=st)
