@@ -215,6 +215,18 @@ __device__ inline const double *tab_view()
 }
 #define RMH_TAB() tab_view<P>()
 
+// The kernel's argument struct re-read from the kernarg segment at the point of use (see ho_kernel2, phase I)
+__device__ inline const HoArgs &late_args(const HoArgs &a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   int z = 0;
+   asm volatile("" : "+s"(z));
+   return *(const HoArgs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + z);
+#else
+   return a;
+#endif
+}
+
 // Sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r] (the
 // element total, broadcast back to the dof threads).  ONE barrier per call: results go through a
 // ring of three LDS buffers (s_acc3[3][NB]); the buffer of the call before the previous one is
@@ -1154,6 +1166,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // generic orders: the deterministic reductions stage their operands in the sB slot of W, which may
    // overlap the tail of R2 that slower threads are still reading in phase G
    if (!C::WAVE_ALIGNED) { __syncthreads(); }
+   // kernel arguments that are only needed from here on (limiter, RK update, stores) are read through a late view of
+   // the kernarg segment: held in scalar registers from the kernel's first instruction they cost ~30 SGPRs through
+   // phases A-J and push table values into VGPR-lane spills
+   const HoArgs &L = late_args(a);
    // fused stage: the global reads of the limiter part are issued here so that they are in flight during
    // the PCG iterations (u is an L2 hit: this workgroup read it in phase A)
    constexpr int NLS = (NB * 27 + NT - 1) / NT;
@@ -1167,9 +1183,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          uu[r] = 0.0; xb[r] = 0.0;
          if (t < NB * D3)
          {
-            const size_t g = (size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3;
+            const size_t g = (size_t)min(e0 + t / D3, L.e_end - 1) * D3 + t % D3;
             uu[r] = a.u[g];
-            if (a.x_base) { xb[r] = a.x_base[g]; }
+            if (L.x_base) { xb[r] = L.x_base[g]; }
          }
       }
 #pragma unroll
@@ -1179,12 +1195,12 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          slo[j] = INFINITY; shi[j] = -INFINITY;
          if (k < NB * 27)
          {
-            const int e = min(e0 + k / 27, a.e_end - 1);
-            const int nb = a.stencil27[(size_t)e * 27 + k % 27];
+            const int e = min(e0 + k / 27, L.e_end - 1);
+            const int nb = L.stencil27[(size_t)e * 27 + k % 27];
             if (nb >= 0)
             {
-               if (nb < a.ne_owned) { slo[j] = a.xe_min[nb]; shi[j] = a.xe_max[nb]; }
-               else { slo[j] = a.gh_min[(size_t)(nb - a.ne_owned) * a.gh_mstride]; shi[j] = a.gh_max[(size_t)(nb - a.ne_owned) * a.gh_mstride]; }
+               if (nb < L.ne_owned) { slo[j] = L.xe_min[nb]; shi[j] = L.xe_max[nb]; }
+               else { slo[j] = L.gh_min[(size_t)(nb - L.ne_owned) * L.gh_mstride]; shi[j] = L.gh_max[(size_t)(nb - L.ne_owned) * L.gh_mstride]; }
             }
          }
       }
@@ -1405,16 +1421,16 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
-         if (t < NB * D3 && e0 + t / D3 < a.e_end)
+         if (t < NB * D3 && e0 + t / D3 < L.e_end)
          {
-            a.du[(size_t)e0 * D3 + t] = xg[r];
-            a.m[(size_t)e0 * D3 + t] = mm[r];
+            L.du[(size_t)e0 * D3 + t] = xg[r];
+            L.m[(size_t)e0 * D3 + t] = mm[r];
          }
       }
-      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < a.e_end)
+      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < L.e_end)
       {
-         a.xe_min[e0 + tid] = my_min;
-         a.xe_max[e0 + tid] = my_max;
+         L.xe_min[e0 + tid] = my_min;
+         L.xe_max[e0 + tid] = my_max;
       }
    }
    else
@@ -1436,7 +1452,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
       double mass[DR], vol[DR];
 #pragma unroll
-      for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + a.dt * xg[r]); }
+      for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
       batch_dot<C>(tmp, mass, lds, s_acc, ring);
       RMH_STAMP(22);
       batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
@@ -1452,13 +1468,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          {
             const int eb = t / D3, i = t % D3;
             double lo, hi;
-            dof_bounds_bt<P>(a.bounds_type, i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
+            dof_bounds_bt<P>(L.bounds_type, i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
             const double ubar = mass[r] / vol[r];
-            if (!BOTH) { dlo[r] = (ubar - uu[r]) / a.dt; } // MassBasedAvg; with RD dlo is already there
+            if (!BOTH) { dlo[r] = (ubar - uu[r]) / L.dt; } // MassBasedAvg; with RD dlo is already there
             dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi));
-            const double u_new_lo = uu[r] + a.dt * dlo[r];
-            const double f_clip_min = mm[r] / a.dt * (lo - u_new_lo);
-            const double f_clip_max = mm[r] / a.dt * (hi - u_new_lo);
+            const double u_new_lo = uu[r] + L.dt * dlo[r];
+            const double f_clip_min = mm[r] / L.dt * (lo - u_new_lo);
+            const double f_clip_max = mm[r] / L.dt * (hi - u_new_lo);
             double fc = mm[r] * (xg[r] - dlo[r]);
             fc = fmin(f_clip_max, fmax(f_clip_min, fc));
             fcl[r] = fc;
@@ -1466,10 +1482,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             pos[r] = fmax(fc, 0.0);
          }
       }
-      if (a.dt_est)
+      if (L.dt_est)
       {
          dtc = wave_minmax<true>(dtc);
-         if ((tid & 63) == 63) { atomic_min_nonneg(a.dt_est, dtc); }
+         if ((tid & 63) == 63) { atomic_min_nonneg(L.dt_est, dtc); }
       }
       RMH_STAMP(18);
       double sumPos[DR], sumNeg[DR];
@@ -1489,11 +1505,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             if (new_mass > eps) { fc = fmin(0.0, fc) - fmax(0.0, fc) * sumNeg[r] / sumPos[r]; }
             if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos[r] / sumNeg[r]; }
             const double dui = dlo[r] + fc / mm[r];
-            ynew[r] = (a.x_base ? a.rk_a * xb[r] : 0.0) + a.rk_b * (uu[r] + a.dt_rk * dui);
-            if (e0 + t / D3 < a.e_end)
+            ynew[r] = (L.x_base ? L.rk_a * xb[r] : 0.0) + L.rk_b * (uu[r] + L.dt_rk * dui);
+            if (e0 + t / D3 < L.e_end)
             {
-               a.y_out[(size_t)e0 * D3 + t] = ynew[r];
-               if (a.du) { a.du[(size_t)e0 * D3 + t] = dui; }
+               L.y_out[(size_t)e0 * D3 + t] = ynew[r];
+               if (L.du) { L.du[(size_t)e0 * D3 + t] = dui; }
             }
          }
       }
@@ -1507,10 +1523,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int t = tid + r * NT;
             const double lo = wave_minmax<true>(t < NB * D3 ? ynew[r] : INFINITY);
             const double hi = wave_minmax<false>(t < NB * D3 ? ynew[r] : -INFINITY);
-            if ((tid & 63) == 63 && t < NB * D3 && e0 + t / D3 < a.e_end)
+            if ((tid & 63) == 63 && t < NB * D3 && e0 + t / D3 < L.e_end)
             {
-               a.xe_min_out[e0 + t / D3] = lo;
-               a.xe_max_out[e0 + t / D3] = hi;
+               L.xe_min_out[e0 + t / D3] = lo;
+               L.xe_max_out[e0 + t / D3] = hi;
             }
          }
       }
@@ -1538,7 +1554,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                if (lane == 63) { part[2 * k] = lo; part[2 * k + 1] = hi; }
             }
             __syncthreads();
-            if (tid < NB && e0 + tid < a.e_end)
+            if (tid < NB && e0 + tid < L.e_end)
             {
                double lo = INFINITY, hi = -INFINITY;
 #pragma unroll
@@ -1547,11 +1563,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                   lo = fmin(lo, part[2 * (tid * CH + c)]);
                   hi = fmax(hi, part[2 * (tid * CH + c) + 1]);
                }
-               a.xe_min_out[e0 + tid] = lo;
-               a.xe_max_out[e0 + tid] = hi;
+               L.xe_min_out[e0 + tid] = lo;
+               L.xe_max_out[e0 + tid] = hi;
             }
          }
-         else if (tid < NB && e0 + tid < a.e_end)
+         else if (tid < NB && e0 + tid < L.e_end)
          {
             double lo = INFINITY, hi = -INFINITY;
             for (int i = 0; i < D3; i++)
@@ -1559,15 +1575,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                lo = fmin(lo, RMH_W(tid)[64 + i]);
                hi = fmax(hi, RMH_W(tid)[64 + i]);
             }
-            a.xe_min_out[e0 + tid] = lo;
-            a.xe_max_out[e0 + tid] = hi;
+            L.xe_min_out[e0 + tid] = lo;
+            L.xe_max_out[e0 + tid] = hi;
          }
       }
    }
    // diagnostics: max PCG iteration count over the launch.  A global atomic per wavefront on ONE
    // address serialises at the memory side (~5 ns each: 3 ms per launch at 500 k wavefronts), so the
    // atomic is issued only when it can raise the (monotone) maximum.
-   if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(a.cg_iters)) { atomicMax(a.cg_iters, itmax); }
+   if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(L.cg_iters)) { atomicMax(L.cg_iters, itmax); }
    RMH_STAMP(7);
 }
 
