@@ -271,11 +271,21 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
 } // namespace
 
 #ifdef RMH_STAMPS
+// sums the per-workgroup stamp rows into out[32]; reset != 0 clears them afterwards
 extern "C" int rmh_debug_stamps(unsigned long long *out, int reset)
 {
-   unsigned long long z[32] = {0};
-   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rmh::g_stamps), sizeof(z)) != hipSuccess) { return -1; }
-   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(rmh::g_stamps), z, sizeof(z)) != hipSuccess) { return -1; }
+   const size_t n = (size_t)rmh::RMH_STAMP_MAXWG * 32;
+   std::vector<unsigned long long> h(n);
+   if (hipDeviceSynchronize() != hipSuccess) { return -1; }
+   if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(rmh::g_stamps), n * sizeof(unsigned long long)) != hipSuccess) { return -1; }
+   for (int k = 0; k < 32; k++) { out[k] = 0; }
+   for (size_t i = 0; i < n; i++) { out[i % 32] += h[i]; }
+   if (reset)
+   {
+      void *p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(rmh::g_stamps)) != hipSuccess) { return -1; }
+      if (hipMemset(p, 0, n * sizeof(unsigned long long)) != hipSuccess) { return -1; }
+   }
    return 0;
 }
 #endif

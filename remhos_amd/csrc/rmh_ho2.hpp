@@ -334,19 +334,29 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
 }
 
 #ifdef RMH_STAMPS
-// diagnostic build only: per-phase cycle shares of workgroup-thread 0, accumulated in a debug buffer
-__device__ unsigned long long g_stamps[32];
+// diagnostic build only: per-phase cycle shares of workgroup-thread 0.  The deltas are accumulated in LDS and
+// written once at the end of the kernel (a global atomic per stamp would be waited for by the next
+// s_waitcnt vmcnt(0) of the workgroup and show up as a phantom wait); one row of 32 counters per workgroup,
+// summed by the host.
+constexpr int RMH_STAMP_MAXWG = 1 << 18;
+__device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
 #define RMH_STAMP(k)                                                                   \
    do {                                                                                \
       if (threadIdx.x == 0)                                                            \
       {                                                                                \
          const unsigned long long now_ = clock64();                                    \
-         atomicAdd(&g_stamps[k], now_ - stamp_prev_);                                  \
+         s_stamp[k] += now_ - stamp_prev_;                                             \
          stamp_prev_ = now_;                                                           \
       }                                                                                \
    } while (0)
+#define RMH_STAMP_FLUSH()                                                              \
+   do {                                                                                \
+      __syncthreads();                                                                 \
+      if (threadIdx.x < 32 && blockIdx.x < RMH_STAMP_MAXWG) { g_stamps[blockIdx.x][threadIdx.x] += s_stamp[threadIdx.x]; } \
+   } while (0)
 #else
 #define RMH_STAMP(k)
+#define RMH_STAMP_FLUSH()
 #endif
 
 // FUSED = false: HOSolver::CalcHOSolution (writes du_HO, lumped mass, element extrema of u).
@@ -369,6 +379,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    constexpr bool BOTH = MODE == 3;               // HO and RD in the same kernel
    constexpr bool HAS_HO = MODE != 2;
 #ifdef RMH_STAMPS
+   __shared__ unsigned long long s_stamp[32];
+   if (threadIdx.x < 32) { s_stamp[threadIdx.x] = 0; }
    unsigned long long stamp_prev_ = clock64();
 #endif
    using C = K2Cfg<P, (MODE >= 2), (MODE == 3)>;
@@ -1453,9 +1465,47 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       double mass[DR], vol[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
-      batch_dot<C>(tmp, mass, lds, s_acc, ring);
+      batch_dot<C>(tmp, mass, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
       RMH_STAMP(22);
-      batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
+      // per-dof bounds are box minima / maxima of the 3 x 3 x 3 stencil: a dof sees, per direction, the offsets
+      // {-1, 0} on the low layer, {0} inside, {0, +1} on the high layer (remhos_tools.cpp:432-495).  The 27 boxes are
+      // reduced once per element; every dof then reads one pair.  Bounds type 1: the same 7-point value for all.
+      static_assert(C::W - C::PCG >= 54, "no room for the box table behind the PCG buffers");
+      for (int k = tid; k < NB * 27; k += NT)
+      {
+         const int eb = k / 27, s3 = k % 27;
+         const double *smin = RMH_W(eb), *smax = RMH_W(eb) + 27;
+         double lo = INFINITY, hi = -INFINITY;
+         if (L.bounds_type == 0)
+         {
+            const int sx = s3 % 3, sy = (s3 / 3) % 3, sz = s3 / 9;
+            for (int oz = (sz == 0 ? -1 : 0); oz <= (sz == 2 ? 1 : 0); oz++)
+            {
+               for (int oy = (sy == 0 ? -1 : 0); oy <= (sy == 2 ? 1 : 0); oy++)
+               {
+                  for (int ox = (sx == 0 ? -1 : 0); ox <= (sx == 2 ? 1 : 0); ox++)
+                  {
+                     const int q = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
+                     lo = fmin(lo, smin[q]);
+                     hi = fmax(hi, smax[q]);
+                  }
+               }
+            }
+         }
+         else
+         {
+            constexpr int fs[7] = {13, 12, 14, 10, 16, 4, 22};
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+            {
+               lo = fmin(lo, smin[fs[q]]);
+               hi = fmax(hi, smax[fs[q]]);
+            }
+         }
+         RMH_W(eb)[C::PCG + s3] = lo;
+         RMH_W(eb)[C::PCG + 27 + s3] = hi;
+      }
+      batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the box table)
       RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];
       double dtc = INFINITY; // UpdateTimeStepEstimate(u, du_LO, u_min, u_max), remhos.cpp:1839-1842
@@ -1467,8 +1517,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          if (t < NB * D3)
          {
             const int eb = t / D3, i = t % D3;
-            double lo, hi;
-            dof_bounds_bt<P>(L.bounds_type, i, RMH_W(eb), RMH_W(eb) + 27, lo, hi);
+            const int bx = i % D, by = (i / D) % D, bz = i / D2;
+            const int s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
+            const double lo = RMH_W(eb)[C::PCG + s3], hi = RMH_W(eb)[C::PCG + 27 + s3];
             const double ubar = mass[r] / vol[r];
             if (!BOTH) { dlo[r] = (ubar - uu[r]) / L.dt; } // MassBasedAvg; with RD dlo is already there
             dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi));
@@ -1585,6 +1636,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // atomic is issued only when it can raise the (monotone) maximum.
    if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(L.cg_iters)) { atomicMax(L.cg_iters, itmax); }
    RMH_STAMP(7);
+   RMH_STAMP_FLUSH();
 }
 
 #undef RMH_W

@@ -1,9 +1,9 @@
 """Diagnostic (never part of the product build): per-phase cycle shares of ho_kernel2 from a
 -DRMH_STAMPS build of the library (remhos_amd/librmh_stamps.so).
 
-Caveat: a stamp is clock64() + a global atomicAdd by thread 0; the workgroup's next s_waitcnt vmcnt(0) also waits for
-that atomic (32 hot addresses shared by all workgroups), so phases that contain such a wait look far longer than they
-are.  Trust the shares of pure compute / LDS phases only."""
+The deltas of thread 0 are accumulated in LDS and written once per workgroup at the end of the kernel (the first
+version issued a global atomic per stamp, which the next s_waitcnt vmcnt(0) of the workgroup then waited for:
+phantom waits worth a third of the kernel)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
