@@ -947,6 +947,30 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
       }
    }
+   if (HAS_HO)
+   {
+      // the face rows are contracted along q1 here, in place (column (f, k2) of the face buffer belongs to one
+      // thread: Q values in, D values out): F[(f*Q + k1)*D + k2] = sum_q1 Bg[q1][k1] F[(f*Q + q1)*D + k2], so that a
+      // dof of phase G adds one value per face instead of a Q-term sum
+      for (int k = NT - 1 - tid; k < NB * 6 * D; k += NT) // (from the top: the y-leg tasks occupy the low threads)
+      {
+         const int eb = k / (6 * D), rem = k % (6 * D);
+         const int f = rem / D, k2 = rem % D;
+         double *F = RMH_W(eb) + oF + f * Q * D + k2;
+         double in[Q];
+#pragma unroll
+         for (int q1 = 0; q1 < Q; q1++) { in[q1] = F[q1 * D]; }
+#pragma unroll
+         for (int k1 = 0; k1 < D; k1++)
+         {
+            const double *gt = RMH_TAB();
+            double acc = 0.0;
+#pragma unroll
+            for (int q1 = 0; q1 < Q; q1++) { acc += gt[oBg + q1 * D + k1] * in[q1]; }
+            F[k1 * D] = acc;
+         }
+      }
+   }
    __syncthreads();
 
    RMH_STAMP(4);
@@ -986,11 +1010,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
             for (int side = 0; side < 2; side++)
             {
-               const double *F = RMH_W(eb) + oF + (2 * c + side) * Q * D + k2;
-               double fa = 0.0;
-#pragma unroll
-               for (int q1 = 0; q1 < Q; q1++) { fa += stab[oBg + q1 * D + k1] * F[q1 * D]; }
-               a0 += stab[C::oBgE + side * D + kc] * fa;
+               // (face rows already contracted along q1 in phase F)
+               a0 += stab[C::oBgE + side * D + kc] * RMH_W(eb)[oF + ((2 * c + side) * Q + k1) * D + k2];
             }
          }
          rg[r] = a0; mm[r] = a1; dg[r] = a2;
