@@ -20,7 +20,10 @@ What is restated (reference file:line):
   * LO  mass-based average           remhos_lo.cpp:247-324
   * LO  subcell residual distrib.    remhos_lo.cpp:111-245 (host form), 1620-1802 (PA form),
                                      remhos_tools.cpp:678-734 (Sub2Ind), 860-913
-  * bounds                           remhos_tools.cpp:432-523
+  * bounds                           remhos_tools.cpp:432-523 (overlap, -bt 0), 381-430 (face neighbours, -bt 1)
+  * time step control -dtc 1         remhos.cpp:1968-1998 (estimate), 1146-1197 (repeat / grow)
+  * plain residual distribution      remhos_lo.cpp:965-1034 (-lo 3: the subcell scheme without subcell terms)
+  * element FCT projection (-fct 4)  remhos_fct.cpp:613-735 -- only to pin -bt 1 / -dtc 1 with the reference's KATs
   * ClipScale FCT                    remhos_fct.cpp:449-541
   * stage order / RK3-SSP / report   remhos.cpp:1146-1296, 1382-1428, 1596-1916
 
