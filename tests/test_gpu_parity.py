@@ -260,3 +260,60 @@ def test_one_kernel_stage_lo4(gpu, mesh, rs, p, prob, t):
     torch.cuda.synchronize()
     assert torch.equal(yr, y) and torch.equal(dur, du)
     ctx.close()
+
+
+@pytest.mark.parametrize("p,lo,part", [(3, 5, (2, 1, 1)), (2, 4, (1, 2, 1)), (4, 5, (2, 2, 2)), (3, 4, (2, 2, 1))])
+def test_partitioned_blocks_on_one_gpu(gpu, p, lo, part):
+    """The multi-rank data path on real hardware without a second GPU: every block of a box partition gets its own
+    context on this device, ghost records are packed by rmh_halo_pack_records and copied into the neighbours' ghost
+    blocks by hand (what the RCCL send/recv of the stepper does), the stage runs as interior range + halo range.
+    The result must equal the single-block stage bit for bit."""
+    torch, lib = gpu
+    from remhos_amd.capi import Context
+    from remhos_amd.case import Case, bind_driver, make_config
+
+    lib = bind_driver(lib)
+    mesh, rs, prob, t, dt = "periodic-cube", 1, 10, 0.3, 0.01
+    dev = "cuda:0"
+
+    def mk(c):
+        ctx = Context(lib, order=p, exec_mode=c.exec_mode, x0=c.x0, vel=c.vel, face_nbr=c.face_nbr, stencil27=c.stencil27,
+                      ne_ghost=c.ne_ghost, subcell_vel=c.subcell_vel)
+        if lo != 5:
+            ctx.set_lo_type(lo)
+        return ctx
+
+    g = Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5, lo_type=lo))
+    u_g = perturbed(g.u0)
+    cg = mk(g)
+    cg.setup(t)
+    ug = torch.from_numpy(u_g).to(dev)
+    y_g = torch.empty_like(ug)
+    cg.stage_fused(ug, dt, y_g, dt_rk=dt)
+    nr = part[0] * part[1] * part[2]
+    cases = [Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5, lo_type=lo, part=part, rank=k)) for k in range(nr)]
+    nd = g.ndof
+    us = [torch.from_numpy(np.ascontiguousarray(u_g[c.owned_gid])).to(dev) for c in cases]
+    ctxs = [mk(c) for c in cases]
+    ghosts = [torch.zeros(max(c.ne_ghost, 1), nd + 2, dtype=torch.float64, device=dev) for c in cases]
+    for c, ctx, gh in zip(cases, ctxs, ghosts):
+        ctx.set_ghost_records(gh)
+    for k, (c, ctx) in enumerate(zip(cases, ctxs)):
+        for rank, send, _ in c.peers:
+            recv = [r for rk, _, r in cases[rank].peers if rk == k][0]
+            se = torch.from_numpy(np.ascontiguousarray(send, dtype=np.int32)).to(dev)
+            rec = torch.empty(len(send), nd + 2, dtype=torch.float64, device=dev)
+            ctx.halo_pack_records(us[k], se, len(send), rec)
+            ghosts[rank][torch.from_numpy(np.ascontiguousarray(recv, dtype=np.int64)).to(dev)] = rec
+    torch.cuda.synchronize()
+    y_ref = y_g.cpu().numpy()
+    for k, (c, ctx) in enumerate(zip(cases, ctxs)):
+        ctx.setup(t)
+        y = torch.empty_like(us[k])
+        assert 0 < c.ne_halo <= c.ne_owned
+        ctx.stage_fused_range(us[k], dt, y, c.ne_halo, c.ne_owned, False, dt_rk=dt)
+        ctx.stage_fused_range(us[k], dt, y, 0, c.ne_halo, True, dt_rk=dt)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy(), y_ref[c.owned_gid])
+        ctx.close()
+    cg.close()
