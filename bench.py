@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--lo", type=int, default=5, help="LO solver: 5 mass-based average (default), 4 subcell residual distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference call sequence instead of the fused limiter")
+    ap.add_argument("--ref-mass-tol", action="store_true",
+                    help="local mass solve with the reference's DGMassInverse tolerances (abs 1e-8, rel 0: remhos_ho.cpp:79-80) "
+                         "instead of rel 1e-14 (see DESIGN.md 4)")
     ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
     args = ap.parse_args()
 
@@ -119,6 +122,8 @@ def main():
     t0 = time.perf_counter()
     case = Case(lib, cfg)
     st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused, one_kernel=not args.two_kernels)
+    if args.ref_mass_tol:
+        st.ctx.set_mass_tol(0.0, 1e-8, 100)
     setup_s = time.perf_counter() - t0
     global_dofs = case.ne_global * case.ndof
     dt = case.dt
@@ -207,6 +212,7 @@ def main():
                 "limiter": "reference call sequence" if args.unfused else ("inside the stage kernel" if st.one_kernel else "fused (LO avg + bounds + ClipScale + RK update)"),
                 "dt": dt,
                 "mass_cg_max_iters": cg_iters,
+                "mass_tol": "abs 1e-8 (reference)" if args.ref_mass_tol else "rel 1e-14",
                 "final_mass": mass,
                 "max_value": umax,
                 "setup_s": setup_s,
