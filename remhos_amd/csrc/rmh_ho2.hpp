@@ -975,6 +975,16 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 
    RMH_STAMP(4);
    // ---- phase G: dof threads: x-leg, face contributions ------------------------------------------------
+   // (RD solver: the element's u in the dof role is needed right after this phase; the reload -- an L2 hit -- is
+   // issued here so that the x-leg hides it)
+   double uu4[DR];
+#pragma unroll
+   for (int r = 0; r < DR; r++)
+   {
+      const int t = tid + r * NT;
+      uu4[r] = 0.0;
+      if (LO4 && t < NB * D3) { uu4[r] = a.u[(size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3]; }
+   }
    double rg[DR], mm[DR], dg[DR], zb[DR];
    double cBg[DR][Q]; // column ix of the GL basis table of each dof of this thread (x-legs)
 #pragma unroll
@@ -1027,7 +1037,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       // ---- residual distribution per element (remhos_lo.cpp:1702-1800); zb = z = K_vol u, mm = lumped mass
       constexpr int NS = C::NS;
       const double eps = 1.E-15, gamma = 1.0;
-      double uu4[DR], t0[DR], t1[DR], t2[DR], xSum[DR], rhoP[DR], rhoN[DR];
+      double t0[DR], t1[DR], t2[DR], xSum[DR], rhoP[DR], rhoN[DR];
       int ring4 = 0;
       __syncthreads(); // R2 has been consumed: the front of W is free
       if (BOTH)
@@ -1067,12 +1077,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
-         uu4[r] = 0.0;
-         if (t < NB * D3)
-         {
-            uu4[r] = a.u[(size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3];
-            RMH_W(t / D3)[oSA + t % D3] = uu4[r];
-         }
+         if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = uu4[r]; }
          t0[r] = uu4[r];
          t1[r] = fmax(0., zb[r]);
          t2[r] = fmin(0., zb[r]);
@@ -1217,7 +1222,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          if (t < NB * D3)
          {
             const size_t g = (size_t)min(e0 + t / D3, L.e_end - 1) * D3 + t % D3;
-            uu[r] = a.u[g];
+            uu[r] = BOTH ? uu4[r] : a.u[g]; // (HO + RD: already reloaded for the RD solver)
             if (L.x_base) { xb[r] = L.x_base[g]; }
          }
       }

@@ -14,8 +14,11 @@ lib = bind_driver(load_library(os.path.join("remhos_amd", "librmh_stamps.so")))
 rs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 maxit = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+lo = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 nb = {1: 32, 2: 16, 3: 7, 4: 2, 5: 4, 6: 1}[order]
-st = Stepper(lib, Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5)), device="cuda:0")
+if lo != 5:
+    nb = {2: 15, 3: 6, 4: 2, 5: 3, 6: 1}[order]
+st = Stepper(lib, Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5, lo_type=lo)), device="cuda:0")
 st.ctx.set_mass_tol(1e-14, 0.0, maxit) if maxit > 0 else st.ctx.set_mass_tol(1.0)
 for _ in range(2): st.step(st.dt)
 torch.cuda.synchronize()
