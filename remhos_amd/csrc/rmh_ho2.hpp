@@ -1504,18 +1504,18 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          double lo = INFINITY, hi = -INFINITY;
          if (L.bounds_type == 0)
          {
+            // box {lo, hi} per direction: low layer {-1, 0} -> entries (0, 1), inside {0} -> (1, 1), high layer
+            // {0, +1} -> (1, 2); the eight corners of the box are read unconditionally (duplicates are harmless)
             const int sx = s3 % 3, sy = (s3 / 3) % 3, sz = s3 / 9;
-            for (int oz = (sz == 0 ? -1 : 0); oz <= (sz == 2 ? 1 : 0); oz++)
+            const int x0 = (sx == 0) ? 0 : 1, x1 = (sx == 2) ? 2 : 1;
+            const int y0 = (sy == 0) ? 0 : 1, y1 = (sy == 2) ? 2 : 1;
+            const int z0 = (sz == 0) ? 0 : 1, z1 = (sz == 2) ? 2 : 1;
+#pragma unroll
+            for (int c = 0; c < 8; c++)
             {
-               for (int oy = (sy == 0 ? -1 : 0); oy <= (sy == 2 ? 1 : 0); oy++)
-               {
-                  for (int ox = (sx == 0 ? -1 : 0); ox <= (sx == 2 ? 1 : 0); ox++)
-                  {
-                     const int q = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
-                     lo = fmin(lo, smin[q]);
-                     hi = fmax(hi, smax[q]);
-                  }
-               }
+               const int q = ((c & 1) ? x1 : x0) + 3 * ((c & 2) ? y1 : y0) + 9 * ((c & 4) ? z1 : z0);
+               lo = fmin(lo, smin[q]);
+               hi = fmax(hi, smax[q]);
             }
          }
          else
