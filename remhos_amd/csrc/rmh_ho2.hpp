@@ -215,6 +215,26 @@ __device__ inline const double *tab_view()
 }
 #define RMH_TAB() tab_view<P>()
 
+// a / b for well-scaled operands (mass, dt, PCG scalars: no denormals, no overflow, b != 0): hardware reciprocal,
+// two Newton steps and one correction of the quotient -- the core of the IEEE expansion without its scaling and
+// special-case fix-up (8 instead of ~14 instructions; ~30 divisions per wavefront were 12 % of the stage kernel's
+// VALU instructions).  The result is within 1 ulp of a / b, not always correctly rounded.
+#ifndef RMH_FAST_DIV
+#define RMH_FAST_DIV 1
+#endif
+__device__ inline double fdiv(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RMH_FAST_DIV
+   double r = __builtin_amdgcn_rcp(b);
+   r = fma(fma(-b, r, 1.0), r, r);
+   r = fma(fma(-b, r, 1.0), r, r);
+   const double q = a * r;
+   return fma(fma(-b, q, a), r, q);
+#else
+   return a / b;
+#endif
+}
+
 // The kernel's argument struct re-read from the kernarg segment at the point of use (see ho_kernel2, phase I)
 __device__ inline const HoArgs &late_args(const HoArgs &a)
 {
@@ -1179,16 +1199,16 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
             const double sumWeightsP = D3 * xe_max - xSum[r] + eps;
             const double sumWeightsN = D3 * xe_min - xSum[r] - eps;
-            double weightP = (xe_max - ui) / sumWeightsP;
-            double weightN = (xe_min - ui) / sumWeightsN;
-            double aux = gamma / (rhoP[r] + eps);
+            double weightP = fdiv(xe_max - ui, sumWeightsP);
+            double weightN = fdiv(xe_min - ui, sumWeightsN);
+            double aux = fdiv(gamma, rhoP[r] + eps);
             weightP *= 1. - fmin(aux * sumFluctP, 1.);
-            weightP += fmin(aux, 1. / (sumFluctP + eps)) * nwP;
-            aux = gamma / (rhoN[r] - eps);
+            weightP += fmin(aux, fdiv(1., sumFluctP + eps)) * nwP;
+            aux = fdiv(gamma, rhoN[r] - eps);
             weightN *= 1. - fmin(aux * sumFluctN, 1.);
-            weightN += fmax(aux, 1. / (sumFluctN - eps)) * nwN;
+            weightN += fmax(aux, fdiv(1., sumFluctN - eps)) * nwN;
             const double duf = RMH_W(eb)[C::oDuf + i];
-            dlo[r] = (duf + weightP * rhoP[r] + weightN * rhoN[r]) / mm[r];
+            dlo[r] = fdiv(duf + weightP * rhoP[r] + weightN * rhoN[r], mm[r]);
             if (!BOTH && e0 + eb < a.e_end)
             {
                a.du[(size_t)e0 * D3 + t] = dlo[r];
@@ -1251,7 +1271,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    for (int r = 0; r < DR; r++)
    {
       xg[r] = 0.0;
-      dg[r] = 1.0 / dg[r]; // from here on dg holds the inverse diagonal (one division per dof instead of two per iteration)
+      dg[r] = fdiv(1.0, dg[r]); // from here on dg holds the inverse diagonal (one division per dof instead of two per iteration)
       dd[r] = rg[r] * dg[r];
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
@@ -1387,7 +1407,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int r = 0; r < DR; r++)
       {
          const bool ok = act[r] && red[r] > 0.0;
-         const double al = ok ? nom[r] / red[r] : 0.0;
+         const double al = ok ? fdiv(nom[r], red[r]) : 0.0;
          if (act[r] && !ok) { tol[r] = INFINITY; } // breakdown: freeze this element
          xg[r] += al * dd[r];
          rg[r] -= al * Ad[r];
@@ -1407,7 +1427,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const double z = rg[r] * dg[r];
          if (act[r])
          {
-            dd[r] = z + (red[r] / nom[r]) * dd[r];
+            dd[r] = z + fdiv(red[r], nom[r]) * dd[r];
             nom[r] = red[r];
             its[r]++;
          }
@@ -1546,12 +1566,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int bx = i % D, by = (i / D) % D, bz = i / D2;
             const int s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
             const double lo = RMH_W(eb)[C::PCG + s3], hi = RMH_W(eb)[C::PCG + 27 + s3];
-            const double ubar = mass[r] / vol[r];
-            if (!BOTH) { dlo[r] = (ubar - uu[r]) / L.dt; } // MassBasedAvg; with RD dlo is already there
+            const double ubar = fdiv(mass[r], vol[r]);
+            if (!BOTH) { dlo[r] = fdiv(ubar - uu[r], L.dt); } // MassBasedAvg; with RD dlo is already there
             dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi));
             const double u_new_lo = uu[r] + L.dt * dlo[r];
-            const double f_clip_min = mm[r] / L.dt * (lo - u_new_lo);
-            const double f_clip_max = mm[r] / L.dt * (hi - u_new_lo);
+            const double m_dt = fdiv(mm[r], L.dt);
+            const double f_clip_min = m_dt * (lo - u_new_lo);
+            const double f_clip_max = m_dt * (hi - u_new_lo);
             double fc = mm[r] * (xg[r] - dlo[r]);
             fc = fmin(f_clip_max, fmax(f_clip_min, fc));
             fcl[r] = fc;
@@ -1579,9 +1600,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          {
             const double new_mass = sumNeg[r] + sumPos[r];
             double fc = fcl[r];
-            if (new_mass > eps) { fc = fmin(0.0, fc) - fmax(0.0, fc) * sumNeg[r] / sumPos[r]; }
-            if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos[r] / sumNeg[r]; }
-            const double dui = dlo[r] + fc / mm[r];
+            if (new_mass > eps) { fc = fmin(0.0, fc) - fdiv(fmax(0.0, fc) * sumNeg[r], sumPos[r]); }
+            if (new_mass < -eps) { fc = fmax(0.0, fc) - fdiv(fmin(0.0, fc) * sumPos[r], sumNeg[r]); }
+            const double dui = dlo[r] + fdiv(fc, mm[r]);
             ynew[r] = (L.x_base ? L.rk_a * xb[r] : 0.0) + L.rk_b * (uu[r] + L.dt_rk * dui);
             if (e0 + t / D3 < L.e_end)
             {
