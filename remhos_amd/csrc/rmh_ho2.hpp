@@ -163,6 +163,20 @@ __device__ inline void swap32(double &a, double &b)
 #endif
 }
 
+// v_permlane16_swap (gfx950): the odd 16-lane rows of a are exchanged with the even rows of b; afterwards
+// a = {a.row0, b.row0, a.row2, b.row2} and b = {a.row1, b.row1, a.row3, b.row3}
+__device__ inline void swap16(double &a, double &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   const auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+   const auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+   a = __hiloint2double((int)r1[0], (int)r0[0]);
+   b = __hiloint2double((int)r1[1], (int)r0[1]);
+#elif defined(HIPEMU)
+   hipemu_permlane16_swap(a, b);
+#endif
+}
+
 template <int CTRL, int ROW_MASK, bool IS_MIN>
 __device__ inline double dpp_minmax(double v)
 {
@@ -259,7 +273,7 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
 {
    const int tid = threadIdx.x;
    double *cur = s_acc3 + ring * C::NB;
-   double *old = s_acc3 + ((ring + 1) % 3) * C::NB; // used two calls ago
+   double *old = s_acc3 + ((ring + 1) % 4) * C::NB; // (a slot is reused two calls later at the earliest)
    if (C::WAVE_ALIGNED && C::DR == 2)
    {
       const int lane = tid & 63, wave = tid >> 6;
@@ -340,7 +354,7 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
          }
          out[r] = acc;
       }
-      ring = (ring + 1) % 3;
+      ring = (ring + 1) % 4;
       return;
    }
    __syncthreads();
@@ -350,7 +364,53 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
       const int t = tid + r * C::NT;
       out[r] = (t < C::NB * C::D3) ? cur[t / C::D3] : 0.0;
    }
-   ring = (ring + 1) % 3;
+   ring = (ring + 1) % 4;
+}
+
+// Two element sums at once (v -> outv, w -> outw): for p = 3 the two half-wave results share one row reduction --
+// after the half-wave swap each value occupies two 16-lane rows per round; a row swap between the two values puts
+// {v round 0, w round 0, v round 1, w round 1} into the four rows, which the four DPP row steps then reduce together.
+// One barrier instead of two.  Other orders: two calls of batch_dot.
+template <class C>
+__device__ inline void batch_dot2(const double (&v)[C::DR], const double (&w)[C::DR], double (&outv)[C::DR],
+                                  double (&outw)[C::DR], double *lds, double *s_acc3, int &ring)
+{
+   if (C::WAVE_ALIGNED && C::DR == 2)
+   {
+      const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      double *curv = s_acc3 + ring * C::NB, *curw = s_acc3 + ((ring + 1) % 4) * C::NB;
+      const bool has1 = tid + C::NT < C::NB * C::D3;
+      double v0 = v[0], v1 = has1 ? v[C::DR == 2 ? 1 : 0] : 0.0;
+      double w0 = w[0], w1 = has1 ? w[C::DR == 2 ? 1 : 0] : 0.0;
+      swap32(v0, v1);
+      swap32(w0, w1);
+      double xa = v0 + v1, xb = w0 + w1;
+      swap16(xa, xb);
+      double x = xa + xb;
+      x = dpp_add_all<0xB1>(x);
+      x = dpp_add_all<0x4E>(x);
+      x = dpp_add_all<0x141>(x);
+      x = dpp_add_all<0x140>(x);
+      const int e1 = C::NT / C::D3 + wave;
+      if (lane == 15) { curv[wave] = x; }
+      if (lane == 31) { curw[wave] = x; }
+      if (lane == 47 && e1 < C::NB) { curv[e1] = x; }
+      if (lane == 63 && e1 < C::NB) { curw[e1] = x; }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const int t = tid + r * C::NT;
+         outv[r] = (t < C::NB * C::D3) ? curv[t / C::D3] : 0.0;
+         outw[r] = (t < C::NB * C::D3) ? curw[t / C::D3] : 0.0;
+      }
+      ring = (ring + 2) % 4;
+   }
+   else
+   {
+      batch_dot<C>(v, outv, lds, s_acc3, ring);
+      batch_dot<C>(w, outw, lds, s_acc3, ring);
+   }
 }
 
 #ifdef RMH_STAMPS
@@ -1103,8 +1163,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          t2[r] = fmin(0., zb[r]);
       }
       batch_dot<C>(t0, xSum, lds, s_acc, ring4);
-      batch_dot<C>(t1, rhoP, lds, s_acc, ring4);
-      batch_dot<C>(t2, rhoN, lds, s_acc, ring4);
+      batch_dot2<C>(t1, t2, rhoP, rhoN, lds, s_acc, ring4);
       // element extrema (el[0..1]) and the sums of the subcell fluctuations (8 partial sums each, el[2..17])
       if (C::WAVE_ALIGNED)
       {
@@ -1446,6 +1505,22 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       const int t = tid + r * NT;
       if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = xg[r]; }
    }
+   if (FUSED)
+   {
+      // limiter: the stencil extrema go to LDS behind the PCG buffers and the box table (smin at [PCG + 54, +27),
+      // smax at [PCG + 81, +27)); the barriers of the back-transform publish them and the box table made from them
+      static_assert(C::W - C::PCG >= 108, "no room for the stencil and the box table behind the PCG buffers");
+#pragma unroll
+      for (int j = 0; j < NLS; j++)
+      {
+         const int k = tid + j * NT;
+         if (k < NB * 27)
+         {
+            RMH_W(k / 27)[C::PCG + 54 + k % 27] = slo[j];
+            RMH_W(k / 27)[C::PCG + 81 + k % 27] = shi[j];
+         }
+      }
+   }
    __syncthreads();
    for (int dir = 0; dir < 3; dir++)
    {
@@ -1467,60 +1542,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             else { RMH_W(eb)[oout + i] = acc; }
          }
       }
-      __syncthreads();
-   }
-   RMH_STAMP(16);
-   int itmax = 0;
-#pragma unroll
-   for (int r = 0; r < DR; r++) { itmax = max(itmax, its[r]); }
-   if (!FUSED)
-   {
-#pragma unroll
-      for (int r = 0; r < DR; r++)
+      if (FUSED && dir == 0)
       {
-         const int t = tid + r * NT;
-         if (t < NB * D3 && e0 + t / D3 < L.e_end)
-         {
-            L.du[(size_t)e0 * D3 + t] = xg[r];
-            L.m[(size_t)e0 * D3 + t] = mm[r];
-         }
-      }
-      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < L.e_end)
-      {
-         L.xe_min[e0 + tid] = my_min;
-         L.xe_max[e0 + tid] = my_max;
-      }
-   }
-   else
-   {
-      // ---- phase K: LimitMult + RK update (W is free: the last back-transform leg ended with a barrier) ----
-      constexpr double eps = 1.0e-15;
-      // stencil extrema -> LDS: smin at W[0..27), smax at W[27..54)
-#pragma unroll
-      for (int j = 0; j < NLS; j++)
-      {
-         const int k = tid + j * NT;
-         if (k < NB * 27)
-         {
-            RMH_W(k / 27)[k % 27] = slo[j];
-            RMH_W(k / 27)[27 + k % 27] = shi[j];
-         }
-      }
-      RMH_STAMP(21);
-      // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
-      double mass[DR], vol[DR];
-#pragma unroll
-      for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
-      batch_dot<C>(tmp, mass, lds, s_acc, ring); // (the barrier inside also publishes the stencil extrema)
-      RMH_STAMP(22);
       // per-dof bounds are box minima / maxima of the 3 x 3 x 3 stencil: a dof sees, per direction, the offsets
       // {-1, 0} on the low layer, {0} inside, {0, +1} on the high layer (remhos_tools.cpp:432-495).  The 27 boxes are
       // reduced once per element; every dof then reads one pair.  Bounds type 1: the same 7-point value for all.
-      static_assert(C::W - C::PCG >= 54, "no room for the box table behind the PCG buffers");
       for (int k = tid; k < NB * 27; k += NT)
       {
          const int eb = k / 27, s3 = k % 27;
-         const double *smin = RMH_W(eb), *smax = RMH_W(eb) + 27;
+         const double *smin = RMH_W(eb) + C::PCG + 54, *smax = RMH_W(eb) + C::PCG + 81;
          double lo = INFINITY, hi = -INFINITY;
          if (L.bounds_type == 0)
          {
@@ -1551,7 +1581,42 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          RMH_W(eb)[C::PCG + s3] = lo;
          RMH_W(eb)[C::PCG + 27 + s3] = hi;
       }
-      batch_dot<C>(mm, vol, lds, s_acc, ring); // (the barrier inside also publishes the box table)
+      }
+      __syncthreads();
+   }
+   RMH_STAMP(16);
+   int itmax = 0;
+#pragma unroll
+   for (int r = 0; r < DR; r++) { itmax = max(itmax, its[r]); }
+   if (!FUSED)
+   {
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         if (t < NB * D3 && e0 + t / D3 < L.e_end)
+         {
+            L.du[(size_t)e0 * D3 + t] = xg[r];
+            L.m[(size_t)e0 * D3 + t] = mm[r];
+         }
+      }
+      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < L.e_end)
+      {
+         L.xe_min[e0 + tid] = my_min;
+         L.xe_max[e0 + tid] = my_max;
+      }
+   }
+   else
+   {
+      // ---- phase K: LimitMult + RK update (W is free: the last back-transform leg ended with a barrier) ----
+      constexpr double eps = 1.0e-15;
+      RMH_STAMP(21);
+      // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
+      double mass[DR], vol[DR];
+#pragma unroll
+      for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
+      batch_dot2<C>(tmp, mm, mass, vol, lds, s_acc, ring);
+      RMH_STAMP(22);
       RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];
       double dtc = INFINITY; // UpdateTimeStepEstimate(u, du_LO, u_min, u_max), remhos.cpp:1839-1842
@@ -1587,8 +1652,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       RMH_STAMP(18);
       double sumPos[DR], sumNeg[DR];
-      batch_dot<C>(pos, sumPos, lds, s_acc, ring);
-      batch_dot<C>(neg, sumNeg, lds, s_acc, ring);
+      batch_dot2<C>(pos, neg, sumPos, sumNeg, lds, s_acc, ring);
       RMH_STAMP(19);
       double ynew[DR];
 #pragma unroll

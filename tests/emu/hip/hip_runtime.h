@@ -106,6 +106,21 @@ inline void hipemu_permlane32_swap(double &a, double &b)
    b = nb;
 }
 
+// v_permlane16_swap: a = {a.row0, b.row0, a.row2, b.row2}, b = {a.row1, b.row1, a.row3, b.row3}
+inline void hipemu_permlane16_swap(double &a, double &b)
+{
+   const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane, row = lane >> 4, in = lane & 15u;
+   std::memcpy(&hipemu::g_xchg[t], &a, 8);
+   std::memcpy(&hipemu::g_xchg2[t], &b, 8);
+   hipemu_wave_sync();
+   double na = a, nb = b;
+   if (row & 1u) { std::memcpy(&na, &hipemu::g_xchg2[base + (row - 1) * 16 + in], 8); } // odd rows of a <- even rows of b
+   else { std::memcpy(&nb, &hipemu::g_xchg[base + (row + 1) * 16 + in], 8); }          // even rows of b <- odd rows of a
+   hipemu_wave_sync();
+   a = na;
+   b = nb;
+}
+
 template <typename T>
 inline T __builtin_nontemporal_load(const T *p) { return *p; }
 
