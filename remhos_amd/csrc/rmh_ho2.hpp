@@ -1677,7 +1677,31 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       RMH_STAMP(20);
       // element extrema of the new state
-      if (C::WAVE_ALIGNED)
+      if (C::WAVE_ALIGNED && DR == 2)
+      {
+         // min and max of both rounds in one reduction: after the half-wave swap the lower / upper 32 lanes hold
+         // round 0 / 1; max is carried as min of the negated values, the row swap then puts {min r0, -max r0,
+         // min r1, -max r1} into the four 16-lane rows and the four DPP row steps reduce them together
+         const bool has1 = tid + NT < NB * D3;
+         double y0 = ynew[0], y1 = has1 ? ynew[DR == 2 ? 1 : 0] : INFINITY;
+         double z0 = -ynew[0], z1 = has1 ? -ynew[DR == 2 ? 1 : 0] : INFINITY;
+         swap32(y0, y1);
+         swap32(z0, z1);
+         double mn = fmin(y0, y1), nx = fmin(z0, z1);
+         swap16(mn, nx);
+         double x = fmin(mn, nx);
+         x = dpp_minmax<0xB1, 0xF, true>(x);
+         x = dpp_minmax<0x4E, 0xF, true>(x);
+         x = dpp_minmax<0x141, 0xF, true>(x);
+         x = dpp_minmax<0x140, 0xF, true>(x);
+         const int lane = tid & 63, eb = (lane < 32) ? (tid >> 6) : NT / D3 + (tid >> 6);
+         if ((lane & 15) == 15 && eb < NB && e0 + eb < L.e_end)
+         {
+            if (lane & 16) { L.xe_max_out[e0 + eb] = -x; }
+            else { L.xe_min_out[e0 + eb] = x; }
+         }
+      }
+      else if (C::WAVE_ALIGNED)
       {
 #pragma unroll
          for (int r = 0; r < DR; r++)
