@@ -121,7 +121,8 @@ def main():
     cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, lo_type=args.lo, part=PART[args.gpus], rank=rank)
     t0 = time.perf_counter()
     case = Case(lib, cfg)
-    st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused, one_kernel=not args.two_kernels)
+    st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused, one_kernel=not args.two_kernels,
+                 overlap=os.environ.get("RMH_NO_OVERLAP", "0") != "1")  # (escape hatch: exchange, then one launch)
     if args.ref_mass_tol:
         st.ctx.set_mass_tol(0.0, 1e-8, 100)
     setup_s = time.perf_counter() - t0
