@@ -19,6 +19,10 @@ class Stepper:
         self.case = case
         self.overlap = overlap  # one-kernel stage: interior elements overlap the halo exchange
         self.dev = torch.device(device)
+        # validation aid (tools/two_ranks_one_gpu.py): a backend that is not stream-aware needs the pack kernel finished
+        # before it reads the send buffer, and the kernels that read the previous ghosts finished before it overwrites them
+        import os as _os
+        self.sync_exchange = _os.environ.get("RMH_SYNC_EXCHANGE", "0") == "1" and self.dev.type == "cuda"
         self.dist = dist if (dist is not None and case.peers) else None
         self.lo = int(case.cfg.lo_type)
         self.fused_lo4 = fused and self.lo in (3, 4)  # lo 3 / 4: HO kernel + RD kernel + fused limiter/RK kernel
@@ -92,6 +96,8 @@ class Stepper:
         if self.dist is None:
             raise RuntimeError("this rank has neighbour ranks but no torch.distributed group was given")
         self.ctx.halo_pack_records(u, self.send_elems, self.nsend, self.srec)
+        if self.sync_exchange:
+            torch.cuda.synchronize(self.dev)  # backends that are not stream-aware (gloo on device tensors) read srec now
         return self.dist.batch_isend_irecv(self.ops)
 
     # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
