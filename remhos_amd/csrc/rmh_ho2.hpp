@@ -1498,7 +1498,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 
    RMH_STAMP(6);
    // ---- phase J: back to Bernstein coefficients x_b = Ci (x) Ci (x) Ci x_g, stores --------------------------
-   __syncthreads();
+   // (no barrier before the sA slot is overwritten: the PCG loop is left by all threads at the same point -- after
+   // the barrier that follows its sA write, or after the barrier of its last reduction -- and nothing reads sA
+   // between there and here)
 #pragma unroll
    for (int r = 0; r < DR; r++)
    {
