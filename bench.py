@@ -12,16 +12,25 @@ bounds, RK update), inputs resident in HBM.
 Workload (config.workload): BASELINE.json configs[1] -- 3D periodic-cube remap (problem 10,
 Taylor-Green mesh motion, erfc bump), p = 3, -pa -ho 3 -lo 5 -fct 2 (the combination the reference
 itself allows on a device, remhos.cpp:391-397), refined to --rs levels (default 5: 884 736 hex,
-56.6 M dofs).  For N > 1 the SAME global mesh is box-partitioned over the ranks (strong scaling);
-each stage does one RCCL neighbour exchange of ghost-element values.
+56.6 M dofs).  At N = 1 the same JSON line carries a "p6" block: BASELINE.json configs[2]
+(periodic-cube -rs 4 -o 6, 37.9 M dofs), timed after the p = 3 region with the same K and W.
 
-The same JSON line carries `roofline` for the dominant kernel (ho_kernel2<p, 1>, duration from HIP events
+N > 1 (one process per GPU, RCCL): `--scaling weak` (default) keeps one -rs 5 block per GPU -- the lattice is
+refined once more in x (N = 2), x and y (N = 4), all three directions (N = 8: exactly -rs 6) -- and
+`--scaling strong` box-partitions the SAME -rs 5 mesh.  Each stage does one neighbour exchange of ghost-element
+records.  Started without WORLD_SIZE, `--gpus N` launches its N ranks itself (torch.distributed.run as a child
+process, before anything in this process touches the GPU).
+
+The JSON line carries `roofline` for the dominant kernel (ho_kernel2<p, 1>, duration from HIP events
 on the kernel's own stream inside the timed region) and `cpu_baseline` (the C++/OpenMP CPU port of
 oracle/ timed on the host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +41,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # vendor FP64 vector peak of MI355X (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz); tools/ubench_fp64.hip sustains 60.5
 PART = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+KERNEL_SOURCES = ("rmh_ho2.hpp", "rmh_kernels.hpp", "rmh_tables.hpp")
 
 
 def ho_alg_bytes_per_element(p):
@@ -46,6 +56,34 @@ def stage_alg_bytes_per_dof(p):
     """SURVEY.md 8(d) matrix-free model for the whole stage: 8*(8 D^3 + 6 D^2 + 162 + 6 p^3)/D^3."""
     D = p + 1
     return 8.0 * (8 * D**3 + 6 * D**2 + 162 + 6 * p**3) / D**3
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: stored PMC counters are only valid for the kernel they were measured on."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "remhos_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def stored_counters(key, mass_tol, lo):
+    """HBM traffic and FP64 instruction counts per launch from the rocprofv3 --pmc passes committed under profiles/
+    (tools/profile.sh, tools/pmc_insts.sh + tools/update_traffic.py).  They cannot be collected inside this run (the
+    counters need the profiler); an entry is used only if it was measured on the same kernel sources, mass tolerance
+    and LO solver, otherwise the fields are null with the reason."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
+    try:
+        ent = json.load(open(tpath)).get(key)
+    except Exception as e:  # noqa: BLE001
+        return None, None, f"profiles/traffic_ho_kernel.json unreadable: {e}"
+    if not ent:
+        return None, None, f"no PMC entry '{key}' under profiles/"
+    if ent.get("kernel_src_sha") != kernel_source_hash():
+        return None, None, f"PMC entry '{key}' was measured on other kernel sources ({ent.get('kernel_src_sha')})"
+    if ent.get("mass_tol", "rel 1e-14") != mass_tol or ent.get("lo", 5) != lo:
+        return None, None, f"PMC entry '{key}' was measured with other solver options"
+    return ent.get("hbm_bytes_per_launch"), ent.get("fp64_wave_insts_per_launch"), ent.get("source", "profiles/")
 
 
 def cpu_baseline(lib, order, budget_s=15.0):
@@ -65,7 +103,7 @@ def cpu_baseline(lib, order, budget_s=15.0):
         stages += 3
     el = time.perf_counter() - t0
     ndofs = case.u0.size
-    return {
+    out = {
         "value": 1e-6 * ndofs * stages / el,
         "unit": "MDOFs*RK-stage/s",
         "cores": cp.threads,
@@ -73,52 +111,35 @@ def cpu_baseline(lib, order, budget_s=15.0):
         "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads): periodic-cube -rs {rs} -o {order} -p 10 "
                   f"-lo 5 -fct 2, {ndofs} dofs, {stages} RK stages in {el:.2f} s",
     }
+    out.update(cp.extra_report() if hasattr(cp, "extra_report") else {})
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rs", type=int, default=5)
-    ap.add_argument("--order", type=int, default=3)
-    ap.add_argument("--mesh", default="periodic-cube")
-    ap.add_argument("--problem", type=int, default=10)
-    ap.add_argument("--lo", type=int, default=5, help="LO solver: 5 mass-based average (default), 4 subcell residual distribution")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="reference call sequence instead of the fused limiter")
-    ap.add_argument("--ref-mass-tol", action="store_true",
-                    help="local mass solve with the reference's DGMassInverse tolerances (abs 1e-8, rel 0: remhos_ho.cpp:79-80) "
-                         "instead of rel 1e-14 (see DESIGN.md 4)")
-    ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
-    args = ap.parse_args()
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run) and
+    pass its output and exit code through.  Nothing in this process has touched the GPU (torch is not even imported)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
+
+def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters=True):
+    """Set up one configuration, time K steps after W warm-up steps, return the result fields."""
     import torch
 
-    from remhos_amd.capi import load_library
-    from remhos_amd.case import Case, bind_driver, make_config
+    from remhos_amd.case import Case, make_config
     from remhos_amd.stepper import Stepper
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if args.gpus not in PART:
-        raise SystemExit("--gpus must be 1, 2, 4 or 8")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the remhos_amd hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=torch.device(dev))
-
-    lib = bind_driver(load_library())
-    cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, lo_type=args.lo, part=PART[args.gpus], rank=rank)
+    part = PART[world]
+    weak = args.scaling == "weak" and world > 1
+    # weak scaling: one -rs block per rank -- the directions that carry two blocks are refined once more
+    extra = tuple(1 if (weak and part[d] == 2) else 0 for d in range(3))
+    cfg = make_config(args.mesh, rs, order, args.problem, -1.0, 0.5, lo_type=args.lo, part=part, rank=rank, rs_extra=extra)
     t0 = time.perf_counter()
     case = Case(lib, cfg)
     st = Stepper(lib, case, device=dev, dist=dist, fused=not args.unfused, one_kernel=not args.two_kernels,
@@ -152,7 +173,6 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-
     stages = 3 * args.steps
     value = 1e-6 * global_dofs * stages / elapsed
     # sanity of the state after the run: mass conservation and bounds (not timed)
@@ -161,97 +181,172 @@ def main():
         red = torch.tensor([mass], dtype=torch.float64, device=dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
         mass = float(red[0])
+        red = torch.tensor([umax], dtype=torch.float64, device=dev)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        umax = float(red[0])
+    one_kernel = st.one_kernel
+    ne_owned, ndof, ne_global, n_lat = case.ne_owned, case.ndof, case.ne_global, list(case.n)
+    st.close()
+    del st, case
+    torch.cuda.empty_cache()
+
+    mass_tol = "abs 1e-8 (reference)" if args.ref_mass_tol else "rel 1e-14"
+    ho_avg_s = tim[0] / stages
+    if one_kernel:
+        # the dominant kernel is the whole stage: SURVEY 8(d) matrix-free per-dof figure
+        ho_bytes = int(stage_alg_bytes_per_dof(order) * ne_owned * ndof)
+        kname = f"rmh::ho_kernel2<{order}, {3 if args.lo in (3, 4) else 1}> (whole RK stage)"
+    else:
+        ho_bytes = ho_alg_bytes_per_element(order) * ne_owned
+        kname = f"rmh::ho_kernel2<{order}, 0>"
+    achieved = ho_bytes / ho_avg_s / 1e9
+    traffic, fp64, why = None, None, "not looked up"
+    if with_counters:
+        key = f"{args.mesh}-rs{rs}-o{order}-n{world}" + ("-stage" if one_kernel else "")
+        traffic, wi, why = stored_counters(key, mass_tol, args.lo)
+        if wi:
+            # the kernel's real bound: FP64 VALU.  Issued lane-flops = wave64 instructions x 64 lanes x (2 for FMA)
+            flops = 64.0 * (2.0 * wi["fma"] + wi["mul"] + wi["add"])
+            fp64 = {"bound": "fp64 valu", "flops_per_launch": flops, "achieved": flops / ho_avg_s / 1e12,
+                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / ho_avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                    "fp64_share_of_valu_insts": (wi["fma"] + wi["mul"] + wi["add"]) / wi["all_valu"]}
+    lattice = "x".join(str(k) for k in n_lat)
+    res = {
+        "value": value,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "config": {
+            "workload": f"{args.mesh} -rs {rs}{'+' + ''.join(str(k) for k in extra) if any(extra) else ''} -o {order} -p {args.problem} "
+                        f"{'remap' if args.problem >= 10 else 'transport'}, -pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP"
+                        + (" (BASELINE configs[1])" if (args.mesh, order, args.problem, args.lo, rs) == ("periodic-cube", 3, 10, 5, 5) and world == 1 else "")
+                        + (" (BASELINE configs[2])" if (args.mesh, order, args.problem, args.lo, rs) == ("periodic-cube", 6, 10, 5, 4) and world == 1 else "")
+                        + (" (BASELINE configs[3])" if (args.mesh, order, args.problem, args.lo) == ("periodic-cube", 3, 10, 5) and world > 1 else "")
+                        + f"; {lattice} = {ne_global} hex, {global_dofs} dofs",
+            "global_dofs": global_dofs,
+            "elements": ne_global,
+            "dofs_per_gpu": ne_owned * ndof,
+            "partition": "x".join(str(k) for k in part),
+            "limiter": "reference call sequence" if args.unfused else ("inside the stage kernel" if one_kernel else "fused (LO avg + bounds + ClipScale + RK update)"),
+            "dt": dt,
+            "mass_cg_max_iters": cg_iters,
+            "mass_tol": mass_tol,
+            "final_mass": mass,
+            "max_value": umax,
+            "setup_s": setup_s,
+        },
+        "roofline": {
+            "kernel": kname,
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": why,
+            "avg_launch_ms": 1e3 * ho_avg_s,
+            "alg_bytes_per_launch": ho_bytes,
+            "achieved_is": "ALGORITHMIC bytes of SURVEY 8(d) (matrix-free model) / launch time -- a model figure, not measured HBM GB/s; "
+                           "the measured HBM bytes per launch are `traffic`",
+            "binding_resource": "fp64 valu (geometry is recomputed from the 27 nodes per stage: ~130 kflop/element at p=3); see roofline_fp64 and DESIGN.md 3.1",
+        },
+        "roofline_fp64": fp64,
+        "buckets_s": {"ho_rhs_plus_inv_or_stage": tim[0], "lo": tim[2], "fct_or_fused_limiter": tim[3]},
+        # the reference's figures of merit (remhos.cpp:1918-1966): 1e-6 * dofs * stages / bucket time of rank 0; its
+        # printed total uses T_rhs + T_LO + T_FCT.  Here RHS and INV are one kernel (bucket 0); with the one-kernel
+        # stage everything is in bucket 0.  "value" above is the all-inclusive wall-clock figure.
+        "fom_reference_style": {
+            k: (1e-6 * global_dofs * stages / v if v > 0 else None)
+            for k, v in (("rhs_plus_inv", tim[0]), ("lo", tim[2]), ("fct", tim[3]), ("total_rhs_lo_fct", tim[0] + tim[2] + tim[3]))
+        },
+        "stage_roofline": {
+            "alg_bytes_per_dof": stage_alg_bytes_per_dof(order),
+            "achieved_GBs": value * 1e6 * stage_alg_bytes_per_dof(order) / 1e9,
+            "frac_of_hbm_peak": value * 1e6 * stage_alg_bytes_per_dof(order) / 1e9 / (HBM_PEAK_GBS * world),
+        },
+    }
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rs", type=int, default=5)
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--mesh", default="periodic-cube")
+    ap.add_argument("--problem", type=int, default=10)
+    ap.add_argument("--lo", type=int, default=5, help="LO solver: 5 mass-based average (default), 4 subcell residual distribution")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: one -rs block per GPU (weak, default) or the same -rs mesh partitioned (strong)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-p6", action="store_true", help="skip the p = 6 block (BASELINE configs[2]) of the N = 1 line")
+    ap.add_argument("--unfused", action="store_true", help="reference call sequence instead of the fused limiter")
+    ap.add_argument("--ref-mass-tol", action="store_true",
+                    help="local mass solve with the reference's DGMassInverse tolerances (abs 1e-8, rel 0: remhos_ho.cpp:79-80) "
+                         "instead of rel 1e-14 (see DESIGN.md 4)")
+    ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
+    args = ap.parse_args()
+    if args.gpus not in PART:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args))  # (before torch is imported: this process never touches the GPU)
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
+
+    import torch
+
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the remhos_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist, backend = None, None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = dist.get_backend()
+
+    lib = bind_driver(load_library())
+    main_res = measure(args, lib, args.order, args.rs, world, rank, dev, dist, backend)
+    p6 = None
+    if world == 1 and not args.no_p6 and (args.order, args.mesh, args.problem) == (3, "periodic-cube", 10):
+        p6 = measure(args, lib, 6, 4, world, rank, dev, dist, backend)
 
     if rank == 0:
-        ho_avg_s = tim[0] / stages
-        if st.one_kernel:
-            # the dominant kernel is the whole stage: SURVEY 8(d) matrix-free per-dof figure
-            ho_bytes = int(stage_alg_bytes_per_dof(args.order) * case.ne_owned * case.ndof)
-            kname = f"rmh::ho_kernel2<{args.order}, {3 if args.lo in (3, 4) else 1}> (whole RK stage)"
-        else:
-            ho_bytes = ho_alg_bytes_per_element(args.order) * case.ne_owned
-            kname = f"rmh::ho_kernel2<{args.order}, 0>" if os.environ.get("RMH_HO_KERNEL", "2") != "1" else f"rmh::ho_kernel<{args.order}, 0>"
-        achieved = ho_bytes / ho_avg_s / 1e9
-        traffic, fp64 = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"{args.mesh}-rs{args.rs}-o{args.order}-n{args.gpus}" + ("-stage" if st.one_kernel else "")
-                ent = tj.get(key, {}) if args.lo == 5 else {}
-                traffic = ent.get("hbm_bytes_per_launch")
-                wi = ent.get("fp64_wave_insts_per_launch")
-                if wi:
-                    # the kernel's real bound: FP64 VALU.  Issued lane-flops = wave64 instructions x 64 lanes x (2 for FMA)
-                    flops = 64.0 * (2.0 * wi["fma"] + wi["mul"] + wi["add"])
-                    fp64 = {"bound": "fp64 valu", "flops_per_launch": flops, "achieved": flops / ho_avg_s / 1e12,
-                            "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / ho_avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                            "fp64_share_of_valu_insts": (wi["fma"] + wi["mul"] + wi["add"]) / wi["all_valu"]}
-            except Exception:
-                traffic, fp64 = None, None
         out = {
             "metric": "MDOFs*RK-stage/s, 3D hex remap",
-            "value": value,
+            "value": main_res["value"],
             "unit": "MDOFs*RK-stage/s",
             "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {
-                "workload": f"{args.mesh} -rs {args.rs} -o {args.order} -p {args.problem} {'remap' if args.problem >= 10 else 'transport'}, "
-                            f"-pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP"
-                            + (" (BASELINE configs[1])" if (args.mesh, args.order, args.problem, args.lo) == ("periodic-cube", 3, 10, 5) else "")
-                            + f"; {case.ne_global} hex, {global_dofs} dofs",
-                "global_dofs": global_dofs,
-                "elements": case.ne_global,
-                "partition": "x".join(str(k) for k in PART[args.gpus]),
-                "limiter": "reference call sequence" if args.unfused else ("inside the stage kernel" if st.one_kernel else "fused (LO avg + bounds + ClipScale + RK update)"),
-                "dt": dt,
-                "mass_cg_max_iters": cg_iters,
-                "mass_tol": "abs 1e-8 (reference)" if args.ref_mass_tol else "rel 1e-14",
-                "final_mass": mass,
-                "max_value": umax,
-                "setup_s": setup_s,
-            },
-            "roofline": {
-                "kernel": kname,
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "avg_launch_ms": 1e3 * ho_avg_s,
-                "alg_bytes_per_launch": ho_bytes,
-                "note": "FP64 VALU / latency bound at p=3 in matrix-free form (geometry recomputed per stage), not HBM bound; see DESIGN.md 3.1",
-            },
-            "roofline_fp64": fp64,
-            "buckets_s": {"ho_rhs_plus_inv_or_stage": tim[0], "lo": tim[2], "fct_or_fused_limiter": tim[3]},
-            # the reference's figures of merit (remhos.cpp:1918-1966): 1e-6 * dofs * stages / bucket time of rank 0; its
-            # printed total uses T_rhs + T_LO + T_FCT.  Here RHS and INV are one kernel (bucket 0); with the one-kernel
-            # stage everything is in bucket 0.  "value" above is the all-inclusive wall-clock figure.
-            "fom_reference_style": {
-                k: (1e-6 * global_dofs * stages / v if v > 0 else None)
-                for k, v in (("rhs_plus_inv", tim[0]), ("lo", tim[2]), ("fct", tim[3]), ("total_rhs_lo_fct", tim[0] + tim[2] + tim[3]))
-            },
-            "stage_roofline": {
-                "alg_bytes_per_dof": stage_alg_bytes_per_dof(args.order),
-                "achieved_GBs": value * 1e6 * stage_alg_bytes_per_dof(args.order) / 1e9,
-                "frac_of_hbm_peak": value * 1e6 * stage_alg_bytes_per_dof(args.order) / 1e9 / (HBM_PEAK_GBS * args.gpus),
-            },
         }
+        out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+        if world > 1:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["backend"] = backend
+        if p6 is not None:
+            out["p6"] = {"metric": out["metric"], "unit": out["unit"], "steps": args.steps, "warmup": args.warmup, **p6}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, args.order)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    st.close()
 
 
 if __name__ == "__main__":

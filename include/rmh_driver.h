@@ -32,6 +32,8 @@ typedef struct {
    int dt_control;    /* -dtc: 0 fixed dt, 1 LOBoundsError (needs -bt 1; remhos.cpp:1178-1197)  */
    int ho_type;       /* -ho : 3 local inverse (0 means 3), 2 CG to rel. tolerance 1e-12        */
    int save;          /* -save: write meshHO_init/final.mesh and sltn_init/final.gf (cwd)        */
+   int rs_extra[3];   /* additional uniform refinements per direction (0: the reference's meshes;
+                         bench.py's weak-scaling lattices refine the partitioned directions once more) */
 } rmhd_config;
 
 typedef struct {

@@ -32,6 +32,10 @@ int fail(int code, const std::string &msg)
       }                                                                                        \
    } while (0)
 
+// every entry point that touches the device makes its context's device current first (two contexts on different
+// devices in one process would otherwise launch on whatever device the caller left current)
+#define RMH_ENTER(c) RMH_HIP(hipSetDevice((c)->device))
+
 struct EventPair
 {
    hipEvent_t a, b;
@@ -268,6 +272,41 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       default: return fail(RMH_ERR_INVALID, "unsupported order");                              \
    }
 
+// device buffers, tables and lo 4 set-up data of a new context (rmh_create releases the context when this fails)
+int create_device_state(rmh_ctx *c, const rmh_layout *L)
+{
+   const size_t ne = c->ne;
+   int rc = 0;
+   if ((rc = upload(&c->d_x0, L->x0, ne * 81))) { return rc; }
+   if ((rc = upload(&c->d_vel, L->vel, ne * 81))) { return rc; }
+   if ((rc = upload(&c->d_nbr, L->face_nbr, ne * 6))) { return rc; }
+   if ((rc = upload(&c->d_st27, L->stencil27, ne * 27))) { return rc; }
+   if (L->subcell_vel)
+   {
+      if ((rc = upload(&c->d_subvel, L->subcell_vel, ne * 3 * c->ndof))) { return rc; }
+   }
+   RMH_DISPATCH(c, rc = create_tables<P>(c));
+   if (rc) { return rc; }
+   if (c->d_subvel)
+   {
+      const size_t ns = (size_t)c->p * c->p * c->p;
+      RMH_HIP(hipMalloc((void **)&c->d_subx0, ne * 3 * c->ndof * sizeof(double)));
+      RMH_HIP(hipMalloc((void **)&c->d_subvmid, ne * 3 * ns * sizeof(double)));
+      RMH_DISPATCH(c, hipLaunchKernelGGL((subcell_setup_kernel<P>), dim3(c->ne), dim3(64), 0, nullptr, (const double *)c->d_x0,
+                                         (const double *)c->d_subvel, (const double *)c->d_tab, c->d_subx0, c->d_subvmid));
+      RMH_HIP(hipGetLastError());
+      RMH_HIP(hipDeviceSynchronize());
+   }
+   RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_min2, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_max2, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_cg, sizeof(int)));
+   RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
+   return 0;
+}
+
 } // namespace
 
 #ifdef RMH_STAMPS
@@ -328,7 +367,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
       return fail(RMH_ERR_NO_DEVICE, "no HIP device: the remhos_amd hot path has no CPU fallback");
    }
    if (L->device < 0 || L->device >= ndev) { return fail(RMH_ERR_INVALID, "bad device ordinal"); }
-   RMH_HIP(hipSetDevice(L->device));
+   RMH_HIP(hipSetDevice(L->device)); // (stays current: every entry point makes its context's device current)
    rmh_ctx *c = new rmh_ctx;
    c->p = L->order;
    c->ne = L->ne_owned;
@@ -338,35 +377,9 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
    c->gh_ustride = c->ndof;
    if (const char *v = std::getenv("RMH_HO_KERNEL")) { c->ho_variant = std::atoi(v) == 1 ? 1 : 2; }
-   const size_t ne = c->ne;
-   int rc = 0;
-   if ((rc = upload(&c->d_x0, L->x0, ne * 81))) { delete c; return rc; }
-   if ((rc = upload(&c->d_vel, L->vel, ne * 81))) { delete c; return rc; }
-   if ((rc = upload(&c->d_nbr, L->face_nbr, ne * 6))) { delete c; return rc; }
-   if ((rc = upload(&c->d_st27, L->stencil27, ne * 27))) { delete c; return rc; }
-   if (L->subcell_vel)
-   {
-      if ((rc = upload(&c->d_subvel, L->subcell_vel, ne * 3 * c->ndof))) { delete c; return rc; }
-   }
-   RMH_DISPATCH(c, rc = create_tables<P>(c));
-   if (rc) { delete c; return rc; }
-   if (c->d_subvel)
-   {
-      const size_t ns = (size_t)c->p * c->p * c->p;
-      RMH_HIP(hipMalloc((void **)&c->d_subx0, ne * 3 * c->ndof * sizeof(double)));
-      RMH_HIP(hipMalloc((void **)&c->d_subvmid, ne * 3 * ns * sizeof(double)));
-      RMH_DISPATCH(c, hipLaunchKernelGGL((subcell_setup_kernel<P>), dim3(c->ne), dim3(64), 0, nullptr, (const double *)c->d_x0,
-                                         (const double *)c->d_subvel, (const double *)c->d_tab, c->d_subx0, c->d_subvmid));
-      RMH_HIP(hipGetLastError());
-      RMH_HIP(hipDeviceSynchronize());
-   }
-   RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
-   RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
-   RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));
-   RMH_HIP(hipMalloc((void **)&c->d_xe_min2, ne * sizeof(double)));
-   RMH_HIP(hipMalloc((void **)&c->d_xe_max2, ne * sizeof(double)));
-   RMH_HIP(hipMalloc((void **)&c->d_cg, sizeof(int)));
-   RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
+   // every failure past this point releases the context and whatever it already owns
+   const int rc = create_device_state(c, L);
+   if (rc) { rmh_destroy(c); return rc; }
    *out = c;
    return RMH_OK;
 }
@@ -374,6 +387,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
 void rmh_destroy(rmh_ctx *c)
 {
    if (!c) { return; }
+   (void)hipSetDevice(c->device);
    void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
@@ -429,6 +443,7 @@ int rmh_set_ghost_records(rmh_ctx *c, const double *rec)
 int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
 {
    if (!c || !u || !du) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
    EventPair ep;
    int rc = timer_begin(c, 0, ep);
@@ -437,7 +452,7 @@ int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
    if (rc) { return rc; }
    rc = timer_end(c, 0, ep);
    c->ho_done = true;
-   c->xe_of = u;
+   c->xe_of = nullptr; // see rmh_stage_fused_range: only the fused stage chain sets it
    return rc;
 }
 
@@ -446,6 +461,7 @@ const double *rmh_lumped_mass(rmh_ctx *c) { return c ? c->d_m : nullptr; }
 int rmh_compute_lumped_mass(rmh_ctx *c, double t, double *m)
 {
    if (!c || !m) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    int rc = 0;
    RMH_DISPATCH(c, rc = (launch_ho<P, 1>(c, nullptr, nullptr, m, t)));
    return rc;
@@ -454,6 +470,8 @@ int rmh_compute_lumped_mass(rmh_ctx *c, double t, double *m)
 int rmh_lo_massavg(rmh_ctx *c, const double *u, const double *du_ho, double dt, double *du_lo)
 {
    if (!c || !u || !du_ho || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
+   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
    if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_lo_massavg needs the lumped mass of rmh_ho_apply"); }
    EventPair ep;
    int rc = timer_begin(c, 2, ep);
@@ -468,6 +486,8 @@ namespace
 {
 int lo_rd(rmh_ctx *c, const double *u, double *du_lo, int lo_type)
 {
+   RMH_ENTER(c);
+   c->xe_of = nullptr; // (d_xe_min/max now hold the extrema of u, but only the fused stage chain may rely on xe_of)
    EventPair ep;
    int rc = timer_begin(c, 2, ep);
    if (rc) { return rc; }
@@ -501,6 +521,7 @@ int rmh_lo_rd(rmh_ctx *c, const double *u, double *du_lo)
 int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)
 {
    if (!c || !u || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
                                       xe_min, xe_max));
    RMH_HIP(hipGetLastError());
@@ -510,6 +531,8 @@ int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)
 int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u_min, double *u_max)
 {
    if (!c || !xe_min || !xe_max || !u_min || !u_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
+   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
                                       c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
@@ -525,6 +548,8 @@ int rmh_fct_clipscale(rmh_ctx *c, const double *u, const double *m, const double
    {
       return fail(RMH_ERR_INVALID, "null argument");
    }
+   RMH_ENTER(c);
+   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
    EventPair ep;
    int rc = timer_begin(c, 3, ep);
    if (rc) { return rc; }
@@ -539,6 +564,8 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
 {
    if (!c || !u || !du_ho || (!du && !y_out)) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_limit_fused must follow rmh_ho_apply on the same u"); }
+   RMH_ENTER(c);
+   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    LimitArgs la;
    la.u = u;
@@ -586,6 +613,7 @@ int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *
                           double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish)
 {
    if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    if (y_out == u || du == u) { return fail(RMH_ERR_INVALID, "rmh_stage_fused: the output must not alias u"); }
    if (e_begin < 0 || e_end > c->ne || e_begin > e_end) { return fail(RMH_ERR_INVALID, "rmh_stage_fused_range: bad element range"); }
@@ -599,7 +627,9 @@ int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *
    if (c->xe_of != u)
    {
       // element extrema of the stage input are not at hand: one streaming pass (normally they are
-      // left behind by the previous fused stage, whose output is this stage's input)
+      // left behind by the previous fused stage, whose output is this stage's input).  xe_of is set ONLY by a
+      // finished fused stage (to its y_out) and cleared by every other entry point that writes caller vectors; a
+      // caller that modifies y_out by other means before feeding it back calls rmh_invalidate_extrema
       rc = rmh_elem_minmax(c, u, c->d_xe_min, c->d_xe_max);
       if (rc) { return rc; }
       c->xe_of = u;
@@ -634,6 +664,7 @@ int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend,
                   double *out_max)
 {
    if (!c || !u || (nsend > 0 && (!send_elems || !rows || !out_min || !out_max))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    if (nsend <= 0) { return RMH_OK; }
    RMH_DISPATCH(c, hipLaunchKernelGGL((halo_pack_kernel<P>), dim3(nsend), dim3(KCfg<P>::NT), 0, c->stream, u, send_elems,
                                       rows, out_min, out_max, c->ndof, 1));
@@ -644,6 +675,7 @@ int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend,
 int rmh_halo_pack_records(rmh_ctx *c, const double *u, const int *send_elems, int nsend, double *rec)
 {
    if (!c || !u || (nsend > 0 && (!send_elems || !rec))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    if (nsend <= 0) { return RMH_OK; }
    const int w = c->ndof + 2;
    RMH_DISPATCH(c, hipLaunchKernelGGL((halo_pack_kernel<P>), dim3(nsend), dim3(KCfg<P>::NT), 0, c->stream, u, send_elems,
@@ -662,6 +694,7 @@ int rmh_enable_timers(rmh_ctx *c, int on)
 int rmh_reset_timers(rmh_ctx *c)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   RMH_ENTER(c);
    int rc = timers_resolve(c);
    for (int b = 0; b < 4; b++) { c->tacc[b] = 0.0; }
    return rc;
@@ -670,6 +703,7 @@ int rmh_reset_timers(rmh_ctx *c)
 int rmh_timers(rmh_ctx *c, double t[4])
 {
    if (!c || !t) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    int rc = timers_resolve(c);
    for (int b = 0; b < 4; b++) { t[b] = c->tacc[b]; }
    return rc;
@@ -678,6 +712,7 @@ int rmh_timers(rmh_ctx *c, double t[4])
 int rmh_last_cg_iters(rmh_ctx *c, int *max_iters)
 {
    if (!c || !max_iters) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    RMH_HIP(hipStreamSynchronize(c->stream));
    RMH_HIP(hipMemcpy(max_iters, c->d_cg, sizeof(int), hipMemcpyDeviceToHost));
    RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
@@ -715,6 +750,7 @@ __global__ void set_scalar_kernel(double *p, double v) { *p = v; }
 int rmh_dt_estimate_reset(rmh_ctx *c)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   RMH_ENTER(c);
    if (!c->d_dt_est) { RMH_HIP(hipMalloc((void **)&c->d_dt_est, sizeof(double))); }
    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->d_dt_est, (double)INFINITY);
    RMH_HIP(hipGetLastError());
@@ -732,6 +768,7 @@ int rmh_set_dt_control(rmh_ctx *c, int on)
 int rmh_dt_estimate_update(rmh_ctx *c, const double *x, const double *dx, const double *x_min, const double *x_max)
 {
    if (!c || !x || !dx || !x_min || !x_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    if (!c->dt_control) { return RMH_OK; } // TimeStepControl::FixedTimeStep: nothing to do (remhos.cpp:1973)
    const size_t n = (size_t)c->ne * c->ndof;
    const int nblk = (int)std::min<size_t>((n + 255) / 256, 4096);
@@ -743,6 +780,7 @@ int rmh_dt_estimate_update(rmh_ctx *c, const double *x, const double *dx, const 
 int rmh_dt_estimate_get(rmh_ctx *c, double *dt)
 {
    if (!c || !dt) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
    if (!c->d_dt_est) { return fail(RMH_ERR_STATE, "dt control is off"); }
    RMH_HIP(hipStreamSynchronize(c->stream));
    RMH_HIP(hipMemcpy(dt, c->d_dt_est, sizeof(double), hipMemcpyDeviceToHost));

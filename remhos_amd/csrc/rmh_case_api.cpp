@@ -30,6 +30,7 @@ CaseConfig to_config(const rmhd_config &c)
    k.py = c.py > 0 ? c.py : 1;
    k.pz = c.pz > 0 ? c.pz : 1;
    k.rank = c.rank;
+   for (int d = 0; d < 3; d++) { k.rs_extra[d] = c.rs_extra[d]; }
    return k;
 }
 } // namespace remhos

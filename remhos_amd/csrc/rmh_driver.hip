@@ -341,7 +341,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       // For remap, the pseudo-time always evolves from 0 to 1 (remhos.cpp:1128-1134)
       const double t_final = cd.exec_mode == 1 ? 1.0 : cc.t_final;
       bool done = false;
-      int ti = 0;
+      int ti = 0, ti_total = 0; // accepted steps / all steps incl. repeated ones (remhos.cpp:1142)
       HIP_CALL(hipDeviceSynchronize());
       const auto w0 = std::chrono::steady_clock::now();
       Vector y1(fused ? vsize : 0), y2(fused ? vsize : 0);
@@ -371,6 +371,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
          }
          else { ode_solver.Step(u, t, dt_real); }
          ti++;
+         ti_total++;
          if (dtc)
          {
             // remhos.cpp:1178-1197
@@ -390,7 +391,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
             else if (dt_ratio > 1.25) { dt *= 1.02; }
          }
          done = (t >= t_final - 1.e-8 * dt);
-         if (ti == cc.max_steps) { done = true; }
+         if (ti_total == cc.max_steps) { done = true; } // -ms counts repeated steps too (remhos.cpp:1296)
       }
       HIP_CALL(hipDeviceSynchronize());
       const auto w1 = std::chrono::steady_clock::now();
@@ -423,7 +424,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       res->dt = dt;
       res->t_end = t;
       res->steps = ti;
-      res->stages = 3 * ti;
+      res->stages = 3 * ti_total; // the FOMs count repeated steps too (remhos.cpp:1340-1348)
       res->global_dofs = pfes.GlobalVSize();
       res->t_rhs = T.sw_rhs;
       res->t_inv = T.sw_L2inv;

@@ -198,28 +198,34 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    if (cfg.rank < 0 || cfg.rank >= nranks) { return "bad rank"; }
    if (cfg.lo_type != 3 && cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 3, 4 or 5"; }
 
-   const std::vector<double> verts = refine(md.coarse, cfg.rs);
-   const int N = (int)verts.size() - 1;
+   // per direction: -rs levels plus rs_extra[d] more (0 in the reference's meshes; the weak-scaling lattices of
+   // bench.py refine the directions that carry two partition blocks once more)
+   std::vector<double> vertsd[3];
+   int Nd[3];
    const int P[3] = {cfg.px, cfg.py, cfg.pz};
    for (int d = 0; d < 3; d++)
    {
-      if (P[d] > N) { return "more partition blocks than elements in a direction"; }
+      if (cfg.rs_extra[d] < 0 || cfg.rs_extra[d] > 4) { return "bad rs_extra"; }
+      vertsd[d] = refine(md.coarse, cfg.rs + cfg.rs_extra[d]);
+      Nd[d] = (int)vertsd[d].size() - 1;
+      if (P[d] > Nd[d]) { return "more partition blocks than elements in a direction"; }
    }
+   const int Nx = Nd[0], Ny = Nd[1];
    out = CaseData();
    out.order = cfg.order;
    out.exec_mode = cfg.problem < 10 ? 0 : 1; // remhos.cpp:437-440
    const int D = cfg.order + 1, p = cfg.order;
    out.ndof = D * D * D;
    out.periodic = md.periodic;
-   out.ne_global = (long long)N * N * N;
+   out.ne_global = (long long)Nd[0] * Nd[1] * Nd[2];
    for (int d = 0; d < 3; d++)
    {
-      out.n[d] = N;
-      out.bb_min[d] = verts.front();
-      out.bb_max[d] = verts.back();
+      out.n[d] = Nd[d];
+      out.bb_min[d] = vertsd[d].front();
+      out.bb_max[d] = vertsd[d].back();
    }
    const int r3[3] = {cfg.rank % cfg.px, (cfg.rank / cfg.px) % cfg.py, cfg.rank / (cfg.px * cfg.py)};
-   auto chunk_lo = [&](int d, int r) { return (int)(((long long)r * N) / P[d]); };
+   auto chunk_lo = [&](int d, int r) { return (int)(((long long)r * Nd[d]) / P[d]); };
    for (int d = 0; d < 3; d++)
    {
       out.lo[d] = chunk_lo(d, r3[d]);
@@ -228,7 +234,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    auto owner_1d = [&](int d, int g)
    {
       // inverse of chunk_lo
-      int r = (int)(((long long)(g + 1) * P[d] - 1) / N);
+      int r = (int)(((long long)(g + 1) * P[d] - 1) / Nd[d]);
       while (chunk_lo(d, r) > g) { r--; }
       while (chunk_lo(d, r + 1) <= g) { r++; }
       return r;
@@ -240,27 +246,31 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    const int problem = cfg.problem;
 
    // mesh nodes per direction (Gauss-Lobatto order 2 = vertices and midpoints)
-   std::vector<double> nodes1d(2 * N + 1);
-   for (int i = 0; i <= N; i++) { nodes1d[2 * i] = verts[i]; }
-   for (int i = 0; i < N; i++) { nodes1d[2 * i + 1] = 0.5 * verts[i] + 0.5 * verts[i + 1]; }
+   std::vector<double> nodes1d[3];
+   for (int d = 0; d < 3; d++)
+   {
+      nodes1d[d].resize(2 * Nd[d] + 1);
+      for (int i = 0; i <= Nd[d]; i++) { nodes1d[d][2 * i] = vertsd[d][i]; }
+      for (int i = 0; i < Nd[d]; i++) { nodes1d[d][2 * i + 1] = 0.5 * vertsd[d][i] + 0.5 * vertsd[d][i + 1]; }
+   }
 
    // ---- time step (remhos.cpp:538-553): 0.25 * h_e / |v(center)|, min over ALL elements ------------
    double dt = cfg.dt;
    if (dt < 0.0)
    {
       dt = INFINITY;
-      for (int ez = 0; ez < N; ez++)
+      for (int ez = 0; ez < Nd[2]; ez++)
       {
-         for (int ey = 0; ey < N; ey++)
+         for (int ey = 0; ey < Nd[1]; ey++)
          {
-            for (int ex = 0; ex < N; ex++)
+            for (int ex = 0; ex < Nd[0]; ex++)
             {
                // J(center) of the Q2 lattice element: differences of the mid-face nodes
-               const double hx = nodes1d[2 * ex + 2] - nodes1d[2 * ex];
-               const double hy = nodes1d[2 * ey + 2] - nodes1d[2 * ey];
-               const double hz = nodes1d[2 * ez + 2] - nodes1d[2 * ez];
+               const double hx = nodes1d[0][2 * ex + 2] - nodes1d[0][2 * ex];
+               const double hy = nodes1d[1][2 * ey + 2] - nodes1d[1][2 * ey];
+               const double hz = nodes1d[2][2 * ez + 2] - nodes1d[2][2 * ez];
                const double length = std::pow(std::fabs(hx * hy * hz), 1. / 3.);
-               const double xc[3] = {nodes1d[2 * ex + 1], nodes1d[2 * ey + 1], nodes1d[2 * ez + 1]};
+               const double xc[3] = {nodes1d[0][2 * ex + 1], nodes1d[1][2 * ey + 1], nodes1d[2][2 * ez + 1]};
                double v[3];
                velocity_function(problem, bmin, bmax, xc, v);
                const double speed = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + 1e-14);
@@ -282,7 +292,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
       for (long long k = a; k < b; k++)
       {
          const int ix = (int)(k % nnx), iy = (int)((k / nnx) % nny), iz = (int)(k / ((long long)nnx * nny));
-         const double x0[3] = {nodes1d[2 * out.lo[0] + ix], nodes1d[2 * out.lo[1] + iy], nodes1d[2 * out.lo[2] + iz]};
+         const double x0[3] = {nodes1d[0][2 * out.lo[0] + ix], nodes1d[1][2 * out.lo[1] + iy], nodes1d[2][2 * out.lo[2] + iz]};
          double x[3] = {x0[0], x0[1], x0[2]}, v[3];
          velocity_function(problem, bmin, bmax, x, v);
          if (remap)
@@ -320,7 +330,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
       for (long long e = a; e < b; e++)
       {
          const int lx = (int)(e % nlx), ly = (int)((e / nlx) % nly), lz = (int)(e / ((long long)nlx * nly));
-         out.owned_gid[e] = (long long)(out.lo[0] + lx) + (long long)N * ((out.lo[1] + ly) + (long long)N * (out.lo[2] + lz));
+         out.owned_gid[e] = (long long)(out.lo[0] + lx) + (long long)Nx * ((out.lo[1] + ly) + (long long)Ny * (out.lo[2] + lz));
          double *ex0 = &out.x0[(size_t)e * 81], *ev = &out.vel[(size_t)e * 81];
          for (int az = 0; az < 3; az++)
          {
@@ -375,7 +385,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
                         const int id[3] = {ix, iy, iz};
                         for (int c = 0; c < 3; c++)
                         {
-                           bdr = bdr || (g[c] == 0 && id[c] == 0) || (g[c] == N - 1 && id[c] == p);
+                           bdr = bdr || (g[c] == 0 && id[c] == 0) || (g[c] == Nd[c] - 1 && id[c] == p);
                         }
                      }
                      for (int c = 0; c < 3; c++)
@@ -394,11 +404,11 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    out.face_nbr.assign((size_t)ne * 6, -1);
    std::map<std::pair<int, long long>, int> ghost_slot; // (owner, gid) -> slot, ordered
    std::map<int, std::vector<long long>> send_sets;       // peer -> gids of owned elements it needs
-   auto wrap = [&](int g, bool &ok)
+   auto wrap = [&](int d, int g, bool &ok)
    {
-      if (g >= 0 && g < N) { return g; }
+      if (g >= 0 && g < Nd[d]) { return g; }
       if (!md.periodic) { ok = false; return 0; }
-      return (g % N + N) % N;
+      return (g % Nd[d] + Nd[d]) % Nd[d];
    };
    // pass 1: collect ghosts and send sets (only elements near the box surface have remote neighbours)
    for (int lz = 0; lz < nlz; lz++)
@@ -414,12 +424,12 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
             {
                const int o[3] = {s % 3 - 1, (s / 3) % 3 - 1, s / 9 - 1};
                bool ok = true;
-               const int g[3] = {wrap(out.lo[0] + lx + o[0], ok), wrap(out.lo[1] + ly + o[1], ok),
-                                 wrap(out.lo[2] + lz + o[2], ok)};
+               const int g[3] = {wrap(0, out.lo[0] + lx + o[0], ok), wrap(1, out.lo[1] + ly + o[1], ok),
+                                 wrap(2, out.lo[2] + lz + o[2], ok)};
                if (!ok) { continue; }
                const int owner = owner_1d(0, g[0]) + cfg.px * (owner_1d(1, g[1]) + cfg.py * owner_1d(2, g[2]));
                if (owner == cfg.rank) { continue; }
-               const long long gid = g[0] + (long long)N * (g[1] + (long long)N * g[2]);
+               const long long gid = g[0] + (long long)Nx * (g[1] + (long long)Ny * g[2]);
                ghost_slot[{owner, gid}] = 0;
                send_sets[owner].push_back(mygid);
             }
@@ -436,7 +446,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    out.ne_ghost = slot;
    auto local_of_gid = [&](long long gid)
    {
-      const int gx = (int)(gid % N), gy = (int)((gid / N) % N), gz = (int)(gid / ((long long)N * N));
+      const int gx = (int)(gid % Nx), gy = (int)((gid / Nx) % Ny), gz = (int)(gid / ((long long)Nx * Ny));
       return (gx - out.lo[0]) + nlx * ((gy - out.lo[1]) + nly * (gz - out.lo[2]));
    };
    std::map<int, Peer> peers;
@@ -468,8 +478,8 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
             {
                const int o[3] = {s % 3 - 1, (s / 3) % 3 - 1, s / 9 - 1};
                bool ok = true;
-               const int g[3] = {wrap(out.lo[0] + lx + o[0], ok), wrap(out.lo[1] + ly + o[1], ok),
-                                 wrap(out.lo[2] + lz + o[2], ok)};
+               const int g[3] = {wrap(0, out.lo[0] + lx + o[0], ok), wrap(1, out.lo[1] + ly + o[1], ok),
+                                 wrap(2, out.lo[2] + lz + o[2], ok)};
                if (!ok) { continue; }
                int idx;
                const int l[3] = {g[0] - out.lo[0], g[1] - out.lo[1], g[2] - out.lo[2]};
@@ -480,7 +490,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
                else
                {
                   const int owner = owner_1d(0, g[0]) + cfg.px * (owner_1d(1, g[1]) + cfg.py * owner_1d(2, g[2]));
-                  const long long gid = g[0] + (long long)N * (g[1] + (long long)N * g[2]);
+                  const long long gid = g[0] + (long long)Nx * (g[1] + (long long)Ny * g[2]);
                   idx = ne + ghost_slot.at({owner, gid});
                }
                out.stencil27[(size_t)e * 27 + s] = idx;

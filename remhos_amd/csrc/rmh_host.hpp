@@ -21,6 +21,7 @@ struct CaseConfig
    int lo_type = 5;                    // -lo  (3, 4 or 5)
    int px = 1, py = 1, pz = 1;         // box partition of the element lattice
    int rank = 0;
+   int rs_extra[3] = {0, 0, 0};        // additional refinement levels per direction (weak-scaling lattices)
 };
 
 // neighbour rank in the halo exchange: which owned elements it needs, which ghost slots it fills

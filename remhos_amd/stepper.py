@@ -166,7 +166,7 @@ class Stepper:
         """time loop of remhos.cpp:1146-1296"""
         if t_final is None:
             t_final = 1.0 if self.case.exec_mode == 1 else self.case.cfg.t_final
-        ti, done = 0, False
+        ti, ti_total, done = 0, 0, False  # accepted steps / all steps incl. repeated ones (remhos.cpp:1142)
         while not done:
             dt_real = min(self.dt, t_final - self.t)
             if self.dtc:
@@ -178,6 +178,7 @@ class Stepper:
                 t_old = self.t
             self.step(dt_real)
             ti += 1
+            ti_total += 1
             if self.dtc:
                 est = self.ctx.dt_estimate_get()
                 if self.dist is not None:
@@ -199,7 +200,7 @@ class Stepper:
                 if ratio > 1.25:
                     self.dt *= 1.02
             done = self.t >= t_final - 1e-8 * self.dt
-            if ti == max_steps:
+            if ti_total == max_steps:  # -ms counts repeated steps too (remhos.cpp:1296)
                 done = True
         return ti
 

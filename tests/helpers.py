@@ -1,5 +1,20 @@
 """Shared test helpers: turn an oracle case into the arrays rmh_create() takes."""
+import functools
+import os
+import subprocess
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "librmh_emu.so")
+
+
+@functools.lru_cache(maxsize=1)
+def emu_library_path():
+    """The kernel sources compiled with g++ against tests/emu (TEST INFRASTRUCTURE, never loaded by the product):
+    brought up to date with the sources once per test session (`make emu` is incremental)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "remhos_amd", "csrc"), "emu"])
+    return EMU
 
 
 def layout_from_oracle(r):

@@ -36,14 +36,22 @@ def test_case_matches_oracle(lib, mesh, rs, p, prob, dt, tf):
         assert np.abs(c.subcell_vel - r.Vs.transpose(0, 2, 1)).max() < 1e-15
 
 
-@pytest.mark.parametrize("mesh,rs,part", [("periodic-cube", 1, (2, 1, 1)), ("periodic-cube", 1, (2, 2, 2)),
-                                          ("cube01_hex", 2, (2, 2, 1)), ("cube01_hex", 1, (3, 1, 2))])
-def test_partition_is_consistent(lib, mesh, rs, part):
+@pytest.mark.parametrize("mesh,rs,part,extra", [("periodic-cube", 1, (2, 1, 1), (0, 0, 0)), ("periodic-cube", 1, (2, 2, 2), (0, 0, 0)),
+                                                ("cube01_hex", 2, (2, 2, 1), (0, 0, 0)), ("cube01_hex", 1, (3, 1, 2), (0, 0, 0)),
+                                                # bench.py's weak-scaling lattices: partitioned directions refined once more
+                                                ("periodic-cube", 0, (2, 1, 1), (1, 0, 0)), ("periodic-cube", 0, (2, 2, 1), (1, 1, 0)),
+                                                ("cube01_hex", 1, (1, 2, 2), (0, 1, 1))])
+def test_partition_is_consistent(lib, mesh, rs, part, extra):
     """Union of the blocks = the global lattice; stencils agree through global ids; send and
     receive lists of neighbouring ranks match element for element."""
     nr = part[0] * part[1] * part[2]
-    g = Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5))
-    cases = [Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5, part=part, rank=k)) for k in range(nr)]
+    g = Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5, rs_extra=extra))
+    cases = [Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5, part=part, rank=k, rs_extra=extra)) for k in range(nr)]
+    n0 = Case(lib, make_config(mesh, rs, 2, 10, -1.0, 0.5)).n[0]
+    assert g.n == [n0 << extra[0], n0 << extra[1], n0 << extra[2]]
+    if any(extra):
+        # one -rs block per rank
+        assert all(c.ne_owned == n0 ** 3 for c in cases)
     assert sum(c.ne_owned for c in cases) == g.ne_owned
     all_gid = np.concatenate([c.owned_gid for c in cases])
     assert np.array_equal(np.sort(all_gid), np.arange(g.ne_owned))

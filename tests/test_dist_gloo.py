@@ -22,6 +22,9 @@ def _free_port():
 
 
 def _run(tmp_path, mesh, rs, p, prob, steps, part, opts=""):
+    from tests.helpers import emu_library_path
+
+    emu_library_path()  # (up to date before the workers load it)
     world = part[0] * part[1] * part[2]
     port = _free_port()
     procs = []

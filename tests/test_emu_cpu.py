@@ -8,22 +8,17 @@ import numpy as np
 import pytest
 
 from oracle.remhos_oracle import Config, Remhos
-from tests.helpers import layout_from_oracle, perturbed
+from tests.helpers import emu_library_path, layout_from_oracle, perturbed
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, "tests", "emu", "librmh_emu.so")
 
 
 @pytest.fixture(scope="module")
 def lib():
-    if not os.path.exists(EMU):
-        import subprocess
-
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "remhos_amd", "csrc"), "emu"])
     from remhos_amd.capi import load_library
     from remhos_amd.case import bind_driver
 
-    return bind_driver(load_library(EMU))
+    return bind_driver(load_library(emu_library_path()))
 
 
 def _rel(a, b):

@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 CSV output of tools_profile.sh into a text summary (committed under profiles/)."""
+"""Condense the rocprofv3 CSV output of tools/profile.sh into a text summary (committed under profiles/)."""
 import csv
 import glob
 import json
