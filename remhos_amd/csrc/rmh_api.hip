@@ -4,6 +4,7 @@
 #include "rmh_kernels.hpp"
 #include "rmh_ho2.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,8 @@ struct rmh_ctx
    bool dt_control = false;
    int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
    int ho_variant = 2; // 2: batched kernel (rmh_ho2.hpp), 1: one element per workgroup (rmh_kernels.hpp)
+   int n_cu = 256;     // compute units of the device
+   int persist = RMH_PERSIST_LOOP; // fused stage: workgroups per CU slot (0: one workgroup per element batch)
    // stopwatches (TimingData, remhos_tools.hpp:52-64)
    bool timers_on = false;
    double tacc[4] = {0, 0, 0, 0};
@@ -245,16 +248,22 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.bounds_type = c->bounds_type;
    a.dt_est = c->dt_control ? c->d_dt_est : nullptr;
    a.rd_subcell = c->lo_type == 3 ? 0 : 1;
+   // persistent workgroups: as many as the chip holds at once (CUs x workgroups per CU); each works through the
+   // element batches blockIdx.x, blockIdx.x + gridDim.x, ... and prefetches its next batch (ho_kernel2)
    if (c->lo_type == 4 || c->lo_type == 3)
    {
       constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
-      constexpr int NB = K2Cfg<P4, true, true>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3((e_end - e_begin + NB - 1) / NB), dim3(K2Cfg<P4, true, true>::NT), 0, c->stream, a);
+      using C = K2Cfg<P4, true, true>;
+      const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
+      const int grid = c->persist > 0 ? std::min(nblk, c->n_cu * C::WG_PER_CU * c->persist) : nblk;
+      hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3(grid), dim3(C::NT), 0, c->stream, a);
    }
    else
    {
-      constexpr int NB = K2Cfg<P>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3((e_end - e_begin + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+      using C = K2Cfg<P>;
+      const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
+      const int grid = c->persist > 0 ? std::min(nblk, c->n_cu * C::WG_PER_CU * c->persist) : nblk;
+      hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3(grid), dim3(C::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
    return 0;
@@ -377,6 +386,13 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
    c->gh_ustride = c->ndof;
    if (const char *v = std::getenv("RMH_HO_KERNEL")) { c->ho_variant = std::atoi(v) == 1 ? 1 : 2; }
+#if RMH_PERSIST_LOOP
+   if (const char *v = std::getenv("RMH_PERSIST")) { c->persist = std::max(0, std::atoi(v)); } // (tuning aid)
+   {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, L->device) == hipSuccess && n > 0) { c->n_cu = n; }
+   }
+#endif
    // every failure past this point releases the context and whatever it already owns
    const int rc = create_device_state(c, L);
    if (rc) { rmh_destroy(c); return rc; }

@@ -26,6 +26,19 @@
 namespace rmh
 {
 
+// Persistent workgroups with register prefetch of the next batch (see ho_kernel2): built and measured in round 2 --
+// the back edge costs the column phase its last registers (60-170 B/lane of scratch at p = 3, 4) and the kernel ran
+// 20-40 % slower; kept as a compile-time option (the launch side sizes the grid accordingly).
+#ifndef RMH_PERSIST_LOOP
+#define RMH_PERSIST_LOOP 0
+#endif
+
+// wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
+// other workgroups on the CU (0: off)
+#ifndef RMH_PRIO
+#define RMH_PRIO 0
+#endif
+
 #ifndef RMH_ABL_MASK
 #define RMH_ABL_MASK 0 // diagnostic builds only: bit k skips a piece of the PCG iteration
 #endif
@@ -110,7 +123,9 @@ struct K2Cfg : TabLayout<P>
    static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
    static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
    static constexpr int PART = (WAVE_ALIGNED && DR <= 2) ? 0 : cmax(8, 2 * DOT_CH) * NB; // (the DPP paths need none)
-   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART;
+   // fused stage: the 27 stencil indices of every element ([NB][27] ints), parked in LDS from phase A to the PCG prelude
+   static constexpr int STI = (NB * 27 + 1) / 2;
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART + STI;
    // LDS allocation granule: a 54 096-byte kernel ran two workgroups per CU, a 52 560-byte one three (measured:
    // 6.3 k vs 8.6 k MDOFs*stage/s); 2 KiB granules are consistent with that
    static constexpr int LDS_BYTES = (8 * LDS_DOUBLES + 2047) / 2048 * 2048;
@@ -228,6 +243,7 @@ __device__ inline const double *tab_view()
    return c_tab[P] + z;
 }
 #define RMH_TAB() tab_view<P>()
+#define RMH_TABK() (P >= 5 ? tab_view<P>() : gtb)
 
 // a / b for well-scaled operands (mass, dt, PCG scalars: no denormals, no overflow, b != 0): hardware reciprocal,
 // two Newton steps and one correction of the quotient -- the core of the IEEE expansion without its scaling and
@@ -249,17 +265,22 @@ __device__ inline double fdiv(double a, double b)
 #endif
 }
 
-// The kernel's argument struct re-read from the kernarg segment at the point of use (see ho_kernel2, phase I)
-__device__ inline const HoArgs &late_args(const HoArgs &a)
-{
+// The kernel's argument struct re-read from the kernarg segment at the point of use (see ho_kernel2, phase I).  The
+// view is typed in the constant address space so that its fields arrive by scalar loads (through a generic pointer
+// they were vector loads from global memory, each followed by a full s_waitcnt vmcnt(0) in front of its first use).
 #if defined(__HIP_DEVICE_COMPILE__)
+typedef const HoArgs __attribute__((address_space(4))) &LateArgs;
+__device__ inline LateArgs late_args(const HoArgs &)
+{
    int z = 0;
    asm volatile("" : "+s"(z));
-   return *(const HoArgs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + z);
-#else
-   return a;
-#endif
+   typedef const char __attribute__((address_space(4))) *kptr;
+   return *(const HoArgs __attribute__((address_space(4))) *)((kptr)__builtin_amdgcn_kernarg_segment_ptr() + z);
 }
+#else
+typedef const HoArgs &LateArgs;
+__device__ inline LateArgs late_args(const HoArgs &a) { return a; }
+#endif
 
 // Sum over the dofs of each element of the batch: values v[r] of the dof role -> out[r] (the
 // element total, broadcast back to the dof threads).  ONE barrier per call: results go through a
@@ -269,9 +290,8 @@ __device__ inline const HoArgs &late_args(const HoArgs &a)
 //   rounds are reduced together with a halving butterfly -- 6 cross-lane steps for both values;
 //   generic path: LDS float64 atomics.
 template <class C>
-__device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR], double *lds, double *s_acc3, int &ring)
+__device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double (&out)[C::DR], double *lds, double *s_acc3, int &ring)
 {
-   const int tid = threadIdx.x;
    double *cur = s_acc3 + ring * C::NB;
    double *old = s_acc3 + ((ring + 1) % 4) * C::NB; // (a slot is reused two calls later at the earliest)
    if (C::WAVE_ALIGNED && C::DR == 2)
@@ -372,12 +392,12 @@ __device__ inline void batch_dot(const double (&v)[C::DR], double (&out)[C::DR],
 // {v round 0, w round 0, v round 1, w round 1} into the four rows, which the four DPP row steps then reduce together.
 // One barrier instead of two.  Other orders: two calls of batch_dot.
 template <class C>
-__device__ inline void batch_dot2(const double (&v)[C::DR], const double (&w)[C::DR], double (&outv)[C::DR],
+__device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const double (&w)[C::DR], double (&outv)[C::DR],
                                   double (&outw)[C::DR], double *lds, double *s_acc3, int &ring)
 {
    if (C::WAVE_ALIGNED && C::DR == 2)
    {
-      const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      const int lane = tid & 63, wave = tid >> 6;
       double *curv = s_acc3 + ring * C::NB, *curw = s_acc3 + ((ring + 1) % 4) * C::NB;
       const bool has1 = tid + C::NT < C::NB * C::D3;
       double v0 = v[0], v1 = has1 ? v[C::DR == 2 ? 1 : 0] : 0.0;
@@ -408,8 +428,8 @@ __device__ inline void batch_dot2(const double (&v)[C::DR], const double (&w)[C:
    }
    else
    {
-      batch_dot<C>(v, outv, lds, s_acc3, ring);
-      batch_dot<C>(w, outw, lds, s_acc3, ring);
+      batch_dot<C>(tid, v, outv, lds, s_acc3, ring);
+      batch_dot<C>(tid, w, outw, lds, s_acc3, ring);
    }
 }
 
@@ -438,6 +458,60 @@ __device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
 #define RMH_STAMP(k)
 #define RMH_STAMP_FLUSH()
 #endif
+
+// Primary global loads of one element batch (phase A): face-neighbour indices, stencil indices (fused stage), Q2
+// nodes of x0 and v, u.  The fused stage calls it for the NEXT batch of a persistent workgroup at the start of its
+// limiter phase, so that the loads are in flight while the current batch finishes (see ho_kernel2).
+template <class C, bool FUSED, int NLN, int NLS, int NLX, int NLU>
+__device__ inline void load_batch(const HoArgs &a, const bool on, const int e0, const int tid, int (&nbi)[NLN], int (&sti)[NLS], double (&gx0)[NLX],
+                                  double (&gv)[NLX], double (&gu)[NLU])
+{
+   constexpr int NT = C::NT, NB = C::NB, D2 = C::D2, D3 = C::D3;
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
+   {
+      const int k = tid + j * NT;
+      nbi[j] = -1;
+      if (on && k < NB * 6 * D2)
+      {
+         const int eb = k / (6 * D2), f = (k % (6 * D2)) / D2;
+         nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.e_end - 1) * 6 + f];
+      }
+   }
+   // fused stage: the indices of the 27 stencil elements are needed before the PCG loop (their extrema are loaded
+   // there); loaded here with everything else so that no index -> value round trip is exposed later
+#pragma unroll
+   for (int j = 0; j < NLS; j++)
+   {
+      const int k = tid + j * NT;
+      sti[j] = -1;
+      if (FUSED && on && k < NB * 27) { sti[j] = a.stencil27[(size_t)min(e0 + k / 27, a.e_end - 1) * 27 + k % 27]; }
+   }
+#pragma unroll
+   for (int j = 0; j < NLX; j++)
+   {
+      const int k = tid + j * NT;
+      gx0[j] = 0.0; gv[j] = 0.0;
+      if (on && k < NB * 81)
+      {
+         const int eb = k / 81, i = k % 81;
+         const int e = min(e0 + eb, a.e_end - 1);
+         gx0[j] = a.x0[(size_t)e * 81 + i];
+         gv[j] = a.vel[(size_t)e * 81 + i];
+      }
+   }
+#pragma unroll
+   for (int j = 0; j < NLU; j++)
+   {
+      const int k = tid + j * NT;
+      gu[j] = 0.0;
+      if (on && k < NB * D3)
+      {
+         const int e = min(e0 + k / D3, a.e_end - 1);
+         gu[j] = a.u[(size_t)e * D3 + k % D3];
+      }
+   }
+}
 
 // FUSED = false: HOSolver::CalcHOSolution (writes du_HO, lumped mass, element extrema of u).
 // FUSED = true : the whole RK stage for -ho 3 -lo 5 -fct 2 (AdvectionOperator::Mult, remhos.cpp:1596-1916,
@@ -474,58 +548,56 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    double *s_acc = lds + NB * C::EL;   // [3][NB] ring of reduction buffers (+ NB spare)
    int *s_flag = (int *)(s_acc + 4 * NB); // [4] "any element still active" flags (ring of 2 used)
    double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
+   int *s_sti = (int *)(stab + C::N2 + C::PART); // [NB][27] stencil indices (fused stage)
 
-   const int tid = threadIdx.x;
-   const int e0 = a.e_begin + blockIdx.x * NB;
+   const int tid0 = threadIdx.x;
    static_assert(C::N2 <= RMH_TAB_STRIDE, "constant table too small");
-   const double *gt = c_tab[P]; // constant memory: compile-time indices become scalar loads
-   (void)gt;
    constexpr int oB = C::oB, oG = C::oG, oL = C::oL, odL = C::odL, oW = C::oW, oBg = C::oBg, oBg2 = C::oBg2,
                  oCi = C::oCi;
 
    // ---- phase A: loads ----------------------------------------------------------------------
-   for (int i = tid; i < C::N2; i += NT) { stab[i] = a.tab[i]; }
+   // Persistent workgroups: the grid may be smaller than the number of element batches (the fused stage is launched
+   // with as many workgroups as the chip holds); a workgroup then works through batches blockIdx.x, blockIdx.x +
+   // gridDim.x, ... and issues the primary loads of its next batch at the start of the limiter phase of the current
+   // one, so that only the (index-dependent) neighbour-trace loads are waited for at the top of a batch.
+   constexpr int NLX = (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
+   constexpr int NLS = (NB * 27 + NT - 1) / NT;
+   const int nblk = (a.e_end - a.e_begin + NB - 1) / NB;
+   int nbi[NLN], sti[NLS];
+   double gx0[NLX], gv[NLX], gu[NLU];
+   int itmax = 0;
+   bool prefetched = false;
+   // (only the fused stage is launched with a persistent grid: the other modes get one batch per workgroup and no
+   // loop -- a back edge costs them registers in the column phase for nothing)
+   int blk = blockIdx.x;
+   if (blk >= nblk) { return; }
+   do
+   {
+   const int e0 = a.e_begin + blk * NB;
+   // the thread index and the table base are made opaque per batch: everything derived from them (thread roles,
+   // LDS addresses, basis-table rows in registers) is then recomputed per batch instead of being hoisted out of the
+   // batch loop and kept live -- and spilled -- through all of it
+   int tid_ = tid0, zt_ = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && RMH_PERSIST_LOOP
+   asm volatile("" : "+v"(tid_));
+   asm volatile("" : "+s"(zt_));
+#endif
+   const int tid = tid_;
+   const double *gtb = c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
+   const double *gt = gtb;
+   (void)gt;
+   if (blk != (int)blockIdx.x) { __syncthreads(); } // the previous batch's last LDS reads precede this batch's stores
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
    // all global loads are issued before the first LDS store so that they are in flight together
    // (neighbour indices first: the trace loads depend on them)
-   constexpr int NLX = (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
-   int nbi[NLN];
+   if (!prefetched) { load_batch<C, FUSED>(a, true, e0, tid, nbi, sti, gx0, gv, gu); }
+   // table copy for lane-dependent indexing: loaded behind the element data, stored with it (a copy loop at the top of
+   // the kernel put a full memory round trip in front of the first element load)
+   constexpr int NLT = (C::N2 + NT - 1) / NT;
+   double gtab[NLT];
 #pragma unroll
-   for (int j = 0; j < NLN; j++)
-   {
-      const int k = tid + j * NT;
-      nbi[j] = -1;
-      if (k < NB * 6 * D2)
-      {
-         const int eb = k / (6 * D2), f = (k % (6 * D2)) / D2;
-         nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.e_end - 1) * 6 + f];
-      }
-   }
-   double gx0[NLX], gv[NLX], gu[NLU], gn[NLN];
-#pragma unroll
-   for (int j = 0; j < NLX; j++)
-   {
-      const int k = tid + j * NT;
-      gx0[j] = 0.0; gv[j] = 0.0;
-      if (k < NB * 81)
-      {
-         const int eb = k / 81, i = k % 81;
-         const int e = min(e0 + eb, a.e_end - 1);
-         gx0[j] = a.x0[(size_t)e * 81 + i];
-         gv[j] = a.vel[(size_t)e * 81 + i];
-      }
-   }
-#pragma unroll
-   for (int j = 0; j < NLU; j++)
-   {
-      const int k = tid + j * NT;
-      gu[j] = 0.0;
-      if (k < NB * D3)
-      {
-         const int e = min(e0 + k / D3, a.e_end - 1);
-         gu[j] = a.u[(size_t)e * D3 + k % D3];
-      }
-   }
+   for (int j = 0; j < NLT; j++) { gtab[j] = (tid + j * NT < C::N2) ? a.tab[tid + j * NT] : 0.0; }
+   double gn[NLN];
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
@@ -568,6 +640,19 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       const int k = tid + j * NT;
       if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
+   }
+#pragma unroll
+   for (int j = 0; j < NLT; j++) { if (tid + j * NT < C::N2) { stab[tid + j * NT] = gtab[j]; } }
+   if (FUSED)
+   {
+      // (in a register the index would be spilled through the column phase, and a pending scratch reload makes
+      // the compiler drain ALL outstanding loads before the extrema loads of the PCG prelude can issue)
+#pragma unroll
+      for (int j = 0; j < NLS; j++)
+      {
+         const int k = tid + j * NT;
+         if (k < NB * 27) { s_sti[k] = sti[j]; }
+      }
    }
    if (LO4 && a.rd_subcell)
    {
@@ -624,7 +709,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int q = 0; q < Q; q++)
       {
-         const double *gt = RMH_TAB();
+         const double *gt = RMH_TABK();
          double ub = 0.0, ug = 0.0;
 #pragma unroll
          for (int ix = 0; ix < D; ix++)
@@ -764,7 +849,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int q2 = 0; q2 < Q; q2++)
       {
-         const double *gt = RMH_TAB();
+         const double *gt = RMH_TABK();
          double t1[3], t2[3], vf[3];
 #pragma unroll
          for (int comp = 0; comp < 3; comp++)
@@ -904,7 +989,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
-            const double *gt = RMH_TAB();
+            const double *gt = RMH_TABK();
             double J[3][3], v[3];
 #pragma unroll
             for (int comp = 0; comp < 3; comp++)
@@ -961,7 +1046,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
-         const double *gt = RMH_TAB();
+         const double *gt = RMH_TABK();
          double gx = 0, gy = 0, gz = 0;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
@@ -1015,7 +1100,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            const double *gt = RMH_TAB();
+            const double *gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
@@ -1043,7 +1128,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int k1 = 0; k1 < D; k1++)
          {
-            const double *gt = RMH_TAB();
+            const double *gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int q1 = 0; q1 < Q; q1++) { acc += gt[oBg + q1 * D + k1] * in[q1]; }
@@ -1162,8 +1247,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          t1[r] = fmax(0., zb[r]);
          t2[r] = fmin(0., zb[r]);
       }
-      batch_dot<C>(t0, xSum, lds, s_acc, ring4);
-      batch_dot2<C>(t1, t2, rhoP, rhoN, lds, s_acc, ring4);
+      batch_dot<C>(tid, t0, xSum, lds, s_acc, ring4);
+      batch_dot2<C>(tid, t1, t2, rhoP, rhoN, lds, s_acc, ring4);
       // element extrema (el[0..1]) and the sums of the subcell fluctuations (8 partial sums each, el[2..17])
       if (C::WAVE_ALIGNED)
       {
@@ -1275,7 +1360,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
          }
       }
-      if (!BOTH) { return; }
+      if (!BOTH) { continue; }
       __syncthreads(); // the PCG reuses the front of W
    }
    RMH_STAMP(5);
@@ -1286,13 +1371,31 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // kernel arguments that are only needed from here on (limiter, RK update, stores) are read through a late view of
    // the kernarg segment: held in scalar registers from the kernel's first instruction they cost ~30 SGPRs through
    // phases A-J and push table values into VGPR-lane spills
-   const HoArgs &L = late_args(a);
+   LateArgs L = late_args(a);
+#if defined(__HIP_DEVICE_COMPILE__) && RMH_PRIO
+   __builtin_amdgcn_s_setprio(RMH_PRIO); // PCG, back-transform, limiter: short dependent phases between barriers
+#endif
    // fused stage: the global reads of the limiter part are issued here so that they are in flight during
    // the PCG iterations (u is an L2 hit: this workgroup read it in phase A)
-   constexpr int NLS = (NB * 27 + NT - 1) / NT;
    double uu[DR], xb[DR], slo[NLS], shi[NLS];
    if (FUSED)
    {
+#pragma unroll
+      for (int j = 0; j < NLS; j++)
+      {
+         const int k = tid + j * NT;
+         slo[j] = INFINITY; shi[j] = -INFINITY;
+         const int nb = (k < NB * 27) ? s_sti[k] : -1;
+         if (nb >= 0)
+         {
+            // (owned or ghost: the two base pointers are scalars, the select happens on the per-lane address)
+            const bool own = nb < L.ne_owned;
+            const size_t off = own ? (size_t)nb : (size_t)(nb - L.ne_owned) * L.gh_mstride;
+            const double *pmin = L.xe_min, *pmax = L.xe_max, *gmin = L.gh_min, *gmax = L.gh_max;
+            slo[j] = (own ? pmin : gmin)[off];
+            shi[j] = (own ? pmax : gmax)[off];
+         }
+      }
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -1303,22 +1406,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const size_t g = (size_t)min(e0 + t / D3, L.e_end - 1) * D3 + t % D3;
             uu[r] = BOTH ? uu4[r] : a.u[g]; // (HO + RD: already reloaded for the RD solver)
             if (L.x_base) { xb[r] = L.x_base[g]; }
-         }
-      }
-#pragma unroll
-      for (int j = 0; j < NLS; j++)
-      {
-         const int k = tid + j * NT;
-         slo[j] = INFINITY; shi[j] = -INFINITY;
-         if (k < NB * 27)
-         {
-            const int e = min(e0 + k / 27, L.e_end - 1);
-            const int nb = L.stencil27[(size_t)e * 27 + k % 27];
-            if (nb >= 0)
-            {
-               if (nb < L.ne_owned) { slo[j] = L.xe_min[nb]; shi[j] = L.xe_max[nb]; }
-               else { slo[j] = L.gh_min[(size_t)(nb - L.ne_owned) * L.gh_mstride]; shi[j] = L.gh_max[(size_t)(nb - L.ne_owned) * L.gh_mstride]; }
-            }
          }
       }
    }
@@ -1335,7 +1422,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
    }
-   batch_dot<C>(tmp, nom, lds, s_acc, ring);
+   batch_dot<C>(tid, tmp, nom, lds, s_acc, ring);
    bool act[DR];
    {
       bool any = false;
@@ -1374,7 +1461,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int q = 0; q < Q; q++)
          {
-            const double *gt = RMH_TAB();
+            const double *gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
@@ -1401,7 +1488,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
-            const double *gt = RMH_TAB();
+            const double *gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
@@ -1428,7 +1515,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            const double *gt = RMH_TAB();
+            const double *gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
@@ -1460,7 +1547,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #ifdef RMH_ABL_NODOT
       for (int r = 0; r < DR; r++) { red[r] = nom[r]; }
 #else
-      batch_dot<C>(tmp, red, lds, s_acc, ring); // den = d.Ad
+      batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // den = d.Ad
 #endif
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -1476,7 +1563,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #ifdef RMH_ABL_NODOT
       for (int r = 0; r < DR; r++) { red[r] = 0.0; }
 #else
-      batch_dot<C>(tmp, red, lds, s_acc, ring); // betanom = r.z
+      batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // betanom = r.z
 #endif
       RMH_STAMP(15);
       bool any = false;
@@ -1587,7 +1674,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       __syncthreads();
    }
    RMH_STAMP(16);
-   int itmax = 0;
 #pragma unroll
    for (int r = 0; r < DR; r++) { itmax = max(itmax, its[r]); }
    if (!FUSED)
@@ -1612,12 +1698,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       // ---- phase K: LimitMult + RK update (W is free: the last back-transform leg ended with a barrier) ----
       constexpr double eps = 1.0e-15;
+      // next batch of this (persistent) workgroup: primary loads in flight during the limiter
+      // (without a next batch the call only resets the registers: a definite assignment, so that this batch's values
+      // are not kept live -- and spilled -- around the loop)
+      if (RMH_PERSIST_LOOP)
+      {
+         prefetched = blk + (int)gridDim.x < nblk;
+         load_batch<C, FUSED>(a, prefetched, a.e_begin + (blk + (int)gridDim.x) * NB, tid, nbi, sti, gx0, gv, gu);
+      }
       RMH_STAMP(21);
       // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
       double mass[DR], vol[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
-      batch_dot2<C>(tmp, mm, mass, vol, lds, s_acc, ring);
+      if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(L.cg_iters)) { atomicMax(L.cg_iters, itmax); }
+      batch_dot2<C>(tid, tmp, mm, mass, vol, lds, s_acc, ring);
       RMH_STAMP(22);
       RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];
@@ -1654,7 +1749,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       RMH_STAMP(18);
       double sumPos[DR], sumNeg[DR];
-      batch_dot2<C>(pos, neg, sumPos, sumNeg, lds, s_acc, ring);
+      batch_dot2<C>(tid, pos, neg, sumPos, sumNeg, lds, s_acc, ring);
       RMH_STAMP(19);
       double ynew[DR];
 #pragma unroll
@@ -1699,8 +1794,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int lane = tid & 63, eb = (lane < 32) ? (tid >> 6) : NT / D3 + (tid >> 6);
          if ((lane & 15) == 15 && eb < NB && e0 + eb < L.e_end)
          {
-            if (lane & 16) { L.xe_max_out[e0 + eb] = -x; }
-            else { L.xe_min_out[e0 + eb] = x; }
+            // (both base pointers as scalars, selected by value: a select between the two kernarg FIELDS is compiled
+            // into a per-lane load of the pointer itself, with a full wait in front of the store)
+            double *pmin = L.xe_min_out, *pmax = L.xe_max_out;
+            double *dst = (lane & 16) ? pmax : pmin;
+            dst[e0 + eb] = (lane & 16) ? -x : x;
          }
       }
       else if (C::WAVE_ALIGNED)
@@ -1768,10 +1866,12 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
       }
    }
+   } while (RMH_PERSIST_LOOP && FUSED && (blk += (int)gridDim.x) < nblk); // batches of this workgroup
    // diagnostics: max PCG iteration count over the launch.  A global atomic per wavefront on ONE
    // address serialises at the memory side (~5 ns each: 3 ms per launch at 500 k wavefronts), so the
    // atomic is issued only when it can raise the (monotone) maximum.
-   if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(L.cg_iters)) { atomicMax(L.cg_iters, itmax); }
+   // (fused stage: done at the start of the limiter phase, in front of the L2 warm-up loads)
+   if (!FUSED && (tid0 & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(a.cg_iters)) { atomicMax(a.cg_iters, itmax); }
    RMH_STAMP(7);
    RMH_STAMP_FLUSH();
 }

@@ -5,7 +5,7 @@ The deltas of thread 0 are accumulated in LDS and written once per workgroup at 
 version issued a global atomic per stamp, which the next s_waitcnt vmcnt(0) of the workgroup then waited for:
 phantom waits worth a third of the kernel)."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from remhos_amd.capi import load_library
 from remhos_amd.case import Case, bind_driver, make_config
