@@ -186,6 +186,14 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
         umax = float(red[0])
     one_kernel = st.one_kernel
     ne_owned, ndof, ne_global, n_lat = case.ne_owned, case.ndof, case.ne_global, list(case.n)
+    xinfo = None
+    if case.peers:
+        _, sn, _, gn = st.ctx.exchange_buffers()
+        xinfo = {"transport": {"rccl": "RCCL grouped ncclSend/ncclRecv inside the library (rmh_exchange_begin/_end)",
+                               "external": "torch.distributed isend/irecv on the library's segments"}.get(st.transport, st.transport),
+                 "ghost_records": "compact (face layer + extrema; extrema only for edge/vertex neighbours)" if st.compact else "whole elements",
+                 "neighbour_ranks": len(case.peers), "send_bytes_per_stage_rank0": 8 * sn, "recv_bytes_per_stage_rank0": 8 * gn,
+                 "rccl_fallback_reason": getattr(st, "rccl_error", None)}
     st.close()
     del st, case
     torch.cuda.empty_cache()
@@ -257,6 +265,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
             k: (1e-6 * global_dofs * stages / v if v > 0 else None)
             for k, v in (("rhs_plus_inv", tim[0]), ("lo", tim[2]), ("fct", tim[3]), ("total_rhs_lo_fct", tim[0] + tim[2] + tim[3]))
         },
+        "exchange": xinfo,
         "stage_roofline": {
             "alg_bytes_per_dof": stage_alg_bytes_per_dof(order),
             "achieved_GBs": value * 1e6 * stage_alg_bytes_per_dof(order) / 1e9,

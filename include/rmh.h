@@ -111,6 +111,59 @@ int rmh_halo_pack(rmh_ctx *ctx, const double *u, const int *send_elems, int nsen
 int rmh_halo_pack_records(rmh_ctx *ctx, const double *u, const int *send_elems, int nsend, double *rec);
 int rmh_set_ghost_records(rmh_ctx *ctx, const double *rec);
 
+/* ---- Neighbour exchange inside the library: RCCL send/recv over xGMI -------------------------------------------
+ * Replaces, per RK stage, ParGridFunction::ExchangeFaceNbrData (remhos_ho.cpp:122; again in LimitMult,
+ * remhos.cpp:1812-1813) and the GroupCommunicator min/max reduction of DofInfo::ComputeOverlapBounds
+ * (remhos_tools.cpp:449-466) by ONE grouped ncclSend/ncclRecv exchange with the neighbour ranks of the box
+ * partition (what ParMesh(comm, mesh, partitioning) sets up in the reference, remhos.cpp:459-463).
+ *
+ * rmh_exchange_setup takes the plan (HOST arrays, copied): for neighbour k, the owned elements it needs
+ * (send_elems[k], in the order of ITS ghost slots) and the contiguous range of this rank's ghost slots it fills.
+ * The library owns the send and ghost buffers from then on (rmh_set_ghost_* must not be used).
+ *   compact = 0: a ghost record is [ndof values | min | max] (every neighbour element in full);
+ *   compact = 1: a ghost record is [min | max | D^2 face layer facing this rank] for elements that share a face
+ *                with this rank and [min | max] for edge / vertex neighbours (only the bounds stencil reads those):
+ *                the payload SURVEY.md 8(e) asks for.  The face_nbr / stencil27 tables on the device are re-indexed
+ *                to the variable-size records.  Fails with RMH_ERR_INVALID when an element is adjacent to the same
+ *                neighbour rank through two faces (blocks one element thin): use compact = 0 on all ranks then.
+ * Transports:
+ *   rmh_comm_init / rmh_comm_attach -- RCCL: a communicator created from a broadcast ncclUniqueId
+ *       (rmh_comm_unique_id on one rank), or the application's own ncclComm_t; the exchange runs on a stream of
+ *       its own, ordered against the context's stream by events (no host synchronisation);
+ *   rmh_comm_connect_local          -- neighbour k is another context of THIS process (several blocks on one GPU,
+ *       or one process driving several GPUs; peer_ctx_index = this context's index among ITS neighbours):
+ *       device-to-device copies instead of RCCL, same plan and buffers;
+ *   neither                         -- the caller moves the bytes itself between rmh_exchange_begin and
+ *       rmh_exchange_end (rmh_exchange_buffers / rmh_exchange_peer describe the segments; used with
+ *       torch.distributed/gloo in the CPU tests).
+ * rmh_exchange_begin(u): packs the send records of u on the context's stream and posts the exchange;
+ * rmh_exchange_end: makes the context's stream wait for the received ghosts.  Kernels launched in between must
+ * not read ghosts (rmh_stage_fused_range over the elements that reach none).  With local peers every context of
+ * the process calls begin before any calls end. */
+typedef struct {
+   int n_peers;
+   const int *peer_rank;         /* [n_peers] rank of neighbour k in the communicator                           */
+   const int *send_count;        /* [n_peers]                                                                   */
+   const int *const *send_elems; /* [n_peers][send_count[k]] owned element indices, in the receiver's ghost order */
+   const int *recv_first;        /* [n_peers] first ghost slot (0-based within the ghost block) neighbour k fills */
+   const int *recv_count;        /* [n_peers] number of consecutive ghost slots it fills                         */
+} rmh_exchange_desc;
+int rmh_exchange_setup(rmh_ctx *ctx, const rmh_exchange_desc *desc, int compact);
+int rmh_comm_unique_id(char id[128]);
+int rmh_comm_init(rmh_ctx *ctx, const char id[128], int nranks, int rank);
+int rmh_comm_attach(rmh_ctx *ctx, void *nccl_comm);
+int rmh_comm_connect_local(rmh_ctx *ctx, int peer_index, rmh_ctx *peer_ctx, int peer_ctx_index);
+int rmh_exchange_begin(rmh_ctx *ctx, const double *u);
+int rmh_exchange_end(rmh_ctx *ctx);
+/* segments of the library-owned buffers (device pointers; counts in doubles) for a caller-side transport */
+int rmh_exchange_buffers(rmh_ctx *ctx, double **send_buf, long long *send_doubles, double **ghost_buf, long long *ghost_doubles);
+int rmh_exchange_peer(rmh_ctx *ctx, int peer_index, int *rank, long long *send_offset, long long *send_doubles,
+                      long long *recv_offset, long long *recv_doubles);
+/* Reductions over the ranks of the RCCL communicator for the driver's report (remhos.cpp:1412-1421 mass / max,
+ * :1934 stopwatch maxima, :1993 dt estimate): vals[n] HOST doubles, in place; op 0 = sum, 1 = min, 2 = max.
+ * Synchronises.  Not on the hot path. */
+int rmh_allreduce(rmh_ctx *ctx, double *vals, int n, int op);
+
 /* HOSolver::CalcHOSolution (remhos_ho.hpp:38, LocalInverseHOSolver remhos_ho.cpp:84-129):
  * du = M^-1 (K_vol + K_face) u with an element-local, tightly converged mass solve.
  * Also refreshes the lumped mass vector (remhos.cpp:1632) and the element extrema of u. */

@@ -86,6 +86,17 @@ typedef struct {
 /* remhos() on one GPU (px = py = pz = 1): setup, RK3-SSP loop, report.  0 on success. */
 int rmhd_run(const rmhd_config *cfg, rmhd_result *res);
 
+/* The same run on a px x py x pz box partition (ParMesh(comm, mesh, partitioning), remhos.cpp:459-463), one fused
+ * kernel per RK stage and block, one neighbour exchange per stage inside the library (rmh_exchange_begin / _end):
+ *   comm_id_file == NULL : ALL blocks live in this process on `device`, exchanged by device copies (validation,
+ *                          or one process driving the blocks of one GPU);
+ *   comm_id_file != NULL : this process owns block cfg->rank on `device`; the blocks talk through RCCL
+ *                          (ncclSend / ncclRecv over xGMI).  Rank 0 writes the ncclUniqueId to that file, the others
+ *                          read it -- any launcher that starts px*py*pz copies with distinct -rank works.
+ * Reductions of the report (mass, max, dt estimate, stopwatches: remhos.cpp:1412-1421, 1934, 1993) go through
+ * rmh_allreduce.  Fixed dt or -dtc 1; -lo 3|4|5.  0 on success. */
+int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_file, int device, rmhd_result *res);
+
 #ifdef __cplusplus
 }
 #endif

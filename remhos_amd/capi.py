@@ -20,6 +20,8 @@ SYMBOLS = [
     "rmh_halo_pack_records", "rmh_set_ghost_records", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
     "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
+    "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
+    "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce",
 ]
 
 
@@ -40,6 +42,17 @@ class RmhLayout(C.Structure):
     ]
 
 
+class RmhExchangeDesc(C.Structure):
+    _fields_ = [
+        ("n_peers", C.c_int),
+        ("peer_rank", C.POINTER(C.c_int)),
+        ("send_count", C.POINTER(C.c_int)),
+        ("send_elems", C.POINTER(C.POINTER(C.c_int))),
+        ("recv_first", C.POINTER(C.c_int)),
+        ("recv_count", C.POINTER(C.c_int)),
+    ]
+
+
 class RmhError(RuntimeError):
     pass
 
@@ -51,6 +64,13 @@ def load_library(path: str | None = None) -> C.CDLL:
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  remhos_amd has no CPU fallback."
         )
+    if os.path.basename(path) != "librmh_emu.so":
+        # PyTorch ships its own HIP runtime: it must be in the process before this library pulls one in, otherwise the
+        # two runtimes fight over the device (torch then reports "No HIP GPUs are available")
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     p, d, i = C.c_void_p, C.c_double, C.c_int
     lib.rmh_create.argtypes = [C.POINTER(RmhLayout), C.POINTER(p)]
@@ -92,6 +112,17 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_dt_estimate_reset.argtypes = [p]
     lib.rmh_dt_estimate_update.argtypes = [p, p, p, p, p]
     lib.rmh_dt_estimate_get.argtypes = [p, C.POINTER(d)]
+    ll = C.c_longlong
+    lib.rmh_exchange_setup.argtypes = [p, C.POINTER(RmhExchangeDesc), i]
+    lib.rmh_comm_unique_id.argtypes = [C.c_char_p]
+    lib.rmh_comm_init.argtypes = [p, C.c_char_p, i, i]
+    lib.rmh_comm_attach.argtypes = [p, p]
+    lib.rmh_comm_connect_local.argtypes = [p, i, p, i]
+    lib.rmh_exchange_begin.argtypes = [p, p]
+    lib.rmh_exchange_end.argtypes = [p]
+    lib.rmh_exchange_buffers.argtypes = [p, C.POINTER(p), C.POINTER(ll), C.POINTER(p), C.POINTER(ll)]
+    lib.rmh_exchange_peer.argtypes = [p, i, C.POINTER(i), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll)]
+    lib.rmh_allreduce.argtypes = [p, C.POINTER(d), i, i]
     return lib
 
 
@@ -264,6 +295,59 @@ class Context:
         v = C.c_double()
         self._check(self.lib.rmh_dt_estimate_get(self.h, C.byref(v)))
         return v.value
+
+    # -- neighbour exchange inside the library (include/rmh.h) ---------------------------------------------------
+    def exchange_setup(self, peers, compact=True):
+        """peers: [(rank, send_elems, recv_slots)] as the case builder lists them (recv slots contiguous)."""
+        import numpy as np
+
+        n = len(peers)
+        ranks = (C.c_int * max(n, 1))(*[int(r) for r, _, _ in peers])
+        scount = (C.c_int * max(n, 1))(*[len(s) for _, s, _ in peers])
+        rfirst = (C.c_int * max(n, 1))(*[int(r[0]) if len(r) else 0 for _, _, r in peers])
+        rcount = (C.c_int * max(n, 1))(*[len(r) for _, _, r in peers])
+        for _, _, r in peers:
+            assert len(r) == 0 or (np.asarray(r) == np.arange(int(r[0]), int(r[0]) + len(r))).all(), "ghost slots of a peer must be contiguous"
+        arrs = [np.ascontiguousarray(s, dtype=np.int32) for _, s, _ in peers]
+        sptr = (C.POINTER(C.c_int) * max(n, 1))(*[a.ctypes.data_as(C.POINTER(C.c_int)) for a in arrs])
+        desc = RmhExchangeDesc(n, ranks, scount, sptr, rfirst, rcount)
+        self._check(self.lib.rmh_exchange_setup(self.h, C.byref(desc), 1 if compact else 0))
+        self.n_peers = n
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.rmh_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, nranks, rank):
+        self._check(self.lib.rmh_comm_init(self.h, uid, int(nranks), int(rank)))
+
+    def comm_connect_local(self, k, other, other_k):
+        self._check(self.lib.rmh_comm_connect_local(self.h, int(k), other.h, int(other_k)))
+
+    def exchange_begin(self, u):
+        self._check(self.lib.rmh_exchange_begin(self.h, _ptr(u)))
+
+    def exchange_end(self):
+        self._check(self.lib.rmh_exchange_end(self.h))
+
+    def exchange_buffers(self):
+        """(send_ptr, send_doubles, ghost_ptr, ghost_doubles) of the library-owned buffers"""
+        sp, gp, sn, gn = C.c_void_p(), C.c_void_p(), C.c_longlong(), C.c_longlong()
+        self._check(self.lib.rmh_exchange_buffers(self.h, C.byref(sp), C.byref(sn), C.byref(gp), C.byref(gn)))
+        return sp.value, sn.value, gp.value, gn.value
+
+    def exchange_peer(self, k):
+        """(rank, send_offset, send_doubles, recv_offset, recv_doubles) of neighbour k"""
+        r = C.c_int()
+        v = [C.c_longlong() for _ in range(4)]
+        self._check(self.lib.rmh_exchange_peer(self.h, int(k), C.byref(r), *[C.byref(x) for x in v]))
+        return (r.value,) + tuple(x.value for x in v)
+
+    def allreduce(self, vals, op="sum"):
+        arr = (C.c_double * len(vals))(*[float(v) for v in vals])
+        self._check(self.lib.rmh_allreduce(self.h, arr, len(vals), {"sum": 0, "min": 1, "max": 2}[op]))
+        return list(arr)
 
     def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
         self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))

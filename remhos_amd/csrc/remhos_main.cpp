@@ -16,7 +16,8 @@ int main(int argc, char **argv)
    std::strcpy(c.mesh, "periodic-cube");
    c.rs = 2; c.order = 3; c.problem = 10; c.dt = -1.0; c.t_final = 0.5; c.max_steps = -1;
    c.lo_type = 5; c.fused = 1; c.px = c.py = c.pz = 1; c.rank = 0;
-   int ho = 3, fct = 2;
+   int ho = 3, fct = 2, device = 0;
+   std::string comm_file;
    for (int i = 1; i < argc; i++)
    {
       const std::string a = argv[i];
@@ -44,6 +45,12 @@ int main(int argc, char **argv)
       else if (a == "-dtc") { c.dt_control = std::atoi(next()); }
       else if (a == "-save") { c.save = 1; }
       else if (a == "-unfused") { c.fused = 0; }
+      else if (a == "-px") { c.px = std::atoi(next()); }
+      else if (a == "-py") { c.py = std::atoi(next()); }
+      else if (a == "-pz") { c.pz = std::atoi(next()); }
+      else if (a == "-rank") { c.rank = std::atoi(next()); }
+      else if (a == "-dev") { device = std::atoi(next()); }
+      else if (a == "-comm-file") { comm_file = next(); }
       else if (a == "-pa" || a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { if (std::atoi(next()) != 3) { std::fprintf(stderr, "only -s 3 (RK3 SSP)\n"); return 3; } }
       else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
@@ -55,11 +62,15 @@ int main(int argc, char **argv)
    }
    c.ho_type = ho;
    rmhd_result r;
-   if (rmhd_run(&c, &r) != 0)
+   // box-partitioned runs: all blocks in this process (no -comm-file), or one block per process over RCCL
+   //   for r in 0 1; do remhos_amd_run ... -px 2 -rank $r -dev $r -comm-file /tmp/rmh.id & done
+   const bool partitioned = c.px * c.py * c.pz > 1;
+   if (partitioned ? rmhd_run_partitioned(&c, comm_file.empty() ? nullptr : comm_file.c_str(), device, &r) != 0 : rmhd_run(&c, &r) != 0)
    {
       std::fprintf(stderr, "remhos_amd: %s\n", rmhd_last_error());
       return 2;
    }
+   if (partitioned && c.rank != 0 && !comm_file.empty()) { return 0; } // (rank 0 reports, remhos.cpp:1423)
    std::printf("Number of unknowns: %lld\n", r.global_dofs);
    std::printf("time step: %d, time: %.8g, dt: %.8g\n", r.steps, r.t_end, r.dt);
    if (c.dt_control) { std::printf("Total time steps: %d (%d repeated).\n", r.steps + r.repeats, r.repeats); } // remhos.cpp:1350-1354

@@ -1,6 +1,6 @@
 // C ABI of the MI355X-native Remhos hot path: context, dispatch over the polynomial order,
 // HIP-event stopwatches.  See include/rmh.h for the contract of every entry point.
-#include "../../include/rmh.h"
+#include "rmh_ctx.hpp"
 #include "rmh_kernels.hpp"
 #include "rmh_ho2.hpp"
 
@@ -14,7 +14,7 @@
 
 using namespace rmh;
 
-namespace
+namespace rmh
 {
 thread_local std::string g_last_error;
 
@@ -23,56 +23,7 @@ int fail(int code, const std::string &msg)
    g_last_error = msg;
    return code;
 }
-
-#define RMH_HIP(call)                                                                          \
-   do {                                                                                        \
-      hipError_t err_ = (call);                                                                \
-      if (err_ != hipSuccess)                                                                  \
-      {                                                                                        \
-         return fail(RMH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err_));        \
-      }                                                                                        \
-   } while (0)
-
-// every entry point that touches the device makes its context's device current first (two contexts on different
-// devices in one process would otherwise launch on whatever device the caller left current)
-#define RMH_ENTER(c) RMH_HIP(hipSetDevice((c)->device))
-
-struct EventPair
-{
-   hipEvent_t a, b;
-};
-} // namespace
-
-struct rmh_ctx
-{
-   int p = 0, ne = 0, ng = 0, exec_mode = 0, device = 0;
-   int ndof = 0;
-   hipStream_t stream = nullptr;
-   double t = 0.0;
-   double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
-   double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
-   double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
-   double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
-   const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold
-   int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
-   const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
-   int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)
-   double rel_tol = 1e-14, abs_tol = 0.0;
-   int max_iter = 100;
-   bool ho_done = false;
-   int bounds_type = 0; // DofInfo bounds type (-bt): 0 overlap, 1 face neighbours
-   double *d_dt_est = nullptr; // running minimum of UpdateTimeStepEstimate; null while dt control is off
-   bool dt_control = false;
-   int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
-   int ho_variant = 2; // 2: batched kernel (rmh_ho2.hpp), 1: one element per workgroup (rmh_kernels.hpp)
-   int n_cu = 256;     // compute units of the device
-   int persist = RMH_PERSIST_LOOP; // fused stage: workgroups per CU slot (0: one workgroup per element batch)
-   // stopwatches (TimingData, remhos_tools.hpp:52-64)
-   bool timers_on = false;
-   double tacc[4] = {0, 0, 0, 0};
-   std::vector<EventPair> pending[4];
-   std::vector<EventPair> pool;
-};
+} // namespace rmh
 
 namespace
 {
@@ -149,6 +100,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.u_ghost = c->u_ghost;
    a.gh_ustride = c->gh_ustride;
    a.gh_mstride = c->gh_mstride;
+   a.gh_compact = c->gh_compact;
    a.x0 = c->d_x0;
    a.vel = c->d_vel;
    a.face_nbr = c->d_nbr;
@@ -212,6 +164,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.u_ghost = c->u_ghost;
    a.gh_ustride = c->gh_ustride;
    a.gh_mstride = c->gh_mstride;
+   a.gh_compact = c->gh_compact;
    a.x0 = c->d_x0;
    a.vel = c->d_vel;
    a.face_nbr = c->d_nbr;
@@ -404,6 +357,7 @@ void rmh_destroy(rmh_ctx *c)
 {
    if (!c) { return; }
    (void)hipSetDevice(c->device);
+   exchange_free(c);
    void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
@@ -822,3 +776,5 @@ int rmh_set_mass_tol(rmh_ctx *c, double rel_tol, double abs_tol, int max_iter)
 }
 
 } // extern "C"
+
+#include "rmh_comm.hpp"

@@ -1,0 +1,75 @@
+// Private to the library: the context behind the opaque rmh_ctx of include/rmh.h, shared by the entry points
+// (rmh_api.hip) and the neighbour exchange (rmh_comm.hip).
+#pragma once
+#include "../../include/rmh.h"
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#ifndef RMH_PERSIST_LOOP
+#define RMH_PERSIST_LOOP 0
+#endif
+
+namespace rmh
+{
+int fail(int code, const std::string &msg); // records the message of rmh_last_error and returns code
+
+#define RMH_HIP(call)                                                                          \
+   do {                                                                                        \
+      hipError_t err_ = (call);                                                                \
+      if (err_ != hipSuccess)                                                                  \
+      {                                                                                        \
+         return rmh::fail(RMH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err_));   \
+      }                                                                                        \
+   } while (0)
+
+// every entry point that touches the device makes its context's device current first (two contexts on different
+// devices in one process would otherwise launch on whatever device the caller left current)
+#define RMH_ENTER(c) RMH_HIP(hipSetDevice((c)->device))
+
+struct EventPair
+{
+   hipEvent_t a, b;
+};
+
+struct Exchange; // rmh_comm.hpp
+} // namespace rmh
+
+struct rmh_ctx
+{
+   int p = 0, ne = 0, ng = 0, exec_mode = 0, device = 0;
+   int ndof = 0;
+   hipStream_t stream = nullptr;
+   double t = 0.0;
+   double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
+   double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
+   double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
+   double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
+   const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold
+   int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
+   const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
+   int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)
+   int gh_compact = 0; // 1: ghost records are [min | max | D^2 face trace] cells (rmh_exchange_setup, compact)
+   double rel_tol = 1e-14, abs_tol = 0.0;
+   int max_iter = 100;
+   bool ho_done = false;
+   int bounds_type = 0; // DofInfo bounds type (-bt): 0 overlap, 1 face neighbours
+   double *d_dt_est = nullptr; // running minimum of UpdateTimeStepEstimate; null while dt control is off
+   bool dt_control = false;
+   int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
+   int ho_variant = 2; // 2: batched kernel (rmh_ho2.hpp), 1: one element per workgroup (rmh_kernels.hpp)
+   int n_cu = 256;     // compute units of the device
+   int persist = RMH_PERSIST_LOOP; // fused stage: workgroups per CU slot (0: one workgroup per element batch)
+   // stopwatches (TimingData, remhos_tools.hpp:52-64)
+   bool timers_on = false;
+   double tacc[4] = {0, 0, 0, 0};
+   std::vector<rmh::EventPair> pending[4];
+   std::vector<rmh::EventPair> pool;
+   rmh::Exchange *xch = nullptr; // neighbour exchange (rmh_exchange_setup), or null
+};
+
+namespace rmh
+{
+void exchange_free(rmh_ctx *c); // rmh_comm.hpp
+}

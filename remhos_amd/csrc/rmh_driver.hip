@@ -9,7 +9,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace remhos
@@ -263,7 +265,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
    CaseConfig cc = to_config(*cfg);
    if (cc.px * cc.py * cc.pz != 1)
    {
-      g_driver_error = "rmhd_run drives one GPU; multi-GPU runs go through remhos_amd.stepper (torch.distributed)";
+      g_driver_error = "rmhd_run drives one block; box-partitioned runs go through rmhd_run_partitioned";
       return -1;
    }
    CaseData cd;
@@ -449,4 +451,278 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
    }
    rmh_destroy(ctx);
    return rc;
+}
+
+
+// ---- box-partitioned runs: the time loop of remhos() (remhos.cpp:1146-1330) over the blocks of a ParMesh-like
+// partition, one fused kernel per RK stage and block, one neighbour exchange per stage (rmh_exchange_begin / _end) ----
+namespace
+{
+struct Block
+{
+   CaseData cd;
+   rmh_ctx *ctx = nullptr;
+   double *x = nullptr, *y1 = nullptr, *y2 = nullptr, *xold = nullptr, *m = nullptr;
+   int vsize = 0;
+};
+
+bool read_or_write_id(const char *path, bool writer, char id[128])
+{
+   // rank 0 writes the ncclUniqueId to <path>.tmp and renames it; the other ranks poll for <path>
+   if (writer)
+   {
+      const std::string tmp = std::string(path) + ".tmp";
+      FILE *f = std::fopen(tmp.c_str(), "wb");
+      if (!f) { return false; }
+      const bool ok = std::fwrite(id, 1, 128, f) == 128;
+      std::fclose(f);
+      return ok && std::rename(tmp.c_str(), path) == 0;
+   }
+   for (int tries = 0; tries < 6000; tries++)
+   {
+      FILE *f = std::fopen(path, "rb");
+      if (f)
+      {
+         const bool ok = std::fread(id, 1, 128, f) == 128;
+         std::fclose(f);
+         if (ok) { return true; }
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(10));
+   }
+   return false;
+}
+} // namespace
+
+extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_file, int device, rmhd_result *res)
+{
+   if (!cfg || !res) { g_driver_error = "null argument"; return -1; }
+   CaseConfig cc0 = to_config(*cfg);
+   const int nranks = cc0.px * cc0.py * cc0.pz;
+   const bool rccl = comm_id_file && comm_id_file[0];
+   if (!cfg->fused) { g_driver_error = "rmhd_run_partitioned runs the one-kernel stage (fused = 1)"; return -1; }
+   std::vector<Block> blocks(rccl ? 1 : nranks);
+   auto cleanup = [&]()
+   {
+      for (Block &b : blocks)
+      {
+         (void)hipFree(b.x); (void)hipFree(b.y1); (void)hipFree(b.y2); (void)hipFree(b.xold); (void)hipFree(b.m);
+         if (b.ctx) { rmh_destroy(b.ctx); }
+      }
+   };
+#define RMHD_TRY(expr)                                                          \
+   do {                                                                         \
+      if ((expr) != 0) { g_driver_error = std::string(#expr) + ": " + rmh_last_error(); cleanup(); return -1; } \
+   } while (0)
+#define RMHD_HIP(expr)                                                          \
+   do {                                                                         \
+      if ((expr) != hipSuccess) { g_driver_error = #expr; cleanup(); return -1; } \
+   } while (0)
+   // ---- set-up of every block this process owns ------------------------------------------------------------------
+   for (size_t k = 0; k < blocks.size(); k++)
+   {
+      Block &b = blocks[k];
+      CaseConfig cc = cc0;
+      cc.rank = rccl ? cc0.rank : (int)k;
+      const std::string err = build_case(cc, b.cd);
+      if (!err.empty()) { g_driver_error = err; cleanup(); return -1; }
+      rmh_layout L;
+      L.dim = 3; L.order = b.cd.order; L.mesh_order = 2; L.exec_mode = b.cd.exec_mode;
+      L.ne_owned = b.cd.ne_owned; L.ne_ghost = b.cd.ne_ghost;
+      L.x0 = b.cd.x0.data(); L.vel = b.cd.vel.data(); L.face_nbr = b.cd.face_nbr.data(); L.stencil27 = b.cd.stencil27.data();
+      L.subcell_vel = b.cd.subcell_vel.empty() ? nullptr : b.cd.subcell_vel.data();
+      L.device = device;
+      RMHD_TRY(rmh_create(&L, &b.ctx));
+      RMHD_TRY(rmh_set_lo_type(b.ctx, cc.lo_type));
+      RMHD_TRY(rmh_set_bounds_type(b.ctx, cfg->bounds_type));
+      if (cfg->dt_control) { RMHD_TRY(rmh_set_dt_control(b.ctx, 1)); }
+      if (cfg->ho_type == 2) { RMHD_TRY(rmh_set_mass_tol(b.ctx, 1e-12, 0.0, 500)); }
+      b.vsize = b.cd.ne_owned * b.cd.ndof;
+      const size_t bytes = sizeof(double) * (size_t)b.vsize;
+      RMHD_HIP(hipMalloc((void **)&b.x, bytes));
+      RMHD_HIP(hipMalloc((void **)&b.y1, bytes));
+      RMHD_HIP(hipMalloc((void **)&b.y2, bytes));
+      RMHD_HIP(hipMalloc((void **)&b.m, bytes));
+      if (cfg->dt_control) { RMHD_HIP(hipMalloc((void **)&b.xold, bytes)); }
+      RMHD_HIP(hipMemcpy(b.x, b.cd.u0.data(), bytes, hipMemcpyHostToDevice));
+      // exchange plan from the case builder's halo lists; compact records unless a block is one element thin
+      const int np = (int)b.cd.peers.size();
+      std::vector<int> prank(np), scount(np), rfirst(np), rcount(np);
+      std::vector<const int *> selems(np);
+      for (int j = 0; j < np; j++)
+      {
+         const Peer &pr = b.cd.peers[j];
+         prank[j] = pr.rank;
+         scount[j] = (int)pr.send_elems.size();
+         selems[j] = pr.send_elems.data();
+         rfirst[j] = pr.recv_slots.empty() ? 0 : pr.recv_slots.front();
+         rcount[j] = (int)pr.recv_slots.size();
+      }
+      rmh_exchange_desc d = {np, prank.data(), scount.data(), selems.data(), rfirst.data(), rcount.data()};
+      bool thin = false;
+      const int P3[3] = {cc.px, cc.py, cc.pz};
+      for (int dd = 0; dd < 3; dd++) { thin = thin || (P3[dd] > 1 && b.cd.n[dd] / P3[dd] < 2); }
+      RMHD_TRY(rmh_exchange_setup(b.ctx, &d, thin ? 0 : 1));
+   }
+   if (rccl)
+   {
+      char id[128];
+      if (cc0.rank == 0) { RMHD_TRY(rmh_comm_unique_id(id)); }
+      if (!read_or_write_id(comm_id_file, cc0.rank == 0, id)) { g_driver_error = "cannot exchange the RCCL unique id through the file"; cleanup(); return -1; }
+      RMHD_TRY(rmh_comm_init(blocks[0].ctx, id, nranks, cc0.rank));
+   }
+   else
+   {
+      for (int r = 0; r < nranks; r++)
+      {
+         for (size_t j = 0; j < blocks[r].cd.peers.size(); j++)
+         {
+            const int q = blocks[r].cd.peers[j].rank;
+            if (q < r) { continue; } // (each pair once; a block may be its own neighbour's neighbour only through q != r)
+            int jq = -1;
+            for (size_t i = 0; i < blocks[q].cd.peers.size(); i++) { if (blocks[q].cd.peers[i].rank == r) { jq = (int)i; } }
+            if (jq < 0) { g_driver_error = "halo lists of two blocks do not mirror each other"; cleanup(); return -1; }
+            RMHD_TRY(rmh_comm_connect_local(blocks[r].ctx, (int)j, blocks[q].ctx, jq));
+         }
+      }
+   }
+   bool reduce_failed = false;
+   auto reduce = [&](double v, int op) -> double
+   {
+      // over the blocks of this process, then over the ranks of the communicator
+      if (rccl && nranks > 1) { if (rmh_allreduce(blocks[0].ctx, &v, 1, op) != 0) { reduce_failed = true; } }
+      return v;
+   };
+   auto mass_and_max = [&](double t, double &mass, double &umax) -> bool
+   {
+      mass = 0.0; umax = -INFINITY;
+      for (Block &b : blocks)
+      {
+         if (rmh_compute_lumped_mass(b.ctx, b.cd.exec_mode == 1 ? t : 0.0, b.m) != 0) { return false; }
+         std::vector<double> hm(b.vsize), hu(b.vsize);
+         if (hipMemcpy(hm.data(), b.m, sizeof(double) * b.vsize, hipMemcpyDeviceToHost) != hipSuccess) { return false; }
+         if (hipMemcpy(hu.data(), b.x, sizeof(double) * b.vsize, hipMemcpyDeviceToHost) != hipSuccess) { return false; }
+         for (int i = 0; i < b.vsize; i++) { mass += hm[i] * hu[i]; umax = std::fmax(umax, hu[i]); }
+      }
+      mass = reduce(mass, 0);  // MPI_Allreduce SUM, remhos.cpp:1412
+      umax = reduce(umax, 2);  // MPI_Allreduce MAX, remhos.cpp:1415
+      return true;
+   };
+   double mass0 = 0, umax0 = 0;
+   if (!mass_and_max(0.0, mass0, umax0)) { g_driver_error = "initial mass"; cleanup(); return -1; }
+   // ---- time loop ----------------------------------------------------------------------------------------------
+   const double t_final = blocks[0].cd.exec_mode == 1 ? 1.0 : cc0.t_final;
+   double dt = blocks[0].cd.dt, t = 0.0;
+   int ti = 0, ti_total = 0, repeats = 0;
+   bool done = false;
+   for (Block &b : blocks) { RMHD_TRY(rmh_enable_timers(b.ctx, 1)); }
+   RMHD_HIP(hipDeviceSynchronize());
+   const auto w0 = std::chrono::steady_clock::now();
+   // one RK stage of all blocks: post every exchange, run the elements that reach no ghost while the messages are
+   // in flight, complete the exchanges, run the halo-dependent shells
+   auto stage = [&](int which, double ts, double dt_real, double ra, double rb) -> bool
+   {
+      auto in = [&](Block &b) { return which == 0 ? b.x : (which == 1 ? b.y1 : b.y2); };
+      auto out = [&](Block &b) { return which == 0 ? b.y1 : (which == 1 ? b.y2 : b.x); };
+      for (Block &b : blocks) { if (rmh_exchange_begin(b.ctx, in(b)) != 0) { return false; } }
+      for (Block &b : blocks)
+      {
+         if (rmh_setup(b.ctx, ts) != 0) { return false; }
+         if (rmh_stage_fused_range(b.ctx, in(b), dt_real, which == 0 ? nullptr : b.x, ra, rb, dt_real, out(b), nullptr,
+                                   b.cd.ne_halo, b.cd.ne_owned, 0) != 0) { return false; }
+      }
+      for (Block &b : blocks) { if (rmh_exchange_end(b.ctx) != 0) { return false; } }
+      for (Block &b : blocks)
+      {
+         if (rmh_stage_fused_range(b.ctx, in(b), dt_real, which == 0 ? nullptr : b.x, ra, rb, dt_real, out(b), nullptr, 0,
+                                   b.cd.ne_halo, 1) != 0) { return false; }
+      }
+      return true;
+   };
+   while (!done)
+   {
+      const double dt_real = std::min(dt, t_final - t);
+      if (cfg->dt_control)
+      {
+         for (Block &b : blocks)
+         {
+            RMHD_TRY(rmh_dt_estimate_reset(b.ctx));
+            RMHD_HIP(hipMemcpyAsync(b.xold, b.x, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, nullptr));
+         }
+         RMHD_HIP(hipDeviceSynchronize());
+      }
+      // RK3SSPSolver::Step: stage times t, t + dt, t + dt/2
+      if (!stage(0, t, dt_real, 0.0, 1.0) || !stage(1, t + dt_real, dt_real, 3. / 4, 1. / 4) ||
+          !stage(2, t + dt_real / 2, dt_real, 1. / 3, 2. / 3))
+      {
+         g_driver_error = std::string("stage: ") + rmh_last_error(); cleanup(); return -1;
+      }
+      t += dt_real;
+      ti++;
+      ti_total++;
+      if (cfg->dt_control)
+      {
+         double est = INFINITY;
+         for (Block &b : blocks) { double e = 0; RMHD_TRY(rmh_dt_estimate_get(b.ctx, &e)); est = std::fmin(est, e); }
+         est = reduce(est, 1); // MPI_Allreduce MIN, remhos.cpp:1993
+         const double ratio = dt_real != 0. ? est / dt_real : 0.;
+         if (ratio < 1.)
+         {
+            ti--;
+            t -= dt_real;
+            for (Block &b : blocks)
+            {
+               RMHD_HIP(hipMemcpyAsync(b.x, b.xold, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, nullptr));
+               RMHD_TRY(rmh_invalidate_extrema(b.ctx));
+            }
+            RMHD_HIP(hipDeviceSynchronize());
+            dt = 0.85 * dt;
+            repeats++;
+            if (dt < 1e-12) { g_driver_error = "The time step crashed!"; cleanup(); return -1; }
+            continue;
+         }
+         else if (ratio > 1.25) { dt *= 1.02; }
+      }
+      done = (t >= t_final - 1.e-8 * dt);
+      if (ti_total == cc0.max_steps) { done = true; }
+   }
+   RMHD_HIP(hipDeviceSynchronize());
+   const auto w1 = std::chrono::steady_clock::now();
+   double mass = 0, umax = 0;
+   if (!mass_and_max(t, mass, umax)) { g_driver_error = "final mass"; cleanup(); return -1; }
+   double tk = 0.0;
+   int itmax = 0;
+   for (Block &b : blocks)
+   {
+      double tm[4];
+      RMHD_TRY(rmh_timers(b.ctx, tm));
+      tk = std::fmax(tk, tm[0]);
+      int it = 0;
+      rmh_last_cg_iters(b.ctx, &it);
+      itmax = std::max(itmax, it);
+   }
+   tk = reduce(tk, 2); // MPI_Reduce MAX of the stopwatches, remhos.cpp:1934
+   if (reduce_failed) { g_driver_error = std::string("rmh_allreduce: ") + rmh_last_error(); cleanup(); return -1; }
+   std::memset(res, 0, sizeof(*res));
+   res->final_mass = mass;
+   res->max_value = umax;
+   res->mass0 = mass0;
+   res->mass_loss = std::fabs(mass0 - mass);
+   res->dt = dt;
+   res->t_end = t;
+   res->steps = ti;
+   res->stages = 3 * ti_total;
+   res->global_dofs = blocks[0].cd.ne_global * blocks[0].cd.ndof;
+   res->t_rhs = tk; // the whole stage is one kernel: everything is in the RHS bucket
+   res->t_total = tk;
+   const double dofs_steps = 1e-6 * (double)res->global_dofs * res->stages;
+   res->fom_rhs = tk > 0 ? dofs_steps / tk : 0;
+   res->fom = res->fom_rhs;
+   res->wall = reduce(std::chrono::duration<double>(w1 - w0).count(), 2);
+   res->fom_wall = dofs_steps / res->wall;
+   res->cg_iters_max = itmax;
+   res->repeats = repeats;
+   cleanup();
+   return 0;
+#undef RMHD_TRY
+#undef RMHD_HIP
 }

@@ -615,7 +615,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
          const int nb = nbi[j];
          const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
-         gn[j] = un[(side ? 0 : P) * strc + i1 * str1 + i2 * str2]; // the neighbour's opposite face layer
+         // the neighbour's opposite face layer (compact ghost records hold exactly that layer, ordered like this face:
+         // rmh_exchange_setup)
+         const int off = (a.gh_compact && nb >= a.ne_owned) ? r : (side ? 0 : P) * strc + i1 * str1 + i2 * str2;
+         gn[j] = un[off];
       }
    }
 #pragma unroll

@@ -63,6 +63,7 @@ struct HoArgs
    const int *stencil27;            // [ne][27]
    const double *gh_min, *gh_max;   // ghost element extrema, element g at [g * gh_mstride]
    int gh_ustride, gh_mstride;
+   int gh_compact;                  // 1: a ghost's trace record holds only the face layer facing this rank, [i1 + D*i2]
    double dt;                       // full time step (LO / FCT)
    const double *x_base;            // y_out = rk_a * x_base + rk_b * (u + dt_rk * du)
    double rk_a, rk_b, dt_rk;
@@ -208,7 +209,8 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
             const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3
                                : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
             const int ic = side ? 0 : P; // the neighbour's opposite face layer
-            val = un[ic * strc + i1 * str1 + i2 * str2];
+            // (compact ghost records hold exactly that layer, ordered like this face: rmh_exchange_setup)
+            val = (a.gh_compact && nb >= a.ne_owned) ? un[r] : un[ic * strc + i1 * str1 + i2 * str2];
          }
          sNb[k] = val;
       }

@@ -3,9 +3,10 @@
 Everything numeric is a HIP kernel behind include/rmh.h; torch supplies device buffers, the
 stream and torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests).  Stage sequence = AdvectionOperator::Mult (remhos.cpp:1596-1916) inside
-RK3SSPSolver::Step [MFEM]; per stage ONE neighbour exchange carries, for every element a
-neighbour rank needs, its ndof values of u (ParGridFunction::ExchangeFaceNbrData,
-remhos_ho.cpp:122) plus its min/max (the GroupCommunicator min/max of remhos_tools.cpp:461-466).
+RK3SSPSolver::Step [MFEM]; per stage ONE neighbour exchange (rmh_exchange_begin / rmh_exchange_end: plan, pack
+kernels, ghost records and the RCCL transport are inside the library) carries, for every element a neighbour rank
+needs, its face layer -- or all its values -- of u (ParGridFunction::ExchangeFaceNbrData, remhos_ho.cpp:122) plus
+its min/max (the GroupCommunicator min/max of remhos_tools.cpp:461-466).
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ class Stepper:
         import os as _os
         self.sync_exchange = _os.environ.get("RMH_SYNC_EXCHANGE", "0") == "1" and self.dev.type == "cuda"
         self.dist = dist if (dist is not None and case.peers) else None
+        self.defer_exchange = False
         self.lo = int(case.cfg.lo_type)
         self.fused_lo4 = fused and self.lo in (3, 4)  # lo 3 / 4: HO kernel + RD kernel + fused limiter/RK kernel
         self.fused = fused and self.lo == 5
@@ -62,60 +64,113 @@ class Stepper:
             self.m = torch.empty_like(self.x)
         self.t = 0.0
         self.dt = case.dt
-        # ghost storage and exchange plan.  A ghost record is [ndof values of u | min | max]; the ghost slots of
-        # a peer are a contiguous range (ghosts are ordered by owner rank, then global id), so ONE message per
-        # peer lands directly in the ghost block; one device pack kernel gathers the records of all peers' send lists
-        self.ghost = torch.zeros(max(ng, 1), nd + 2, **f64)
-        if ng:
-            self.ctx.set_ghost_records(self.ghost)
-        self.plan = []
-        send_all, off = [], 0
-        for rank, send, recv in case.peers:
-            r0, r1 = int(recv[0]), int(recv[-1]) + 1
-            assert r1 - r0 == len(recv) and (recv == range(r0, r1)).all(), "ghost slots of a peer must be contiguous"
-            self.plan.append((rank, off, off + len(send), r0, r1))
-            send_all.append(send)
-            off += len(send)
-        self.nsend = off
+        # Neighbour exchange: plan, pack kernels, ghost records and (with RCCL) the transport live in the library
+        # (rmh_exchange_*, include/rmh.h).  Transports: "rccl" = grouped ncclSend/ncclRecv inside the library on a
+        # communicator made from a unique id broadcast over the process group; "external" = this class moves the
+        # library's send segments into the neighbours' ghost segments with torch.distributed (gloo in the CPU tests,
+        # or the fallback when the in-library communicator cannot be created); "local" = the peers are contexts of
+        # this process (connect_local_peers).
+        self.transport = None
+        # compact records (face layer + extrema instead of whole elements) need every block at least two elements
+        # thick in the partitioned directions; decided from the partition alone, so that all ranks agree
+        part = (case.cfg.px, case.cfg.py, case.cfg.pz)
+        thin = any(part[d] > 1 and case.n[d] // part[d] < 2 for d in range(3))
+        self.compact = _os.environ.get("RMH_COMPACT", "1") != "0" and not thin
         self.ops = []
-        if self.plan:
-            import numpy as np
-
-            self.send_elems = torch.from_numpy(np.concatenate(send_all).astype("int32")).to(self.dev)
-            self.srec = torch.empty(self.nsend, nd + 2, **f64)
+        if case.peers:
+            self.ctx.exchange_setup(case.peers, compact=self.compact)
             if self.dist is not None:
-                d = self.dist
-                for rank, s0, s1, r0, r1 in self.plan:
-                    self.ops += [d.P2POp(d.isend, self.srec[s0:s1], rank), d.P2POp(d.irecv, self.ghost[r0:r1], rank)]
+                self._connect(self.dist)
+
+    def _buffer_tensor(self, ptr, n):
+        """torch view of n doubles of a library-owned buffer (no copy)"""
+        if self.dev.type == "cuda":
+            class _Cai:
+                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+            return torch.as_tensor(_Cai(), device=self.dev)
+        import ctypes as C
+
+        import numpy as np
+
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_double * n).from_address(ptr)))
+
+    def _connect(self, d):
+        import os as _os
+
+        want_rccl = d.get_backend() == "nccl" and _os.environ.get("RMH_EXCHANGE", "rccl") == "rccl"
+        ok = 0
+        if want_rccl:
+            try:
+                box = [self.ctx.comm_unique_id() if d.get_rank() == 0 else None]
+                d.broadcast_object_list(box, src=0)
+                self.ctx.comm_init(box[0], d.get_world_size(), d.get_rank())
+                ok = 1
+            except Exception as e:  # noqa: BLE001 -- every rank must take the same branch below
+                self.rccl_error = str(e)
+            flag = torch.tensor([ok], device=self.dev)
+            d.all_reduce(flag, op=d.ReduceOp.MIN)
+            ok = int(flag[0])
+        if ok:
+            self.transport = "rccl"
+            return
+        self.transport = "external"
+        sp, sn, gp, gn = self.ctx.exchange_buffers()
+        send = self._buffer_tensor(sp, max(sn, 1))
+        ghost = self._buffer_tensor(gp, max(gn, 1))
+        for k in range(len(self.case.peers)):
+            rank, so, scount, ro, rcount = self.ctx.exchange_peer(k)
+            if scount:
+                self.ops.append(d.P2POp(d.isend, send[so:so + scount], rank))
+            if rcount:
+                self.ops.append(d.P2POp(d.irecv, ghost[ro:ro + rcount], rank))
+
+    def connect_local_peers(self, steppers):
+        """All blocks in this process: steppers[r] is the Stepper of rank r (device copies instead of RCCL)."""
+        for k, (rank, _, _) in enumerate(self.case.peers):
+            other = steppers[rank]
+            ok = [j for j, (r2, _, _) in enumerate(other.case.peers) if r2 == self.case.cfg.rank]
+            self.ctx.comm_connect_local(k, other.ctx, ok[0])
+        self.transport = "local"
 
     # -- halo exchange: neighbour all-to-all of ghost records ----------------------------------------
-    def exchange(self, u):
-        """Post the exchange; returns the work handles (wait on them before anything reads the ghosts)."""
-        if not self.plan:
+    def exchange_begin(self, u):
+        """Pack and post the exchange; returns work handles of the external transport."""
+        if not self.case.peers:
             return []
-        if self.dist is None:
-            raise RuntimeError("this rank has neighbour ranks but no torch.distributed group was given")
-        self.ctx.halo_pack_records(u, self.send_elems, self.nsend, self.srec)
+        if self.transport is None:
+            raise RuntimeError("this rank has neighbour ranks but no transport (torch.distributed group or local peers)")
+        self.ctx.exchange_begin(u)
+        if self.transport != "external":
+            return []
         if self.sync_exchange:
-            torch.cuda.synchronize(self.dev)  # backends that are not stream-aware (gloo on device tensors) read srec now
+            torch.cuda.synchronize(self.dev)  # backends that are not stream-aware (gloo on device tensors) read the send buffer now
         return self.dist.batch_isend_irecv(self.ops)
+
+    def exchange_end(self, works):
+        for w in works:
+            w.wait()
+        if self.case.peers:
+            self.ctx.exchange_end()
 
     # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
     def stage(self, u, t, dt, x_base, a, b, out):
         c = self.ctx
-        works = self.exchange(u)
+        if self.defer_exchange:
+            works = []  # (lockstep driver of several same-process blocks: it has begun and will end the exchange itself)
+        else:
+            works = self.exchange_begin(u)
         c.setup(t)
-        if self.one_kernel and works and self.overlap:
+        if self.one_kernel and self.case.peers and self.overlap and not self.defer_exchange:
             # elements that reach no ghost run while the exchange is in flight (the RCCL send/recv
-            # kernels live on the process group's own stream), the halo-dependent shell after it
+            # kernels live on the library's exchange stream), the halo-dependent shell after it
             nh, ne = self.case.ne_halo, self.case.ne_owned
             c.stage_fused_range(u, dt, out, nh, ne, False, x_base=x_base, a=a, b=b, dt_rk=dt)
-            for w in works:
-                w.wait()
+            self.exchange_end(works)
             c.stage_fused_range(u, dt, out, 0, nh, True, x_base=x_base, a=a, b=b, dt_rk=dt)
             return
-        for w in works:
-            w.wait()
+        if not self.defer_exchange:
+            self.exchange_end(works)
         if self.one_kernel:
             c.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt)
             return
@@ -213,3 +268,30 @@ class Stepper:
 
     def close(self):
         self.ctx.close()
+
+
+def lockstep_step(steppers, dt):
+    """One RK3-SSP step of ALL blocks of a partition held by this process (Stepper.connect_local_peers): per stage
+    every block posts its exchange, every block completes it, then every block runs its stage."""
+    def stage(get_u, t_off, get_base, a, b, get_out):
+        for s in steppers:
+            s.exchange_begin(get_u(s))
+        for s in steppers:
+            s.exchange_end([])
+        for s in steppers:
+            s.defer_exchange = True
+            try:
+                s.stage(get_u(s), s.t + t_off, dt, get_base(s), a, b, get_out(s))
+            finally:
+                s.defer_exchange = False
+
+    if steppers[0].one_kernel:
+        stage(lambda s: s.x, 0.0, lambda s: None, 0.0, 1.0, lambda s: s.y)
+        stage(lambda s: s.y, dt, lambda s: s.x, 0.75, 0.25, lambda s: s.y2)
+        stage(lambda s: s.y2, dt / 2, lambda s: s.x, 1.0 / 3.0, 2.0 / 3.0, lambda s: s.x)
+    else:
+        stage(lambda s: s.x, 0.0, lambda s: None, 0.0, 1.0, lambda s: s.y)
+        stage(lambda s: s.y, dt, lambda s: s.x, 0.75, 0.25, lambda s: s.y)
+        stage(lambda s: s.y, dt / 2, lambda s: s.x, 1.0 / 3.0, 2.0 / 3.0, lambda s: s.x)
+    for s in steppers:
+        s.t += dt

@@ -176,6 +176,11 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new std::remove_pointer_t<hipEvent_t>; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 
 template <typename K, typename... Args>

@@ -1,0 +1,135 @@
+"""The in-library neighbour exchange (rmh_exchange_*, include/rmh.h) with its same-process transport: all blocks of
+a box partition as contexts of ONE process, device copies instead of RCCL -- same plan, pack kernels, ghost records
+and stream/event ordering as the RCCL path.  CPU: through the g++ emulation build of the kernel sources; the GPU
+twin is tests/test_gpu_exchange.py."""
+import numpy as np
+import pytest
+
+from remhos_amd.capi import RmhError
+
+
+def run_blocks(lib, device, mesh, rs, p, prob, part, steps, lo=5, compact=None, extra=(0, 0, 0)):
+    """final field in global element order, from a lockstep run of all blocks in this process"""
+    import os
+
+    import torch
+
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper, lockstep_step
+
+    n = part[0] * part[1] * part[2]
+    old = os.environ.get("RMH_COMPACT")
+    if compact is not None:
+        os.environ["RMH_COMPACT"] = "1" if compact else "0"
+    try:
+        cases = [Case(lib, make_config(mesh, rs, p, prob, -1.0, 0.5, lo_type=lo, part=part, rank=r, rs_extra=extra)) for r in range(n)]
+        sts = [Stepper(lib, c, device=device) for c in cases]
+    finally:
+        if old is None:
+            os.environ.pop("RMH_COMPACT", None)
+        else:
+            os.environ["RMH_COMPACT"] = old
+    for s in sts:
+        if s.case.peers:
+            s.connect_local_peers(sts)
+    for _ in range(steps):
+        lockstep_step(sts, cases[0].dt)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    gid = np.concatenate([c.owned_gid for c in cases])
+    u = np.concatenate([s.x.cpu().numpy() for s in sts])
+    compact_used = [s.compact for s in sts]
+    for s in sts:
+        s.close()
+    return u[np.argsort(gid)], compact_used
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+    from tests.helpers import emu_library_path
+
+    return bind_driver(load_library(emu_library_path()))
+
+
+@pytest.mark.parametrize("mesh,rs,p,part,lo,compact", [
+    ("periodic-cube", 1, 2, (2, 1, 1), 5, True),    # 6^3 elements, 3 thick: face layers + extrema only
+    ("periodic-cube", 1, 2, (2, 1, 1), 5, False),   # whole neighbour elements
+    ("cube01_hex", 1, 1, (2, 2, 1), 5, True),       # edge neighbours: extrema-only records
+    ("periodic-cube", 1, 2, (1, 2, 1), 4, True),    # subcell RD reads the same ghost traces
+])
+def test_blocks_in_one_process_equal_single_block(lib, mesh, rs, p, part, lo, compact):
+    u1, _ = run_blocks(lib, "cpu", mesh, rs, p, 10, (1, 1, 1), 1, lo=lo)
+    un, used = run_blocks(lib, "cpu", mesh, rs, p, 10, part, 1, lo=lo, compact=compact)
+    assert all(c == compact for c in used)
+    assert np.array_equal(u1, un)  # the partition and the record format may not change a single bit
+
+
+def test_compact_records_refuse_thin_blocks(lib):
+    """an element adjacent to one neighbour rank through two faces (periodic, 2 blocks, one of them 1 element thick)"""
+    from remhos_amd.capi import Context
+    from remhos_amd.case import Case, make_config
+
+    case = Case(lib, make_config("periodic-cube", 0, 2, 10, -1.0, 0.5, part=(1, 2, 1), rank=0))
+    ctx = Context(lib, order=2, exec_mode=1, x0=case.x0, vel=case.vel, face_nbr=case.face_nbr, stencil27=case.stencil27,
+                  ne_ghost=case.ne_ghost)
+    with pytest.raises(RmhError, match="compact = 0"):
+        ctx.exchange_setup(case.peers, compact=True)
+    ctx.exchange_setup(case.peers, compact=False)  # the full-record plan is accepted afterwards
+    ctx.close()
+
+
+def test_exchange_call_order_is_checked(lib):
+    import torch
+
+    from remhos_amd.capi import Context
+    from remhos_amd.case import Case, make_config
+
+    case = Case(lib, make_config("periodic-cube", 1, 1, 10, -1.0, 0.5, part=(2, 1, 1), rank=0))
+    ctx = Context(lib, order=1, exec_mode=1, x0=case.x0, vel=case.vel, face_nbr=case.face_nbr, stencil27=case.stencil27,
+                  ne_ghost=case.ne_ghost)
+    u = torch.from_numpy(case.u0.copy())
+    with pytest.raises(RmhError, match="no exchange plan"):
+        ctx.exchange_begin(u)
+    ctx.exchange_setup(case.peers, compact=True)
+    with pytest.raises(RmhError, match="without rmh_exchange_begin"):
+        ctx.exchange_end()
+    ctx.exchange_begin(u)
+    with pytest.raises(RmhError, match="not ended"):
+        ctx.exchange_begin(u)
+    with pytest.raises(RmhError, match="already set up"):
+        ctx.exchange_setup(case.peers, compact=True)
+    # segments: face ghosts carry 2 + D^2 doubles, the plan is symmetric for this 2-block periodic case
+    sp, sn, gp, gn = ctx.exchange_buffers()
+    rank, so, scount, ro, rcount = ctx.exchange_peer(0)
+    assert rank == 1 and so == 0 and ro == 0 and scount == sn and rcount == gn
+    D2 = 4
+    nface = 2 * 6 * 6  # both x-faces of a 3 x 6 x 6 block face the other rank
+    assert sn == nface * (2 + D2) and gn == sn
+    ctx.close()
+
+
+def test_partitioned_cpp_driver_equals_single_block(lib):
+    """rmhd_run_partitioned (C++ time loop over all blocks of this process, in-library exchange, compact records)
+    against rmhd_run on the undivided mesh: same steps, same max, mass equal up to the order of the block sums"""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    one, many = RmhdResult(), RmhdResult()
+    cfg = make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, max_steps=2)
+    assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
+    cfgp = make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, max_steps=2, part=(2, 1, 2))
+    assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
+    assert (many.steps, many.stages, many.global_dofs) == (one.steps, one.stages, one.global_dofs)
+    assert many.max_value == one.max_value
+    assert abs(many.final_mass - one.final_mass) < 1e-14 and abs(many.mass0 - one.mass0) < 1e-14
+    # dt control: the min over the blocks drives the controller -- same accepted / repeated steps as one block
+    kw = dict(bounds_type=1, dt_control=1, lo_type=4)
+    cfg = make_config("periodic-cube", 0, 2, 0, 0.06, 0.12, **kw)
+    cfgp = make_config("periodic-cube", 0, 2, 0, 0.06, 0.12, part=(1, 1, 3), **kw)
+    assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
+    assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
+    assert one.repeats > 0 and (many.steps, many.repeats, many.dt) == (one.steps, one.repeats, one.dt)
+    assert many.max_value == one.max_value and abs(many.final_mass - one.final_mass) < 1e-14

@@ -7,5 +7,5 @@ name=$1; shift
 cd "$(dirname "$0")/../remhos_amd/csrc"
 mkdir -p build
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-honor-nans "$@" -c rmh_api.hip -o build/rmh_api_$name.o
-hipcc --offload-arch=gfx950 -shared -fPIC build/rmh_api_$name.o build/rmh_driver.o build/rmh_host.o build/rmh_case_api.o -o ../librmh_$name.so -pthread
+hipcc --offload-arch=gfx950 -shared -fPIC build/rmh_api_$name.o build/rmh_driver.o build/rmh_host.o build/rmh_case_api.o -o ../librmh_$name.so -pthread -ldl
 echo built remhos_amd/librmh_$name.so
