@@ -973,7 +973,7 @@ class Remhos:
         """time loop remhos.cpp:1146-1296 and report :1382-1428."""
         cfg = self.cfg
         t_final = 1.0 if self.exec_mode == 1 else cfg.t_final
-        ti = 0
+        ti = ti_total = 0  # accepted steps / all steps incl. repeated ones (remhos.cpp:1142)
         done = False
         self.repeats = 0
         while not done:
@@ -983,6 +983,7 @@ class Remhos:
             u_old, t_old = self.u, self.t
             self.step(dt_real)
             ti += 1
+            ti_total += 1
             if cfg.dt_control != 0:
                 # remhos.cpp:1178-1197
                 if self.dt_ratio < 1.0:
@@ -996,7 +997,7 @@ class Remhos:
                 if self.dt_ratio > 1.25:
                     self.dt *= 1.02
             done = self.t >= t_final - 1e-8 * self.dt
-            if ti == cfg.max_steps:
+            if ti_total == cfg.max_steps:  # -ms counts repeated steps too (remhos.cpp:1296)
                 done = True
             if verbose and (done or ti % 20 == 0):
                 print(f"step {ti} t {self.t:.6f}")
