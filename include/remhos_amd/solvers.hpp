@@ -53,6 +53,24 @@ public:
    void CopyToHost(double *h) const;
 };
 typedef Vector ParGridFunction;
+typedef Vector GridFunction;   // (only as the unused mesh-velocity argument of MassBasedAvg, remhos_lo.hpp:91)
+class SmoothnessIndicator;     // remhos_tools.hpp:66-112: not on the hot path, only named by the FCTSolver constructors
+
+// mfem::Array<T> as far as the FCTSolver interface needs it (the active-element / active-dof flags of product remap,
+// remhos_fct.hpp:72-86): a device-resident flag array.
+template <class T>
+class Array
+{
+   T *data = nullptr;
+   int size = 0;
+
+public:
+   Array() {}
+   Array(T *device_ptr, int n) : data(device_ptr), size(n) {}
+   int Size() const { return size; }
+   const T *Read() const { return data; }
+   T *Write() { return data; }
+};
 
 // y = a*x + b*y' helpers used by the RK solver (device axpys)
 void add(const Vector &x, double a, const Vector &y, Vector &z);           // z = x + a y
@@ -133,11 +151,16 @@ class MassBasedAvg : public LOSolver
 {
 protected:
    HOSolver &ho_solver;
+   const GridFunction *mesh_v;
    // Temporary HO solution, used only in the next call to CalcLOSolution().
    mutable const Vector *du_HO = nullptr;
 
 public:
-   MassBasedAvg(ParFiniteElementSpace &space, HOSolver &hos) : LOSolver(space), ho_solver(hos) {}
+   // (mesh_vel is unused by the reference as well: SURVEY.md Appendix B.11)
+   MassBasedAvg(ParFiniteElementSpace &space, HOSolver &hos, const GridFunction *mesh_vel)
+      : LOSolver(space), ho_solver(hos), mesh_v(mesh_vel)
+   {
+   }
    void SetHOSolution(Vector &du) { du_HO = &du; }
    void CalcLOSolution(const Vector &u, Vector &du) const override;
 };
@@ -163,18 +186,33 @@ class FCTSolver
 {
 protected:
    ParFiniteElementSpace &pfes;
+   SmoothnessIndicator *smth_indicator;
    real_t dt;
+   const bool needs_LO_input_for_products;
 
 public:
-   FCTSolver(ParFiniteElementSpace &space, real_t dt_) : pfes(space), dt(dt_) {}
+   FCTSolver(ParFiniteElementSpace &space, SmoothnessIndicator *si, real_t dt_, bool needs_LO_prod)
+      : pfes(space), smth_indicator(si), dt(dt_), needs_LO_input_for_products(needs_LO_prod)
+   {
+   }
    virtual ~FCTSolver() {}
    virtual void UpdateTimeStep(real_t dt_new) { dt = dt_new; }
+   bool NeedsLOProductInput() const { return needs_LO_input_for_products; }
    // Calculate du that satisfies the following:
    // bounds preservation: u_min_i <= u_i + dt du_i <= u_max_i,
    // conservation:        sum m_i (u_i + dt du_ho_i) = sum m_i (u_i + dt du_i).
    virtual void CalcFCTSolution(const ParGridFunction &u, const Vector &m, const Vector &du_ho,
                                 const Vector &du_lo, const Vector &u_min, const Vector &u_max,
                                 Vector &du) const = 0;
+   // Used in the case of product remap (remhos_fct.hpp:72-86): given the input, calculates d_us, so that
+   // bounds preservation: s_min_i <= (us_i + dt d_us_i) / u_new_i <= s_max_i,
+   // conservation: sum m_i (us_i + dt d_us_HO_i) = sum m_i (us_i + dt d_us_i).
+   virtual void CalcFCTProduct(const ParGridFunction &us, const Vector &m, const Vector &d_us_HO, const Vector &d_us_LO,
+                               Vector &s_min, Vector &s_max, const Vector &u_new, const Array<bool> &active_el,
+                               const Array<bool> &active_dofs, Vector &d_us)
+   {
+      RMH_VERIFY(false, "Product remap is not implemented for the chosen solver");
+   }
    TimingData *timer = nullptr;
    bool verify_bounds = false;
 };
@@ -183,9 +221,14 @@ public:
 class ClipScaleSolver : public FCTSolver
 {
 public:
-   ClipScaleSolver(ParFiniteElementSpace &space, real_t dt_) : FCTSolver(space, dt_) {}
+   ClipScaleSolver(ParFiniteElementSpace &space, SmoothnessIndicator *si, real_t dt_) : FCTSolver(space, si, dt_, false) {}
    void CalcFCTSolution(const ParGridFunction &u, const Vector &m, const Vector &du_ho, const Vector &du_lo,
                         const Vector &u_min, const Vector &u_max, Vector &du) const override;
+   // remhos_fct.cpp:543-611: compatible low-order product, scaled bounds, clip + scale, empty dofs zeroed -- one kernel
+   // (rmh_fct_product)
+   void CalcFCTProduct(const ParGridFunction &us, const Vector &m, const Vector &d_us_HO, const Vector &d_us_LO,
+                       Vector &s_min, Vector &s_max, const Vector &u_new, const Array<bool> &active_el,
+                       const Array<bool> &active_dofs, Vector &d_us) override;
 };
 
 // Local bounds (remhos_tools.hpp:114-189): element extrema and overlap bounds
@@ -196,9 +239,17 @@ class DofInfo
 public:
    Vector xe_min, xe_max, xi_min, xi_max;
    DofInfo(ParFiniteElementSpace &space);
-   void ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_max) const;
+   // (with the masks of product remap, remhos_tools.cpp:497-523: inactive elements get (+inf, -inf), which makes
+   // ComputeBounds on the result the reference's ComputeBounds(..., &active_el))
+   void ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_max, Array<bool> *active_el = nullptr,
+                              Array<bool> *active_dof = nullptr) const;
    void ComputeBounds(const Vector &el_min, const Vector &el_max, Vector &dof_min, Vector &dof_max) const;
 };
+
+// remhos_sync.hpp: active element / dof flags and the ratio s = us / u of product remap (device kernels)
+void ComputeBoolIndicators(ParFiniteElementSpace &pfes, const Vector &u, Array<bool> &ind_elem, Array<bool> &ind_dofs);
+void ComputeRatio(ParFiniteElementSpace &pfes, const Vector &us, const Vector &u, Vector &s, Array<bool> &bool_el,
+                  Array<bool> &bool_dof);
 
 // remhos_solvers.hpp:25-63
 class LimitedTimeDependentOperator

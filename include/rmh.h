@@ -72,6 +72,20 @@ typedef struct {
    int device;       /* HIP device ordinal */
 } rmh_layout;
 
+/* Neighbour tables from mesh topology (host, no GPU): face_nbr and stencil27 of rmh_layout for ANY element numbering,
+ * from the vertex ids of the elements -- what a binding has at hand (Mesh::GetElementVertices; periodic meshes: the
+ * identified vertex ids).  elem_vertices[ne_total][8]: the 8 corner vertex ids of every element in LEXICOGRAPHIC local
+ * order (corner k = kx + 2 ky + 4 kz along the element's reference axes; MFEM's hexahedron order 0..7 maps to
+ * {0, 1, 3, 2, 4, 5, 7, 6}).  Elements [0, ne_owned) get table rows; elements [ne_owned, ne_total) (ghosts: the
+ * face-, edge- and vertex-neighbour elements of other ranks) only appear as entries.  Two elements are neighbours at
+ * stencil offset (ox, oy, oz) when the corners they share are exactly the corners of the first element's face / edge /
+ * vertex in that direction -- the CG-node sharing that DofInfo::ComputeOverlapBounds reduces over
+ * (remhos_tools.cpp:449-494), without the H1 bounds space.  Requires the neighbours' reference axes to be aligned
+ * with the element's and at least 3 elements per periodic direction (tensor-lattice meshes in any numbering;
+ * checked: RMH_ERR_INVALID otherwise).
+ * face_nbr[ne_owned][6], stencil27[ne_owned][27]: outputs (caller-allocated). */
+int rmh_build_tables(int ne_owned, int ne_total, const int *elem_vertices, int *face_nbr, int *stencil27);
+
 /* Creation / destruction.  Replaces the construction of LocalInverseHOSolver, MassBasedAvg /
  * PAResidualDistributionSubcell, ClipScaleSolver and DofInfo (remhos.cpp:730, 912-995,
  * 1083-1108). */
@@ -197,6 +211,26 @@ int rmh_bounds(rmh_ctx *ctx, const double *xe_min, const double *xe_max,
 int rmh_fct_clipscale(rmh_ctx *ctx, const double *u, const double *m,
                       const double *du_ho, const double *du_lo,
                       const double *u_min, const double *u_max, double dt, double *du);
+
+/* ---- Product-field remap (-ps; second block of AdvectionOperator::LimitMult, remhos.cpp:1848-1915) ----------------
+ * Flags are device byte arrays (mfem::Array<bool>): active_el[ne], active_dofs[ne * ndof].
+ * rmh_product_ratio: ComputeBoolIndicators (remhos_sync.cpp:23-47: u > EMPTY_ZONE_TOL = 1e-12) and, when us and s are
+ *   given, ComputeRatio (remhos_sync.cpp:50-96): s = us / u on active dofs, the element's mean active ratio on its
+ *   other dofs, 0 in empty elements.
+ * rmh_elem_minmax_masked: DofInfo::ComputeElementsMinMax(s, xe_min, xe_max, &active_el, &active_dofs)
+ *   (remhos_tools.cpp:497-523); empty elements get (+inf, -inf), so that rmh_bounds on the result IS
+ *   DofInfo::ComputeBounds(..., &active_el) (remhos_tools.cpp:432-495: inactive elements do not affect the bounds).
+ * rmh_fct_product: ClipScaleSolver::CalcFCTProduct (remhos_fct.cpp:543-566) = CalcCompatibleLOProduct (:26-115; s_min /
+ *   s_max are updated in place like the reference's) + ScaleProductBounds (:117-153) + ClipScale (:449-541) +
+ *   ZeroOutEmptyDofs (remhos_sync.cpp:98-116) in one kernel.  d_us_HO comes from rmh_ho_apply on us.
+ * Single-rank only: the ghost extrema of s would need their own exchange. */
+int rmh_product_ratio(rmh_ctx *ctx, const double *us, const double *u, double *s, unsigned char *active_el,
+                      unsigned char *active_dofs);
+int rmh_elem_minmax_masked(rmh_ctx *ctx, const double *u, const unsigned char *active_el, const unsigned char *active_dofs,
+                           double *xe_min, double *xe_max);
+int rmh_fct_product(rmh_ctx *ctx, const double *us, const double *m, const double *d_us_ho, double *s_min, double *s_max,
+                    const double *u_new, const unsigned char *active_el, const unsigned char *active_dofs, double dt,
+                    double *d_us);
 
 /* Fused LimitMult for -lo 5 -fct 2 (remhos.cpp:1798-1845): mass-based average, overlap bounds
  * and clip+scale in one pass over the element, nothing but du written.  Uses the lumped mass

@@ -1019,3 +1019,96 @@ class Remhos:
             "steps": getattr(self, "steps", 0),
             "dt": self.dt,
         }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Product-field remap (-ps): restatement of the per-element functions of the second block of
+# AdvectionOperator::LimitMult (remhos.cpp:1848-1915).  Plain loops over elements, in the reference's order of
+# operations.  PARITY UNPINNED end to end: the reference's only -ps known answers are 2-D runs with -ho 1 / IDP RK
+# solvers (autotest/out_baseline.dat:188-200), which are outside this path; these functions follow the source
+# line by line instead and are the checker of the HIP kernels (rmh_product_ratio, rmh_elem_minmax_masked,
+# rmh_fct_product).
+# ---------------------------------------------------------------------------------------------------------------
+EMPTY_ZONE_TOL = 1e-12  # remhos_sync.hpp:20
+
+
+def compute_bool_indicators(u):
+    """ComputeBoolIndicators (remhos_sync.cpp:23-47).  u: [ne][ndof] -> (active_el [ne], active_dofs [ne][ndof])"""
+    dofs = u > EMPTY_ZONE_TOL
+    return dofs.any(-1), dofs
+
+
+def compute_ratio(us, u):
+    """ComputeRatio (remhos_sync.cpp:50-96) -> (s, active_el, active_dofs)"""
+    el, dofs = compute_bool_indicators(u)
+    s = np.zeros_like(u)
+    for i in range(u.shape[0]):
+        if not el[i]:
+            continue
+        total, n = 0.0, 0
+        for j in range(u.shape[1]):
+            if dofs[i, j]:
+                total += us[i, j] / u[i, j]
+                n += 1
+        s_avg = total / n
+        for j in range(u.shape[1]):
+            s[i, j] = us[i, j] / u[i, j] if dofs[i, j] else s_avg
+    return s, el, dofs
+
+
+def elem_minmax_masked(u, active_el, active_dofs):
+    """DofInfo::ComputeElementsMinMax with masks (remhos_tools.cpp:497-523)"""
+    ne = u.shape[0]
+    lo, hi = np.full(ne, INF), np.full(ne, -INF)
+    for k in range(ne):
+        if not active_el[k]:
+            continue
+        for i in range(u.shape[1]):
+            if active_dofs[k, i]:
+                lo[k] = min(lo[k], u[k, i])
+                hi[k] = max(hi[k], u[k, i])
+    return lo, hi
+
+
+def fct_product(us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt):
+    """ClipScaleSolver::CalcFCTProduct (remhos_fct.cpp:543-566): CalcCompatibleLOProduct (:26-115), ScaleProductBounds
+    (:117-153), ClipScale (:449-541), ZeroOutEmptyDofs (remhos_sync.cpp:98-116).  Returns (d_us, s_min, s_max) --
+    the bounds are updated like the reference updates them in place."""
+    eps = 1e-12
+    ne, nd = us.shape
+    s_min, s_max = s_min.copy(), s_max.copy()
+    d_us_lo = np.zeros_like(us)
+    for k in range(ne):
+        if not active_el[k]:
+            continue
+        mass_us = mass_u = 0.0
+        for j in range(nd):
+            mass_us += (us[k, j] + dt * d_us_ho[k, j]) * m[k, j]
+            mass_u += u_new[k, j] * m[k, j]
+        s_avg = mass_us / mass_u
+        smin, smax = INF, -INF
+        for j in range(nd):
+            if active_dofs[k, j]:
+                smin = min(smin, s_min[k, j])
+                smax = max(smax, s_max[k, j])
+        for j in range(nd):
+            if not active_dofs[k, j]:
+                continue
+            if s_avg < smin and mass_us + eps > smin * mass_u:
+                s_avg = smin
+            if s_avg > smax and mass_us - eps < smax * mass_u:
+                s_avg = smax
+            if s_avg + eps < s_min[k, j]:
+                s_min[k, j] = s_avg
+            if s_avg - eps > s_max[k, j]:
+                s_max[k, j] = s_avg
+        for j in range(nd):
+            d_us_lo[k, j] = (u_new[k, j] * s_avg - us[k, j]) / dt
+    on = active_el[:, None] & active_dofs
+    with np.errstate(invalid="ignore"):
+        us_min = np.where(on, s_min * u_new, 0.0)
+        us_max = np.where(on, s_max * u_new, 0.0)
+    d_us = Remhos.clip_scale(us, m, d_us_ho, d_us_lo, us_min, us_max, dt)
+    d_us = np.where(~active_el[:, None] & ~active_dofs, 0.0, d_us)  # ZeroOutEmptyDofs
+    return d_us, s_min, s_max
+

@@ -22,6 +22,7 @@ SYMBOLS = [
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
     "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
     "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce",
+    "rmh_build_tables", "rmh_product_ratio", "rmh_elem_minmax_masked", "rmh_fct_product",
 ]
 
 
@@ -123,6 +124,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_exchange_buffers.argtypes = [p, C.POINTER(p), C.POINTER(ll), C.POINTER(p), C.POINTER(ll)]
     lib.rmh_exchange_peer.argtypes = [p, i, C.POINTER(i), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll)]
     lib.rmh_allreduce.argtypes = [p, C.POINTER(d), i, i]
+    lib.rmh_build_tables.argtypes = [i, i, p, p, p]
+    lib.rmh_product_ratio.argtypes = [p, p, p, p, p, p]
+    lib.rmh_elem_minmax_masked.argtypes = [p, p, p, p, p, p]
+    lib.rmh_fct_product.argtypes = [p, p, p, p, p, p, p, p, p, d, p]
     return lib
 
 
@@ -348,6 +353,17 @@ class Context:
         arr = (C.c_double * len(vals))(*[float(v) for v in vals])
         self._check(self.lib.rmh_allreduce(self.h, arr, len(vals), {"sum": 0, "min": 1, "max": 2}[op]))
         return list(arr)
+
+    # -- product-field remap (-ps) ---------------------------------------------------------------------------------
+    def product_ratio(self, us, u, s, active_el, active_dofs):
+        self._check(self.lib.rmh_product_ratio(self.h, _ptr(us), _ptr(u), _ptr(s), _ptr(active_el), _ptr(active_dofs)))
+
+    def elem_minmax_masked(self, u, active_el, active_dofs, xe_min, xe_max):
+        self._check(self.lib.rmh_elem_minmax_masked(self.h, _ptr(u), _ptr(active_el), _ptr(active_dofs), _ptr(xe_min), _ptr(xe_max)))
+
+    def fct_product(self, us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt, d_us):
+        self._check(self.lib.rmh_fct_product(self.h, _ptr(us), _ptr(m), _ptr(d_us_ho), _ptr(s_min), _ptr(s_max), _ptr(u_new),
+                                             _ptr(active_el), _ptr(active_dofs), float(dt), _ptr(d_us)))
 
     def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
         self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))

@@ -529,6 +529,50 @@ int rmh_fct_clipscale(rmh_ctx *c, const double *u, const double *m, const double
    return timer_end(c, 3, ep);
 }
 
+int rmh_product_ratio(rmh_ctx *c, const double *us, const double *u, double *s, unsigned char *active_el,
+                      unsigned char *active_dofs)
+{
+   if (!c || !u || !active_el || !active_dofs || ((us != nullptr) != (s != nullptr))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
+   c->xe_of = nullptr;
+   RMH_DISPATCH(c, hipLaunchKernelGGL((product_ratio_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, us, u, s,
+                                      active_el, active_dofs));
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_elem_minmax_masked(rmh_ctx *c, const double *u, const unsigned char *active_el, const unsigned char *active_dofs,
+                           double *xe_min, double *xe_max)
+{
+   if (!c || !u || !active_el || !active_dofs || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_ENTER(c);
+   RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_masked_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
+                                      active_el, active_dofs, xe_min, xe_max));
+   RMH_HIP(hipGetLastError());
+   return RMH_OK;
+}
+
+int rmh_fct_product(rmh_ctx *c, const double *us, const double *m, const double *d_us_ho, double *s_min, double *s_max,
+                    const double *u_new, const unsigned char *active_el, const unsigned char *active_dofs, double dt,
+                    double *d_us)
+{
+   if (!c || !us || !m || !d_us_ho || !s_min || !s_max || !u_new || !active_el || !active_dofs || !d_us)
+   {
+      return fail(RMH_ERR_INVALID, "null argument");
+   }
+   if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
+   if (c->ng > 0) { return fail(RMH_ERR_STATE, "product remap is single-rank (the ghost extrema of s are not exchanged)"); }
+   RMH_ENTER(c);
+   c->xe_of = nullptr;
+   EventPair ep;
+   int rc = timer_begin(c, 3, ep);
+   if (rc) { return rc; }
+   RMH_DISPATCH(c, hipLaunchKernelGGL((fct_product_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, us, m, d_us_ho,
+                                      s_min, s_max, u_new, active_el, active_dofs, dt, d_us));
+   RMH_HIP(hipGetLastError());
+   return timer_end(c, 3, ep);
+}
+
 static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, const double *du_lo, double dt, double *du,
                             const double *x_base, double a, double b, double dt_rk, double *y_out)
 {

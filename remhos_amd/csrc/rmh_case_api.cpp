@@ -1,10 +1,14 @@
 // C ABI of the host-side case builder (include/rmh_driver.h, rmhd_case_*).  No GPU code.
+#include "../../include/rmh.h"
 #include "../../include/rmh_driver.h"
 #include "rmh_host.hpp"
 
 #include <cstring>
 #include <cstdio>
+#include <algorithm>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 struct rmhd_case
 {
@@ -115,6 +119,55 @@ int rmhd_case_save(const rmhd_case *c, double t, const double *u, const char *me
    const std::string err = remhos::save_mfem(c->d, t, u, mesh_path, gf_path);
    if (!err.empty()) { remhos::g_driver_error = err; return -1; }
    return 0;
+}
+
+
+// include/rmh.h: neighbour tables from the vertex ids of the elements (any element numbering)
+int rmh_build_tables(int ne_owned, int ne_total, const int *ev, int *face_nbr, int *stencil27)
+{
+   if (ne_owned <= 0 || ne_total < ne_owned || !ev || !face_nbr || !stencil27) { return RMH_ERR_INVALID; }
+   std::unordered_map<int, std::vector<int>> v2e; // vertex -> elements (owned and ghost)
+   for (int e = 0; e < ne_total; e++) { for (int k = 0; k < 8; k++) { v2e[ev[(size_t)e * 8 + k]].push_back(e); } }
+   std::fill(stencil27, stencil27 + (size_t)ne_owned * 27, -1);
+   std::vector<int> cand;
+   for (int e = 0; e < ne_owned; e++)
+   {
+      const int *ve = ev + (size_t)e * 8;
+      cand.clear();
+      for (int k = 0; k < 8; k++) { const auto &l = v2e[ve[k]]; cand.insert(cand.end(), l.begin(), l.end()); }
+      std::sort(cand.begin(), cand.end());
+      cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+      for (int o : cand)
+      {
+         if (o == e) { stencil27[(size_t)e * 27 + 13] = e; continue; }
+         const int *vo = ev + (size_t)o * 8;
+         // corners of e shared with o, and the corners of o they coincide with
+         int off[3] = {0, 0, 0}, n = 0, and_e = 7, or_e = 0, and_o = 7, or_o = 0;
+         for (int k = 0; k < 8; k++)
+         {
+            for (int j = 0; j < 8; j++)
+            {
+               if (ve[k] == vo[j]) { n++; and_e &= k; or_e |= k; and_o &= j; or_o |= j; }
+            }
+         }
+         bool ok = n == 4 || n == 2 || n == 1;
+         for (int d = 0; d < 3 && ok; d++)
+         {
+            const int be_and = (and_e >> d) & 1, be_or = (or_e >> d) & 1;
+            const int bo_and = (and_o >> d) & 1, bo_or = (or_o >> d) & 1;
+            if (be_and == 1) { off[d] = 1; ok = bo_or == 0; }         // all shared corners on e's high side: o's low side
+            else if (be_or == 0) { off[d] = -1; ok = bo_and == 1; }   // all on e's low side: o's high side
+            else { off[d] = 0; ok = bo_and == 0 && bo_or == 1; }      // spread over the direction on both elements
+         }
+         // not a face / edge / vertex contact with aligned axes: rotated neighbour, or a periodic direction with fewer
+         // than 3 elements (the same element on both sides)
+         if (!ok) { return RMH_ERR_INVALID; }
+         stencil27[(size_t)e * 27 + (off[0] + 1) + 3 * (off[1] + 1) + 9 * (off[2] + 1)] = o;
+      }
+      const int fs[6] = {12, 14, 10, 16, 4, 22};
+      for (int f = 0; f < 6; f++) { face_nbr[(size_t)e * 6 + f] = stencil27[(size_t)e * 27 + fs[f]]; }
+   }
+   return RMH_OK;
 }
 
 } // extern "C"

@@ -157,12 +157,42 @@ void ClipScaleSolver::CalcFCTSolution(const ParGridFunction &u, const Vector &m,
                               dt, du.Write()));
 }
 
+void ClipScaleSolver::CalcFCTProduct(const ParGridFunction &us, const Vector &m, const Vector &d_us_HO, const Vector &d_us_LO,
+                                     Vector &s_min, Vector &s_max, const Vector &u_new, const Array<bool> &active_el,
+                                     const Array<bool> &active_dofs, Vector &d_us)
+{
+   (void)d_us_LO; // (only solvers with NeedsLOProductInput() read it, remhos.cpp:1865-1869)
+   static_assert(sizeof(bool) == 1, "Array<bool> is handed to the kernels as a byte array");
+   RMH_CALL(rmh_fct_product(pfes.Ctx(), us.Read(), m.Read(), d_us_HO.Read(), s_min.ReadWrite(), s_max.ReadWrite(), u_new.Read(),
+                            (const unsigned char *)active_el.Read(), (const unsigned char *)active_dofs.Read(), dt, d_us.Write()));
+}
+
+// remhos_sync.cpp:23-96
+void ComputeBoolIndicators(ParFiniteElementSpace &pfes, const Vector &u, Array<bool> &ind_elem, Array<bool> &ind_dofs)
+{
+   RMH_CALL(rmh_product_ratio(pfes.Ctx(), nullptr, u.Read(), nullptr, (unsigned char *)ind_elem.Write(),
+                              (unsigned char *)ind_dofs.Write()));
+}
+void ComputeRatio(ParFiniteElementSpace &pfes, const Vector &us, const Vector &u, Vector &s, Array<bool> &bool_el,
+                  Array<bool> &bool_dof)
+{
+   RMH_CALL(rmh_product_ratio(pfes.Ctx(), us.Read(), u.Read(), s.Write(), (unsigned char *)bool_el.Write(),
+                              (unsigned char *)bool_dof.Write()));
+}
+
 DofInfo::DofInfo(ParFiniteElementSpace &space)
    : pfes(space), xe_min(space.GetNE()), xe_max(space.GetNE()), xi_min(space.GetVSize()), xi_max(space.GetVSize())
 {
 }
-void DofInfo::ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_max) const
+void DofInfo::ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_max, Array<bool> *active_el,
+                                    Array<bool> *active_dof) const
 {
+   if (active_el && active_dof)
+   {
+      RMH_CALL(rmh_elem_minmax_masked(pfes.Ctx(), u.Read(), (const unsigned char *)active_el->Read(),
+                                      (const unsigned char *)active_dof->Read(), u_min.Write(), u_max.Write()));
+      return;
+   }
    RMH_CALL(rmh_elem_minmax(pfes.Ctx(), u.Read(), u_min.Write(), u_max.Write()));
 }
 void DofInfo::ComputeBounds(const Vector &el_min, const Vector &el_max, Vector &dof_min, Vector &dof_max) const
@@ -306,11 +336,11 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       if (cfg->ho_type == 2) { ho_solver = new CGHOSolver(pfes); }
       else { ho_solver = new LocalInverseHOSolver(pfes); }
       LOSolver *lo_solver = nullptr;
-      if (cc.lo_type == 5) { lo_solver = new MassBasedAvg(pfes, *ho_solver); }
+      if (cc.lo_type == 5) { lo_solver = new MassBasedAvg(pfes, *ho_solver, nullptr); }
       else if (cc.lo_type == 3) { lo_solver = new PAResidualDistribution(pfes); }
       else { lo_solver = new PAResidualDistributionSubcell(pfes); }
       double dt = cd.dt;
-      FCTSolver *fct_solver = new ClipScaleSolver(pfes, dt);
+      FCTSolver *fct_solver = new ClipScaleSolver(pfes, nullptr, dt);
       // fused = 1: one kernel per RK stage (rmh_stage_fused with the LO solver and the mass tolerance of the options)
       const bool fused = cfg->fused != 0;
       if (fused)

@@ -1106,6 +1106,174 @@ __global__ void __launch_bounds__(KCfg<P>::NT) fct_clipscale_kernel(const double
    }
 }
 
+// ---------------------------------------------------------------------------------------
+// Product-field remap (-ps): the per-element pieces of AdvectionOperator::LimitMult's second block
+// (remhos.cpp:1848-1915).  One element per workgroup, flags are bytes (mfem::Array<bool>).
+// ---------------------------------------------------------------------------------------
+constexpr double RMH_EMPTY_ZONE_TOL = 1e-12; // remhos_sync.hpp:20
+
+// ComputeBoolIndicators (remhos_sync.cpp:23-47) and, with us != null, ComputeRatio (:50-96): s = us / u on the active
+// dofs, the mean of the active ratios elsewhere in an active element, 0 in empty elements.
+template <int P>
+__global__ void __launch_bounds__(KCfg<P>::NT) product_ratio_kernel(const double *us, const double *u, double *s,
+                                                                    unsigned char *active_el, unsigned char *active_dofs)
+{
+   using C = KCfg<P>;
+   __shared__ double s_red[4];
+   const int e = blockIdx.x;
+   double r[C::DPT];
+   bool act[C::DPT];
+   double sum = 0.0, cnt = 0.0;
+#pragma unroll
+   for (int k = 0; k < C::DPT; k++)
+   {
+      const int i = threadIdx.x + k * C::NT;
+      r[k] = 0.0; act[k] = false;
+      if (i < C::D3)
+      {
+         const size_t g = (size_t)e * C::D3 + i;
+         const double ui = u[g];
+         act[k] = ui > RMH_EMPTY_ZONE_TOL;
+         active_dofs[g] = act[k] ? 1 : 0;
+         if (us && act[k]) { r[k] = us[g] / ui; sum += r[k]; }
+         if (act[k]) { cnt += 1.0; }
+      }
+   }
+   cnt = block_sum<C::NW>(cnt, s_red);
+   if (threadIdx.x == 0) { active_el[e] = cnt > 0.0 ? 1 : 0; }
+   if (!us) { return; }
+   sum = block_sum<C::NW>(sum, s_red);
+   const double s_avg = cnt > 0.0 ? sum / cnt : 0.0;
+#pragma unroll
+   for (int k = 0; k < C::DPT; k++)
+   {
+      const int i = threadIdx.x + k * C::NT;
+      if (i < C::D3) { s[(size_t)e * C::D3 + i] = act[k] ? r[k] : s_avg; }
+   }
+}
+
+// DofInfo::ComputeElementsMinMax with the active-element / active-dof masks (remhos_tools.cpp:497-523): inactive
+// elements and dofs do not contribute; an inactive element gets (+inf, -inf), the identities of the bounds stencil.
+template <int P>
+__global__ void __launch_bounds__(KCfg<P>::NT) elem_minmax_masked_kernel(const double *u, const unsigned char *active_el,
+                                                                         const unsigned char *active_dofs, double *xe_min,
+                                                                         double *xe_max)
+{
+   using C = KCfg<P>;
+   __shared__ double s_red[4];
+   const int e = blockIdx.x;
+   double lmin = INFINITY, lmax = -INFINITY;
+   if (active_el[e])
+   {
+      for (int i = threadIdx.x; i < C::D3; i += C::NT)
+      {
+         const size_t g = (size_t)e * C::D3 + i;
+         if (active_dofs[g])
+         {
+            lmin = fmin(lmin, u[g]);
+            lmax = fmax(lmax, u[g]);
+         }
+      }
+   }
+   lmin = block_min<C::NW>(lmin, s_red);
+   lmax = block_max<C::NW>(lmax, s_red);
+   if (threadIdx.x == 0) { xe_min[e] = lmin; xe_max[e] = lmax; }
+}
+
+// ClipScaleSolver::CalcFCTProduct (remhos_fct.cpp:543-566) in one pass over the element:
+//   FCTSolver::CalcCompatibleLOProduct (remhos_fct.cpp:26-115): s_avg = mass_us / mass_u, pulled onto [smin, smax] of the
+//     active dofs when it misses them by round-off only, local bounds widened to s_avg where they exclude it (s_min / s_max
+//     are updated in place like the reference's), d_us_LO = (u_new s_avg - us) / dt;
+//   FCTSolver::ScaleProductBounds (:117-153): us_min/max = s_min/max * u_new on active dofs, 0 elsewhere;
+//   ClipScaleSolver::CalcFCTSolution (:449-541) on (us, m, d_us_HO, d_us_LO, us_min, us_max);
+//   ZeroOutEmptyDofs (remhos_sync.cpp:98-116): empty elements get d_us = 0.
+template <int P>
+__global__ void __launch_bounds__(KCfg<P>::NT) fct_product_kernel(const double *us, const double *m, const double *d_us_ho,
+                                                                  double *s_min, double *s_max, const double *u_new,
+                                                                  const unsigned char *active_el,
+                                                                  const unsigned char *active_dofs, double dt, double *d_us)
+{
+   using C = KCfg<P>;
+   __shared__ double s_red[4];
+   const int e = blockIdx.x;
+   constexpr double eps12 = 1e-12, eps = 1.0e-15;
+   const bool el_on = active_el[e] != 0;
+   double usv[C::DPT], mm[C::DPT], dho[C::DPT], un[C::DPT], lo[C::DPT], hi[C::DPT];
+   bool act[C::DPT];
+   double mass_us = 0.0, mass_u = 0.0, smin = INFINITY, smax = -INFINITY;
+#pragma unroll
+   for (int k = 0; k < C::DPT; k++)
+   {
+      const int i = threadIdx.x + k * C::NT;
+      usv[k] = 0.0; mm[k] = 1.0; dho[k] = 0.0; un[k] = 0.0; lo[k] = 0.0; hi[k] = 0.0; act[k] = false;
+      if (i < C::D3)
+      {
+         const size_t g = (size_t)e * C::D3 + i;
+         usv[k] = us[g]; mm[k] = m[g]; dho[k] = d_us_ho[g]; un[k] = u_new[g];
+         lo[k] = s_min[g]; hi[k] = s_max[g];
+         act[k] = active_dofs[g] != 0;
+         mass_us += (usv[k] + dt * dho[k]) * mm[k];
+         mass_u += un[k] * mm[k];
+         if (act[k]) { smin = fmin(smin, lo[k]); smax = fmax(smax, hi[k]); }
+      }
+   }
+   mass_us = block_sum<C::NW>(mass_us, s_red);
+   mass_u = block_sum<C::NW>(mass_u, s_red);
+   smin = block_min<C::NW>(smin, s_red);
+   smax = block_max<C::NW>(smax, s_red);
+   double s_avg = el_on ? mass_us / mass_u : 0.0;
+   // (the reference repeats these two tests for every active dof; they do not depend on the dof)
+   if (el_on && s_avg < smin && mass_us + eps12 > smin * mass_u) { s_avg = smin; }
+   if (el_on && s_avg > smax && mass_us - eps12 < smax * mass_u) { s_avg = smax; }
+   double f[C::DPT], dl[C::DPT];
+   double sumPos = 0.0, sumNeg = 0.0;
+#pragma unroll
+   for (int k = 0; k < C::DPT; k++)
+   {
+      const int i = threadIdx.x + k * C::NT;
+      f[k] = 0.0; dl[k] = 0.0;
+      if (i < C::D3)
+      {
+         const size_t g = (size_t)e * C::D3 + i;
+         double us_lo = 0.0, us_hi = 0.0;
+         if (el_on)
+         {
+            if (act[k])
+            {
+               if (s_avg + eps12 < lo[k]) { lo[k] = s_avg; s_min[g] = s_avg; }
+               if (s_avg - eps12 > hi[k]) { hi[k] = s_avg; s_max[g] = s_avg; }
+               us_lo = lo[k] * un[k];
+               us_hi = hi[k] * un[k];
+            }
+            dl[k] = (un[k] * s_avg - usv[k]) / dt;
+         }
+         const double us_new_lo = usv[k] + dt * dl[k];
+         const double f_clip_min = mm[k] / dt * (us_lo - us_new_lo);
+         const double f_clip_max = mm[k] / dt * (us_hi - us_new_lo);
+         double fc = mm[k] * (dho[k] - dl[k]);
+         fc = fmin(f_clip_max, fmax(f_clip_min, fc));
+         f[k] = fc;
+         sumNeg += fmin(fc, 0.0);
+         sumPos += fmax(fc, 0.0);
+      }
+   }
+   sumNeg = block_sum<C::NW>(sumNeg, s_red);
+   sumPos = block_sum<C::NW>(sumPos, s_red);
+   const double new_mass = sumNeg + sumPos;
+#pragma unroll
+   for (int k = 0; k < C::DPT; k++)
+   {
+      const int i = threadIdx.x + k * C::NT;
+      if (i < C::D3)
+      {
+         double fc = f[k];
+         if (new_mass > eps) { fc = fmin(0.0, fc) - fmax(0.0, fc) * sumNeg / sumPos; }
+         if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos / sumNeg; }
+         d_us[(size_t)e * C::D3 + i] = el_on ? dl[k] + fc / mm[k] : 0.0;
+      }
+   }
+}
+
 // Fused LimitMult for -lo 5 -fct 2 (remhos.cpp:1798-1845): MassBasedAvg + overlap bounds +
 // ClipScale (+ optional RK update) in one pass; du_lo, u_min, u_max are never materialised.
 struct LimitArgs
