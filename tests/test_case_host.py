@@ -133,3 +133,23 @@ def test_save_writes_mfem_mesh_and_gridfunction(lib, tmp_path, mesh, rs, p, prob
     c2 = Case(lib, make_config(mesh, max(rs, 1), p, prob, -1.0, 0.5, part=(2, 1, 1), rank=0))
     with pytest.raises(RuntimeError, match="single-rank"):
         c2.save(t, None, tmp_path / "x.mesh")
+
+
+@pytest.mark.parametrize("mesh", ["periodic-cube", "cube01_hex"])
+def test_save_matches_reference_mesh_files(lib, mesh):
+    """-save at -rs 0 against the mesh files the reference itself reads (data/periodic-cube.mesh, data/cube01_hex.mesh):
+    same corner coordinates, same vertex sharing between elements (incl. the periodic identification), same section
+    grammar and counts -- through numbering-independent canonical forms whose hashes tools/check_save_format.py derived
+    from the reference files in the build container (tests/golden/save_format.json; only hashes and counts are stored)."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_save_format as csf
+
+    want = json.load(open(os.path.join(root, "tests", "golden", "save_format.json")))[mesh]
+    got = csf.summary(mesh, csf.parse_mesh(csf.our_file(mesh)))
+    for k in ("elements", "vertices", "keywords", "geometry_sha256", "topology_sha256", "shared_vertex_pairs"):
+        assert got[k] == want[k], k
