@@ -86,33 +86,49 @@ def stored_counters(key, mass_tol, lo):
     return ent.get("hbm_bytes_per_launch"), ent.get("fp64_wave_insts_per_launch"), ent.get("source", "profiles/")
 
 
-def cpu_baseline(lib, order, budget_s=15.0):
-    """Time the CPU port (oracle/cpu_port.cpp: C++/OpenMP restatement of the reference's CPU
-    partial-assembly stage, validated against the reference's known answers) on the host cores, on a
-    bounded sample of the same workload: periodic-cube remap, same order, -rs 4 (110 592 hex) at p <= 3."""
+def cpu_baseline(lib, order, rs, budget_s=15.0):
+    """Time the CPU port (oracle/cpu_port.cpp: C++/OpenMP restatement of the reference's CPU partial-assembly stage,
+    contractions specialised on the order, validated against the reference's known answers) on the host cores, one
+    pinned thread per core, on a bounded sample of the same workload: the same mesh as the GPU when one RK step fits
+    the time budget, one refinement level less otherwise.  Reports the reference-style bucket FOMs beside the
+    wall-clock figure."""
     from oracle.cpu_port import CpuPort
     from remhos_amd.case import Case, make_config
 
-    rs = 4 if order <= 3 else (3 if order <= 4 else 2)  # enough elements per host thread, bounded run time
-    case = Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5))
-    cp = CpuPort(order, case.exec_mode, case.x0, case.vel, case.face_nbr, case.stencil27, case.u0)
-    cp.step(case.dt)  # warm-up (first touch, thread pool start)
-    stages, t0 = 0, time.perf_counter()
-    while stages == 0 or (time.perf_counter() - t0 < budget_s and stages < 30):
-        cp.step(case.dt)
-        stages += 3
-    el = time.perf_counter() - t0
+    def run(rs_cpu, max_stages):
+        case = Case(lib, make_config("periodic-cube", rs_cpu, order, 10, -1.0, 0.5))
+        cp = CpuPort(order, case.exec_mode, case.x0, case.vel, case.face_nbr, case.stencil27, case.u0)
+        t0 = time.perf_counter()
+        cp.step(case.dt)  # warm-up (first touch, thread pool start)
+        warm = time.perf_counter() - t0
+        cp.buckets(reset=True)
+        stages, t0 = 0, time.perf_counter()
+        while stages == 0 or (time.perf_counter() - t0 + warm < budget_s and stages < max_stages):
+            cp.step(case.dt)
+            stages += 3
+        return case, cp, stages, time.perf_counter() - t0, warm
+
+    rs_cpu = min(rs, 4 if order <= 3 else (3 if order <= 4 else 2))  # a size that certainly fits the budget ...
+    case, cp, stages, el, warm = run(rs_cpu, 30)
+    rate = case.u0.size * stages / el
+    if rs_cpu < rs and 8.0 * case.u0.size * 6 / rate < budget_s:  # (8 x the dofs; warm-up step + one timed step = 6 stages)
+        case, cp, stages, el, warm = run(rs_cpu + 1, 6)  # ... and the GPU's own mesh when a warm-up + one step of it fit too
+        rs_cpu += 1
     ndofs = case.u0.size
-    out = {
+    tb = cp.buckets()
+    fom = lambda t: 1e-6 * ndofs * stages / t if t > 0 else None
+    return {
         "value": 1e-6 * ndofs * stages / el,
         "unit": "MDOFs*RK-stage/s",
         "cores": cp.threads,
         "kind": "port",
-        "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads): periodic-cube -rs {rs} -o {order} -p 10 "
-                  f"-lo 5 -fct 2, {ndofs} dofs, {stages} RK stages in {el:.2f} s",
+        "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} "
+                  f"OMP_PLACES={os.environ.get('OMP_PLACES')}): periodic-cube -rs {rs_cpu} -o {order} -p 10 -lo 5 -fct 2, "
+                  f"{ndofs} dofs, {stages} RK stages in {el:.2f} s",
+        "buckets_s": {"rhs": tb[0], "inv": tb[1], "lo": tb[2], "fct": tb[3]},
+        "fom_reference_style": {"rhs": fom(tb[0]), "inv": fom(tb[1]), "lo": fom(tb[2]), "fct": fom(tb[3]),
+                                "total_rhs_lo_fct": fom(tb[0] + tb[2] + tb[3])},
     }
-    out.update(cp.extra_report() if hasattr(cp, "extra_report") else {})
-    return out
 
 
 def self_launch(args):
@@ -351,7 +367,7 @@ def main():
         if p6 is not None:
             out["p6"] = {"metric": out["metric"], "unit": out["unit"], "steps": args.steps, "warmup": args.warmup, **p6}
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lib, args.order)
+            out["cpu_baseline"] = cpu_baseline(lib, args.order, args.rs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,14 +1,15 @@
 // CPU port of the Remhos RK stage (HO -> mass-based LO -> overlap bounds -> ClipScale) --
 // TEST INFRASTRUCTURE ONLY: the host-core baseline that bench.py times beside the GPU
 // (cpu_baseline.kind = "port") and a fast checker for meshes too large for the numpy oracle.
-// Never linked into or called by the product (remhos_amd/).
+// Never linked into or called by the product (remhos_amd/), and it shares no source with it: the 1-D tables are
+// generated here (Tables<P>), independently of remhos_amd/csrc/rmh_tables.hpp.
 //
-// Parity status: pinned through tests/test_cpu_port.py -- the port is compared with
+// Parity status: pinned through tests/test_cpu_port.py and tests/test_golden.py -- the port is compared with
 // oracle/remhos_oracle.py (itself pinned by the reference's known answers) and reproduces the
 // reference's ctest #3 / #7 final masses (remhos_tests.cpp:63-68, 81-86).
 //
-// Restated from the reference (same algorithm as its CPU partial-assembly path; sum-factorised
-// like MFEM's PA kernels, OpenMP over elements):
+// Restated from the reference (same algorithm as its CPU partial-assembly path: sum-factorised like MFEM's PA kernels,
+// every contraction specialised on (p + 1, p + 3) at compile time, OpenMP over elements):
 //   HO   : K_vol (ConvectionIntegrator PA apply, remhos.cpp:646-657; qdata remhos_lo.cpp:1155-1190,
 //          apply remhos_lo.cpp:1473-1612) + upwind DG trace (remhos.cpp:659-678) + element-local
 //          Jacobi-PCG mass solve in the Gauss-Legendre basis (DGMassInverse, remhos_ho.cpp:79-80,126)
@@ -16,10 +17,8 @@
 //   bounds: ComputeElementsMinMax + ComputeOverlapBounds (remhos_tools.cpp:432-523)
 //   FCT  : ClipScaleSolver (remhos_fct.cpp:449-541)
 //   RK3-SSP step and the remap re-setup per stage (remhos.cpp:1598-1637).
-// 1-D tables come from remhos_amd/csrc/rmh_tables.hpp (pure host math, shared on purpose: the
-// tables themselves are pinned by every parity test).
-#include "../remhos_amd/csrc/rmh_tables.hpp"
-
+// Stopwatch buckets like TimingData (remhos_tools.hpp:52-64): RHS = geometry + K u (the reference charges the remap
+// re-assembly of K to it, remhos.cpp:1634-1637), INV = mass-solve set-up + PCG (:1620-1623), LO, FCT (incl. bounds).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -31,152 +30,211 @@
 namespace
 {
 
-struct Tab
+// ---- 1-D tables ---------------------------------------------------------------------------------------------------
+// Gauss-Legendre points / weights on [0, 1]: roots of the Legendre polynomial by bisection on the interlacing
+// intervals of the previous degree, polished by Newton
+void gauss_legendre(int n, double *x, double *w)
 {
-   int P, D, Q;
-   std::vector<double> t;
-   int oB, oG, oL, odL, oW, oBg, oCi;
-};
+   auto legendre = [](int m, double z, double &dp)
+   {
+      double p0 = 1.0, p1 = z;
+      if (m == 0) { dp = 0.0; return 1.0; }
+      for (int k = 2; k <= m; k++)
+      {
+         const double pk = ((2 * k - 1) * z * p1 - (k - 1) * p0) / k;
+         p0 = p1;
+         p1 = pk;
+      }
+      dp = m * (z * p1 - p0) / (z * z - 1.0);
+      return p1;
+   };
+   std::vector<double> prev, cur;
+   for (int m = 1; m <= n; m++)
+   {
+      cur.assign(m, 0.0);
+      for (int i = 0; i < m; i++)
+      {
+         double a = i == 0 ? -1.0 : prev[i - 1], b = i == m - 1 ? 1.0 : prev[i], dp;
+         const double fa = legendre(m, a, dp);
+         for (int it = 0; it < 200; it++)
+         {
+            const double mid = 0.5 * (a + b);
+            if ((legendre(m, mid, dp) > 0) == (fa > 0)) { a = mid; } else { b = mid; }
+         }
+         double z = 0.5 * (a + b);
+         for (int it = 0; it < 3; it++) { const double f = legendre(m, z, dp); z -= f / dp; }
+         cur[i] = z;
+      }
+      prev = cur;
+   }
+   for (int i = 0; i < n; i++)
+   {
+      double dp;
+      legendre(n, cur[i], dp);
+      x[i] = 0.5 * (1.0 + cur[i]);
+      w[i] = 1.0 / ((1.0 - cur[i] * cur[i]) * dp * dp); // (2 / ((1-z^2) P'^2)) / 2 for [0, 1]
+   }
+}
 
 template <int P>
-Tab make_tab()
+struct Tables
 {
-   using T = rmh::TabLayout<P>;
-   Tab b;
-   b.P = P; b.D = T::D; b.Q = T::Q;
-   b.t = rmh::make_tables<P>();
-   b.oB = T::oB; b.oG = T::oG; b.oL = T::oL; b.odL = T::odL; b.oW = T::oW; b.oBg = T::oBg; b.oCi = T::oCi;
-   return b;
-}
+   static constexpr int D = P + 1, Q = P + 3; // Q: rule of order 2p + 2*3 - 1
+   double W[Q];
+   double B[Q * D], G[Q * D];     // Bernstein values / derivatives at the quadrature points, [q][i]
+   double Bt[D * Q], Gt[D * Q];   // transposed, [i][q]
+   double L[Q * 3], dL[Q * 3];    // quadratic Lagrange basis on {0, 1/2, 1} (mesh nodes), [q][a]
+   double Bg[Q * D], Bgt[D * Q];  // Gauss-Legendre nodal basis (D nodes) at the quadrature points
+   double Bg2t[D * Q];            // its square, transposed (Jacobi diagonal)
+   double Ci[D * D], Cit[D * D];  // x_b = Ci x_g: inverse of V[k][i] = Bernstein_i(GL node k)
 
-Tab get_tab(int p)
-{
-   switch (p)
+   Tables()
    {
-      case 1: return make_tab<1>();
-      case 2: return make_tab<2>();
-      case 3: return make_tab<3>();
-      case 4: return make_tab<4>();
-      case 5: return make_tab<5>();
-      default: return make_tab<6>();
-   }
-}
-
-// out[.., q, ..] = sum_i M[q*ni + i] in[.., i, ..] along direction dir of an (n0,n1,n2) tensor (x fastest)
-void contract(const double *M, int nq, int ni, int dir, const int n[3], const double *in, double *out)
-{
-   int no[3] = {n[0], n[1], n[2]};
-   no[dir] = nq;
-   const int si = (dir == 0) ? 1 : (dir == 1 ? n[0] : n[0] * n[1]);
-   const int so = (dir == 0) ? 1 : (dir == 1 ? no[0] : no[0] * no[1]);
-   for (int k2 = 0; k2 < no[2]; k2++)
-   {
-      for (int k1 = 0; k1 < no[1]; k1++)
+      double xq[Q], xg[D], wg[D];
+      gauss_legendre(Q, xq, W);
+      gauss_legendre(D, xg, wg);
+      auto binom = [](int n, int k) { double r = 1.0; for (int i = 1; i <= k; i++) { r = r * (n - k + i) / i; } return r; };
+      auto bern = [&](int p, int i, double t) { return (i < 0 || i > p) ? 0.0 : binom(p, i) * std::pow(t, i) * std::pow(1.0 - t, p - i); };
+      for (int q = 0; q < Q; q++)
       {
-         for (int k0 = 0; k0 < no[0]; k0++)
+         const double t = xq[q];
+         for (int i = 0; i < D; i++)
          {
-            const int k[3] = {k0, k1, k2};
-            int ib = 0, st = 1;
-            for (int d = 0; d < 3; d++)
-            {
-               if (d != dir) { ib += k[d] * st; }
-               st *= n[d];
-            }
-            double acc = 0.0;
-            for (int i = 0; i < ni; i++) { acc += M[k[dir] * ni + i] * in[ib + i * si]; }
-            out[k0 + no[0] * (k1 + no[1] * k2)] = acc;
-            (void)so;
+            B[q * D + i] = bern(P, i, t);
+            G[q * D + i] = P * (bern(P - 1, i - 1, t) - bern(P - 1, i, t));
+            Bt[i * Q + q] = B[q * D + i];
+            Gt[i * Q + q] = G[q * D + i];
+            double l = 1.0;
+            for (int k = 0; k < D; k++) { if (k != i) { l *= (t - xg[k]) / (xg[i] - xg[k]); } }
+            Bg[q * D + i] = l;
+            Bgt[i * Q + q] = l;
+            Bg2t[i * Q + q] = l * l;
+         }
+         L[q * 3 + 0] = 2.0 * (t - 0.5) * (t - 1.0);
+         L[q * 3 + 1] = -4.0 * t * (t - 1.0);
+         L[q * 3 + 2] = 2.0 * t * (t - 0.5);
+         dL[q * 3 + 0] = 4.0 * t - 3.0;
+         dL[q * 3 + 1] = -8.0 * t + 4.0;
+         dL[q * 3 + 2] = 4.0 * t - 1.0;
+      }
+      // Ci = V^-1 by Gauss-Jordan with partial pivoting
+      double A[D][2 * D];
+      for (int k = 0; k < D; k++)
+      {
+         for (int i = 0; i < D; i++) { A[k][i] = bern(P, i, xg[k]); A[k][D + i] = k == i ? 1.0 : 0.0; }
+      }
+      for (int c = 0; c < D; c++)
+      {
+         int piv = c;
+         for (int r = c + 1; r < D; r++) { if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) { piv = r; } }
+         for (int j = 0; j < 2 * D; j++) { std::swap(A[c][j], A[piv][j]); }
+         const double inv = 1.0 / A[c][c];
+         for (int j = 0; j < 2 * D; j++) { A[c][j] *= inv; }
+         for (int r = 0; r < D; r++)
+         {
+            if (r == c) { continue; }
+            const double f = A[r][c];
+            for (int j = 0; j < 2 * D; j++) { A[r][j] -= f * A[c][j]; }
          }
       }
+      for (int i = 0; i < D; i++) { for (int k = 0; k < D; k++) { Ci[i * D + k] = A[i][D + k]; Cit[k * D + i] = A[i][D + k]; } }
    }
-}
-
-// transpose version: out[.., i, ..] = sum_q M[q*ni + i] in[.., q, ..]
-void contract_t(const double *M, int nq, int ni, int dir, const int n[3], const double *in, double *out)
-{
-   int no[3] = {n[0], n[1], n[2]};
-   no[dir] = ni;
-   const int si = (dir == 0) ? 1 : (dir == 1 ? n[0] : n[0] * n[1]);
-   for (int k2 = 0; k2 < no[2]; k2++)
-   {
-      for (int k1 = 0; k1 < no[1]; k1++)
-      {
-         for (int k0 = 0; k0 < no[0]; k0++)
-         {
-            const int k[3] = {k0, k1, k2};
-            int ib = 0, st = 1;
-            for (int d = 0; d < 3; d++)
-            {
-               if (d != dir) { ib += k[d] * st; }
-               st *= n[d];
-            }
-            double acc = 0.0;
-            for (int q = 0; q < nq; q++) { acc += M[q * ni + k[dir]] * in[ib + q * si]; }
-            out[k0 + no[0] * (k1 + no[1] * k2)] = acc;
-         }
-      }
-   }
-}
-
-struct Work
-{
-   std::vector<double> a, b, c, X, V, J, g, wd, Dq;
 };
 
-// tensor apply of three 1-D matrices (values or derivative per direction), D^3 / 3^3 -> Q^3
-void interp3(const double *Mx, const double *My, const double *Mz, int nq, int ni, const double *in, double *out,
-             Work &w)
+// ---- contractions, all extents known at compile time ------------------------------------------------------------
+// out[(k2*N1 + k1)*NQ + q] = sum_i M[q*NI + i] in[(k2*N1 + k1)*NI + i]
+template <int NQ, int NI, int N12>
+inline void cx(const double *M, const double *in, double *out)
 {
-   const int n0[3] = {ni, ni, ni};
-   const int n1[3] = {nq, ni, ni};
-   const int n2[3] = {nq, nq, ni};
-   w.a.resize((size_t)nq * ni * ni);
-   w.b.resize((size_t)nq * nq * ni);
-   contract(Mx, nq, ni, 0, n0, in, w.a.data());
-   contract(My, nq, ni, 1, n1, w.a.data(), w.b.data());
-   contract(Mz, nq, ni, 2, n2, w.b.data(), out);
+   for (int k = 0; k < N12; k++)
+   {
+      for (int q = 0; q < NQ; q++)
+      {
+         double acc = 0.0;
+         for (int i = 0; i < NI; i++) { acc += M[q * NI + i] * in[k * NI + i]; }
+         out[k * NQ + q] = acc;
+      }
+   }
+}
+// out[(k2*NQ + q)*N0 + k0] = sum_i M[q*NI + i] in[(k2*NI + i)*N0 + k0]
+template <int NQ, int NI, int N0, int N2>
+inline void cy(const double *M, const double *in, double *out)
+{
+   for (int k2 = 0; k2 < N2; k2++)
+   {
+      for (int q = 0; q < NQ; q++)
+      {
+         double acc[N0];
+         for (int k0 = 0; k0 < N0; k0++) { acc[k0] = 0.0; }
+         for (int i = 0; i < NI; i++)
+         {
+            const double m = M[q * NI + i];
+            for (int k0 = 0; k0 < N0; k0++) { acc[k0] += m * in[(k2 * NI + i) * N0 + k0]; }
+         }
+         for (int k0 = 0; k0 < N0; k0++) { out[(k2 * NQ + q) * N0 + k0] = acc[k0]; }
+      }
+   }
+}
+// out[q*N01 + k] = sum_i M[q*NI + i] in[i*N01 + k]
+template <int NQ, int NI, int N01>
+inline void cz(const double *M, const double *in, double *out)
+{
+   for (int q = 0; q < NQ; q++)
+   {
+      for (int k = 0; k < N01; k++) { out[q * N01 + k] = 0.0; }
+      for (int i = 0; i < NI; i++)
+      {
+         const double m = M[q * NI + i];
+         for (int k = 0; k < N01; k++) { out[q * N01 + k] += m * in[i * N01 + k]; }
+      }
+   }
+}
+// NI^3 -> NQ^3 with one matrix per direction ([q][i] layout); and the transposed use NQ^3 -> NI^3 with [i][q] matrices
+template <int NQ, int NI>
+inline void interp3(const double *Mx, const double *My, const double *Mz, const double *in, double *out, double *wa, double *wb)
+{
+   cx<NQ, NI, NI * NI>(Mx, in, wa);        // [NI][NI][NQ]
+   cy<NQ, NI, NQ, NI>(My, wa, wb);         // [NI][NQ][NQ]
+   cz<NQ, NI, NQ * NQ>(Mz, wb, out);       // [NQ][NQ][NQ]
+}
+template <int NI, int NQ>
+inline void test3(const double *Mxt, const double *Myt, const double *Mzt, const double *in, double *out, double *wa, double *wb)
+{
+   cz<NI, NQ, NQ * NQ>(Mzt, in, wa);       // [NI][NQ][NQ]
+   cy<NI, NQ, NQ, NI>(Myt, wa, wb);        // [NI][NI][NQ]
+   cx<NI, NQ, NI * NI>(Mxt, wb, out);      // [NI][NI][NI]
 }
 
-void test3(const double *Mx, const double *My, const double *Mz, int nq, int ni, const double *in, double *out,
-           Work &w)
+double g_bucket[4] = {0, 0, 0, 0}; // RHS, INV, LO, FCT: max over threads, accumulated over calls
+
+inline double now()
 {
-   const int n0[3] = {nq, nq, nq};
-   const int n1[3] = {nq, nq, ni};
-   const int n2[3] = {nq, ni, ni};
-   w.a.resize((size_t)nq * nq * ni);
-   w.b.resize((size_t)nq * ni * ni);
-   contract_t(Mz, nq, ni, 2, n0, in, w.a.data());
-   contract_t(My, nq, ni, 1, n1, w.a.data(), w.b.data());
-   contract_t(Mx, nq, ni, 0, n2, w.b.data(), out);
+#ifdef _OPENMP
+   return omp_get_wtime();
+#else
+   return 0.0;
+#endif
 }
 
-} // namespace
-
-extern "C" {
-
-// One stage: du = F(u, t) with dt the full step (LO/FCT).  Arrays as in include/rmh.h (host memory).
-// ws_m receives the lumped mass.  Returns the max PCG iteration count.
-int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr,
-              const int *stencil27, double t, double dt, const double *u, double *du, double *ws_m,
-              double *ws_duho, double *ws_xe /* [2*ne] */, double rel_tol)
+template <int P>
+int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr, const int *stencil27, double t,
+            double dt, const double *u, double *du, double *ws_m, double *ws_duho, double *ws_xe, double rel_tol)
 {
-   const Tab T = get_tab(p);
-   const int D = T.D, Q = T.Q, D2 = D * D, D3 = D2 * D, Q2 = Q * Q, Q3 = Q2 * Q;
-   const double *B = &T.t[T.oB], *G = &T.t[T.oG], *L = &T.t[T.oL], *dL = &T.t[T.odL], *W = &T.t[T.oW];
-   const double *Bg = &T.t[T.oBg], *Ci = &T.t[T.oCi];
+   static const Tables<P> T;
+   constexpr int D = P + 1, Q = P + 3, D2 = D * D, D3 = D2 * D, Q2 = Q * Q, Q3 = Q2 * Q;
    const double alpha = exec_mode == 1 ? 1.0 : -1.0, upw = exec_mode == 1 ? 1.0 : -1.0;
    int itmax = 0;
+   double b_rhs = 0.0, b_inv = 0.0, b_lo = 0.0, b_fct = 0.0;
 
-#pragma omp parallel reduction(max : itmax)
+#pragma omp parallel reduction(max : itmax, b_rhs, b_inv)
    {
-   // per-thread scratch (allocated once per thread, not per element)
-   Work w;
-   std::vector<double> X(81), V(81), Jc(9 * Q3), vq(3 * Q3), tmp(Q3), Dq(3 * Q3), wd(Q3), g(Q3), gr(3 * Q3);
-   std::vector<double> rhs(D3), rg(D3), xg(D3), dd(D3), Ad(D3), dg(D3), zz(D3), t1(D3), t2(D3), val(Q2), Bg2(Q * D);
-   for (int i = 0; i < Q * D; i++) { Bg2[i] = Bg[i] * Bg[i]; }
+   alignas(64) double X[81], V[81], Jc[9 * Q3], vq[3 * Q3], tmp[Q3], Dq[3 * Q3], wd[Q3], g[Q3], gr[3 * Q3], wa[Q3], wb[Q3];
+   alignas(64) double rhs[D3], rg[D3], xg[D3], dd[D3], Ad[D3], dg[D3], t1[D3], t2[D3], val[Q2], row[Q * D];
+   double my_rhs = 0.0, my_inv = 0.0;
 #pragma omp for schedule(static)
    for (int e = 0; e < ne; e++)
    {
+      const double c0 = now();
       const double *ue = u + (size_t)e * D3;
       for (int i = 0; i < 81; i++)
       {
@@ -186,44 +244,63 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
       // geometry at the quadrature points (remap: moved mesh, remhos.cpp:1598-1608)
       for (int c = 0; c < 3; c++)
       {
-         interp3(dL, L, L, Q, 3, &X[c * 27], &Jc[(c * 3 + 0) * Q3], w);
-         interp3(L, dL, L, Q, 3, &X[c * 27], &Jc[(c * 3 + 1) * Q3], w);
-         interp3(L, L, dL, Q, 3, &X[c * 27], &Jc[(c * 3 + 2) * Q3], w);
-         interp3(L, L, L, Q, 3, &V[c * 27], &vq[c * Q3], w);
+         interp3<Q, 3>(T.dL, T.L, T.L, &X[c * 27], &Jc[(c * 3 + 0) * Q3], wa, wb);
+         interp3<Q, 3>(T.L, T.dL, T.L, &X[c * 27], &Jc[(c * 3 + 1) * Q3], wa, wb);
+         interp3<Q, 3>(T.L, T.L, T.dL, &X[c * 27], &Jc[(c * 3 + 2) * Q3], wa, wb);
+         interp3<Q, 3>(T.L, T.L, T.L, &V[c * 27], &vq[c * Q3], wa, wb);
       }
-      for (int q = 0; q < Q3; q++)
+      for (int qz = 0; qz < Q; qz++)
       {
-         const int qx = q % Q, qy = (q / Q) % Q, qz = q / Q2;
-         double J[3][3];
-         for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) { J[a][b] = Jc[(a * 3 + b) * Q3 + q]; } }
-         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1], A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
-         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2], A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
-         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0], A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
-         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1], A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
-         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-         const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
-         const double w3 = W[qx] * W[qy] * W[qz];
-         const double v0 = vq[q], v1 = vq[Q3 + q], v2 = vq[2 * Q3 + q];
-         Dq[q] = alpha * w3 * (A11 * v0 + A12 * v1 + A13 * v2);
-         Dq[Q3 + q] = alpha * w3 * (A21 * v0 + A22 * v1 + A23 * v2);
-         Dq[2 * Q3 + q] = alpha * w3 * (A31 * v0 + A32 * v1 + A33 * v2);
-         wd[q] = w3 * detJ;
+         for (int qy = 0; qy < Q; qy++)
+         {
+            const double wyz = T.W[qy] * T.W[qz];
+            for (int qx = 0; qx < Q; qx++)
+            {
+               const int q = qx + Q * (qy + Q * qz);
+               const double J00 = Jc[0 * Q3 + q], J01 = Jc[1 * Q3 + q], J02 = Jc[2 * Q3 + q];
+               const double J10 = Jc[3 * Q3 + q], J11 = Jc[4 * Q3 + q], J12 = Jc[5 * Q3 + q];
+               const double J20 = Jc[6 * Q3 + q], J21 = Jc[7 * Q3 + q], J22 = Jc[8 * Q3 + q];
+               const double A11 = J11 * J22 - J12 * J21, A12 = J21 * J02 - J01 * J22, A13 = J01 * J12 - J11 * J02;
+               const double A21 = J20 * J12 - J10 * J22, A22 = J00 * J22 - J02 * J20, A23 = J10 * J02 - J00 * J12;
+               const double A31 = J10 * J21 - J20 * J11, A32 = J20 * J01 - J00 * J21, A33 = J00 * J11 - J01 * J10;
+               const double detJ = J00 * A11 + J01 * A21 + J02 * A31;
+               const double w3 = T.W[qx] * wyz;
+               const double v0 = vq[q], v1 = vq[Q3 + q], v2 = vq[2 * Q3 + q];
+               Dq[q] = alpha * w3 * (A11 * v0 + A12 * v1 + A13 * v2);
+               Dq[Q3 + q] = alpha * w3 * (A21 * v0 + A22 * v1 + A23 * v2);
+               Dq[2 * Q3 + q] = alpha * w3 * (A31 * v0 + A32 * v1 + A33 * v2);
+               wd[q] = w3 * detJ;
+            }
+         }
       }
       // K_vol u
-      interp3(G, B, B, Q, D, ue, &gr[0], w);
-      interp3(B, G, B, Q, D, ue, &gr[Q3], w);
-      interp3(B, B, G, Q, D, ue, &gr[2 * Q3], w);
+      interp3<Q, D>(T.G, T.B, T.B, ue, &gr[0], wa, wb);
+      interp3<Q, D>(T.B, T.G, T.B, ue, &gr[Q3], wa, wb);
+      interp3<Q, D>(T.B, T.B, T.G, ue, &gr[2 * Q3], wa, wb);
       for (int q = 0; q < Q3; q++) { g[q] = Dq[q] * gr[q] + Dq[Q3 + q] * gr[Q3 + q] + Dq[2 * Q3 + q] * gr[2 * Q3 + q]; }
-      test3(B, B, B, Q, D, g.data(), rhs.data(), w);
-      // lumped mass M 1
-      test3(B, B, B, Q, D, wd.data(), &ws_m[(size_t)e * D3], w);
-      // faces (own outward normal)
+      test3<D, Q>(T.Bt, T.Bt, T.Bt, g, rhs, wa, wb);
+      // faces (own outward normal), sum-factorised per face
       for (int f = 0; f < 6; f++)
       {
          const int c = f >> 1, side = f & 1, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
          const int pw3[3] = {1, 3, 9}, pwD[3] = {1, D, D2};
          const int nb = face_nbr[(size_t)e * 6 + f];
          const double *un = nb >= 0 ? u + (size_t)nb * D3 : nullptr;
+         // jump of the traces, contracted along i1: row[q1][i2]
+         for (int q1 = 0; q1 < Q; q1++)
+         {
+            for (int i2 = 0; i2 < D; i2++)
+            {
+               double acc = 0.0;
+               for (int i1 = 0; i1 < D; i1++)
+               {
+                  const double own = ue[(side ? (D - 1) : 0) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]];
+                  const double nbv = un ? un[(side ? 0 : (D - 1)) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]] : 0.0;
+                  acc += T.B[q1 * D + i1] * (nbv - own);
+               }
+               row[q1 * D + i2] = acc;
+            }
+         }
          for (int q2 = 0; q2 < Q; q2++)
          {
             for (int q1 = 0; q1 < Q; q1++)
@@ -234,8 +311,8 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
                   for (int a1 = 0; a1 < 3; a1++)
                   {
                      const int n = (side ? 2 : 0) * pw3[c] + a1 * pw3[c1] + a2 * pw3[c2];
-                     const double w1 = dL[q1 * 3 + a1] * L[q2 * 3 + a2], w2 = L[q1 * 3 + a1] * dL[q2 * 3 + a2];
-                     const double w0 = L[q1 * 3 + a1] * L[q2 * 3 + a2];
+                     const double w1 = T.dL[q1 * 3 + a1] * T.L[q2 * 3 + a2], w2 = T.L[q1 * 3 + a1] * T.dL[q2 * 3 + a2];
+                     const double w0 = T.L[q1 * 3 + a1] * T.L[q2 * 3 + a2];
                      for (int k = 0; k < 3; k++)
                      {
                         t1v[k] += w1 * X[k * 27 + n];
@@ -248,18 +325,20 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
                const double nz = t1v[0] * t2v[1] - t1v[1] * t2v[0];
                double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
                if (!side) { vn = -vn; }
-               const double s = std::fmax(0.0, upw * vn) * W[q1] * W[q2];
+               const double s = std::fmax(0.0, upw * vn) * T.W[q1] * T.W[q2];
                double jump = 0.0;
-               for (int i2 = 0; i2 < D; i2++)
-               {
-                  for (int i1 = 0; i1 < D; i1++)
-                  {
-                     const double own = ue[(side ? (D - 1) : 0) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]];
-                     const double nbv = un ? un[(side ? 0 : (D - 1)) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]] : 0.0;
-                     jump += B[q1 * D + i1] * B[q2 * D + i2] * (nbv - own);
-                  }
-               }
+               for (int i2 = 0; i2 < D; i2++) { jump += T.B[q2 * D + i2] * row[q1 * D + i2]; }
                val[q1 + Q * q2] = s * jump;
+            }
+         }
+         // test with the face's Bernstein functions: along q1 first
+         for (int q2 = 0; q2 < Q; q2++)
+         {
+            for (int i1 = 0; i1 < D; i1++)
+            {
+               double acc = 0.0;
+               for (int q1 = 0; q1 < Q; q1++) { acc += T.B[q1 * D + i1] * val[q1 + Q * q2]; }
+               row[q2 * D + i1] = acc;
             }
          }
          for (int i2 = 0; i2 < D; i2++)
@@ -267,20 +346,20 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
             for (int i1 = 0; i1 < D; i1++)
             {
                double acc = 0.0;
-               for (int q2 = 0; q2 < Q; q2++)
-               {
-                  for (int q1 = 0; q1 < Q; q1++) { acc += B[q1 * D + i1] * B[q2 * D + i2] * val[q1 + Q * q2]; }
-               }
+               for (int q2 = 0; q2 < Q; q2++) { acc += T.B[q2 * D + i2] * row[q2 * D + i1]; }
                rhs[(side ? (D - 1) : 0) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]] += acc;
             }
          }
       }
-      // local mass solve: Jacobi-PCG in the GL nodal basis
-      const int nD[3] = {D, D, D};
-      contract_t(Ci, D, D, 0, nD, rhs.data(), t1.data()); // b_g = Ci^T (x)3 b : out[k] = sum_i Ci[i*D+k] in[i]
-      contract_t(Ci, D, D, 1, nD, t1.data(), t2.data());
-      contract_t(Ci, D, D, 2, nD, t2.data(), rg.data());
-      test3(Bg2.data(), Bg2.data(), Bg2.data(), Q, D, wd.data(), dg.data(), w);
+      const double c1 = now();
+      my_rhs += c1 - c0;
+      // lumped mass M 1 (remhos.cpp:1632) and the local mass solve: Jacobi-PCG in the GL nodal basis
+      test3<D, Q>(T.Bt, T.Bt, T.Bt, wd, &ws_m[(size_t)e * D3], wa, wb);
+      // b_g = Ci^T (x)3 b : out[k] = sum_i Ci[i*D+k] in[i]
+      cx<D, D, D2>(T.Cit, rhs, t1);
+      cy<D, D, D, D>(T.Cit, t1, t2);
+      cz<D, D, D2>(T.Cit, t2, rg);
+      test3<D, Q>(T.Bg2t, T.Bg2t, T.Bg2t, wd, dg, wa, wb);
       double nom = 0.0;
       for (int i = 0; i < D3; i++)
       {
@@ -292,9 +371,9 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
       int it = 0;
       while (nom > tol && it < 100)
       {
-         interp3(Bg, Bg, Bg, Q, D, dd.data(), tmp.data(), w);
+         interp3<Q, D>(T.Bg, T.Bg, T.Bg, dd, tmp, wa, wb);
          for (int q = 0; q < Q3; q++) { tmp[q] *= wd[q]; }
-         test3(Bg, Bg, Bg, Q, D, tmp.data(), Ad.data(), w);
+         test3<D, Q>(T.Bgt, T.Bgt, T.Bgt, tmp, Ad, wa, wb);
          double den = 0.0;
          for (int i = 0; i < D3; i++) { den += dd[i] * Ad[i]; }
          if (!(den > 0.0)) { break; }
@@ -312,9 +391,10 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
          it++;
       }
       itmax = std::max(itmax, it);
-      contract(Ci, D, D, 0, nD, xg.data(), t1.data()); // x_b = Ci (x)3 x_g : out[i] = sum_k Ci[i*D+k] in[k]
-      contract(Ci, D, D, 1, nD, t1.data(), t2.data());
-      contract(Ci, D, D, 2, nD, t2.data(), &ws_duho[(size_t)e * D3]);
+      // x_b = Ci (x)3 x_g : out[i] = sum_k Ci[i*D+k] in[k]
+      cx<D, D, D2>(T.Ci, xg, t1);
+      cy<D, D, D, D>(T.Ci, t1, t2);
+      cz<D, D, D2>(T.Ci, t2, &ws_duho[(size_t)e * D3]);
       double lo = INFINITY, hi = -INFINITY;
       for (int i = 0; i < D3; i++)
       {
@@ -323,16 +403,21 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
       }
       ws_xe[e] = lo;
       ws_xe[ne + e] = hi;
+      my_inv += now() - c1;
    }
+   b_rhs = my_rhs;
+   b_inv = my_inv;
    } // omp parallel
 
    // LimitMult: MassBasedAvg + overlap bounds + ClipScale
-#pragma omp parallel
+#pragma omp parallel reduction(max : b_lo, b_fct)
    {
-   std::vector<double> fc(D3), dl(D3);
+   double fc[D3], dl[D3];
+   double my_lo = 0.0, my_fct = 0.0;
 #pragma omp for schedule(static)
    for (int e = 0; e < ne; e++)
    {
+      const double c0 = now();
       const double *ue = u + (size_t)e * D3, *m = ws_m + (size_t)e * D3, *dh = ws_duho + (size_t)e * D3;
       double mass = 0.0, vol = 0.0;
       for (int i = 0; i < D3; i++)
@@ -341,6 +426,9 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
          vol += m[i];
       }
       const double ubar = mass / vol;
+      for (int i = 0; i < D3; i++) { dl[i] = (ubar - ue[i]) / dt; }
+      const double c1 = now();
+      my_lo += c1 - c0;
       double smin[27], smax[27];
       for (int s = 0; s < 27; s++)
       {
@@ -366,7 +454,6 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
                }
             }
          }
-         dl[i] = (ubar - ue[i]) / dt;
          const double u_new_lo = ue[i] + dt * dl[i];
          const double f_clip_min = m[i] / dt * (umin - u_new_lo);
          const double f_clip_max = m[i] / dt * (umax - u_new_lo);
@@ -384,12 +471,76 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
          if (new_mass < -eps) { f = std::fmax(0.0, f) - std::fmin(0.0, f) * sumPos / sumNeg; }
          du[(size_t)e * D3 + i] = dl[i] + f / m[i];
       }
+      my_fct += now() - c1;
    }
+   b_lo = my_lo;
+   b_fct = my_fct;
    } // omp parallel
+   g_bucket[0] += b_rhs;
+   g_bucket[1] += b_inv;
+   g_bucket[2] += b_lo;
+   g_bucket[3] += b_fct;
    return itmax;
 }
 
-// RK3-SSP step in place on u (size ne*ndof); work arrays are allocated by the caller (5 * ne*ndof + 2*ne).
+template <int P>
+void lumped_mass_t(int ne, int exec_mode, const double *x0, const double *vel, double t, double *m)
+{
+   static const Tables<P> T;
+   constexpr int D = P + 1, Q = P + 3, D3 = D * D * D, Q2 = Q * Q, Q3 = Q2 * Q;
+#pragma omp parallel
+   {
+   alignas(64) double X[81], Jc[9 * Q3], wd[Q3], wa[Q3], wb[Q3];
+#pragma omp for schedule(static)
+   for (int e = 0; e < ne; e++)
+   {
+      for (int i = 0; i < 81; i++) { X[i] = x0[(size_t)e * 81 + i] + (exec_mode == 1 ? t * vel[(size_t)e * 81 + i] : 0.0); }
+      for (int c = 0; c < 3; c++)
+      {
+         interp3<Q, 3>(T.dL, T.L, T.L, &X[c * 27], &Jc[(c * 3 + 0) * Q3], wa, wb);
+         interp3<Q, 3>(T.L, T.dL, T.L, &X[c * 27], &Jc[(c * 3 + 1) * Q3], wa, wb);
+         interp3<Q, 3>(T.L, T.L, T.dL, &X[c * 27], &Jc[(c * 3 + 2) * Q3], wa, wb);
+      }
+      for (int q = 0; q < Q3; q++)
+      {
+         const double J00 = Jc[0 * Q3 + q], J01 = Jc[1 * Q3 + q], J02 = Jc[2 * Q3 + q];
+         const double J10 = Jc[3 * Q3 + q], J11 = Jc[4 * Q3 + q], J12 = Jc[5 * Q3 + q];
+         const double J20 = Jc[6 * Q3 + q], J21 = Jc[7 * Q3 + q], J22 = Jc[8 * Q3 + q];
+         const double detJ = J00 * (J11 * J22 - J12 * J21) + J01 * (J20 * J12 - J10 * J22) + J02 * (J10 * J21 - J20 * J11);
+         wd[q] = T.W[q % Q] * T.W[(q / Q) % Q] * T.W[q / Q2] * detJ;
+      }
+      test3<D, Q>(T.Bt, T.Bt, T.Bt, wd, &m[(size_t)e * D3], wa, wb);
+   }
+   }
+}
+
+#define CPU_DISPATCH(p, expr)                   \
+   switch (p)                                   \
+   {                                            \
+      case 1: { constexpr int P = 1; expr; break; } \
+      case 2: { constexpr int P = 2; expr; break; } \
+      case 3: { constexpr int P = 3; expr; break; } \
+      case 4: { constexpr int P = 4; expr; break; } \
+      case 5: { constexpr int P = 5; expr; break; } \
+      default: { constexpr int P = 6; expr; break; } \
+   }
+
+} // namespace
+
+extern "C" {
+
+// One stage: du = F(u, t) with dt the full step (LO/FCT).  Arrays as in include/rmh.h (host memory).
+// ws_m receives the lumped mass.  Returns the max PCG iteration count.
+int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr,
+              const int *stencil27, double t, double dt, const double *u, double *du, double *ws_m,
+              double *ws_duho, double *ws_xe /* [2*ne] */, double rel_tol)
+{
+   int it = 0;
+   CPU_DISPATCH(p, it = stage_t<P>(ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, du, ws_m, ws_duho, ws_xe, rel_tol));
+   return it;
+}
+
+// RK3-SSP step in place on u (size ne*ndof); work arrays are allocated by the caller (4 * ne*ndof + 2*ne).
 int cpu_rk3_step(int p, int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr,
                  const int *stencil27, double t, double dt, double *u, double *work, double rel_tol)
 {
@@ -410,30 +561,16 @@ int cpu_rk3_step(int p, int ne, int exec_mode, const double *x0, const double *v
 // lumped mass at pseudo-time t (initial / final mass)
 void cpu_lumped_mass(int p, int ne, int exec_mode, const double *x0, const double *vel, double t, double *m)
 {
-   const Tab T = get_tab(p);
-   const int D = T.D, Q = T.Q, D3 = D * D * D, Q2 = Q * Q, Q3 = Q2 * Q;
-   const double *B = &T.t[T.oB], *L = &T.t[T.oL], *dL = &T.t[T.odL], *W = &T.t[T.oW];
-#pragma omp parallel for schedule(static)
-   for (int e = 0; e < ne; e++)
+   CPU_DISPATCH(p, lumped_mass_t<P>(ne, exec_mode, x0, vel, t, m));
+}
+
+// TimingData-style buckets accumulated since the last reset: seconds in RHS, INV, LO, FCT (max over threads per stage)
+void cpu_buckets(double t[4], int reset)
+{
+   for (int k = 0; k < 4; k++)
    {
-      Work w;
-      std::vector<double> X(81), Jc(9 * Q3), wd(Q3);
-      for (int i = 0; i < 81; i++) { X[i] = x0[(size_t)e * 81 + i] + (exec_mode == 1 ? t * vel[(size_t)e * 81 + i] : 0.0); }
-      for (int c = 0; c < 3; c++)
-      {
-         interp3(dL, L, L, Q, 3, &X[c * 27], &Jc[(c * 3 + 0) * Q3], w);
-         interp3(L, dL, L, Q, 3, &X[c * 27], &Jc[(c * 3 + 1) * Q3], w);
-         interp3(L, L, dL, Q, 3, &X[c * 27], &Jc[(c * 3 + 2) * Q3], w);
-      }
-      for (int q = 0; q < Q3; q++)
-      {
-         double J[3][3];
-         for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) { J[a][b] = Jc[(a * 3 + b) * Q3 + q]; } }
-         const double detJ = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[2][0] * J[1][2] - J[1][0] * J[2][2]) +
-                             J[0][2] * (J[1][0] * J[2][1] - J[2][0] * J[1][1]);
-         wd[q] = W[q % Q] * W[(q / Q) % Q] * W[q / Q2] * detJ;
-      }
-      test3(B, B, B, Q, D, wd.data(), &m[(size_t)e * D3], w);
+      t[k] = g_bucket[k];
+      if (reset) { g_bucket[k] = 0.0; }
    }
 }
 

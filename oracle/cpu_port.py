@@ -8,6 +8,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def load():
+    # one thread per core, pinned (reported with the baseline): set before the OpenMP runtime starts
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     path = os.path.join(_HERE, "libcpu_port.so")
     if not os.path.exists(path):
         import subprocess
@@ -19,6 +22,8 @@ def load():
     lib.cpu_rk3_step.argtypes = [i, i, i, p, p, p, p, d, d, p, p, d]
     lib.cpu_lumped_mass.argtypes = [i, i, i, p, p, d, p]
     lib.cpu_lumped_mass.restype = None
+    lib.cpu_buckets.argtypes = [C.POINTER(d * 4), i]
+    lib.cpu_buckets.restype = None
     return lib
 
 
@@ -55,6 +60,12 @@ class CpuPort:
                            self.st.ctypes.data, t, dt, u.ctypes.data, du.ctypes.data, m.ctypes.data, dh.ctypes.data,
                            xe.ctypes.data, self.rel_tol)
         return du, m, dh
+
+    def buckets(self, reset=False):
+        """TimingData-style buckets (seconds: RHS, INV, LO, FCT) accumulated since the last reset"""
+        t = (C.c_double * 4)()
+        self.lib.cpu_buckets(C.byref(t), 1 if reset else 0)
+        return list(t)
 
     def mass(self, t):
         m = np.zeros_like(self.u)

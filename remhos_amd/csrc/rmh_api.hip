@@ -137,19 +137,16 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.y_out = nullptr;
    a.xe_min_out = nullptr;
    a.xe_max_out = nullptr;
-   if (MODE == 2 && c->ho_variant == 2 && P >= 2)
+   if (MODE == 2)
    {
-      constexpr int NB = K2Cfg<P, true>::NB;
-      hipLaunchKernelGGL((ho_kernel2<(P >= 2 ? P : 2), 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P, true>::NT), 0, c->stream, a);
-   }
-   else if (MODE == 0 && c->ho_variant == 2)
-   {
-      constexpr int NB = K2Cfg<P>::NB;
-      hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
+      constexpr int P2 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the callers)
+      constexpr int NB = K2Cfg<P2, true>::NB;
+      hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
    else
    {
-      hipLaunchKernelGGL((ho_kernel<P, MODE>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, a);
+      constexpr int NB = K2Cfg<P>::NB;
+      hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
    return 0;
@@ -338,7 +335,6 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->device = L->device;
    c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
    c->gh_ustride = c->ndof;
-   if (const char *v = std::getenv("RMH_HO_KERNEL")) { c->ho_variant = std::atoi(v) == 1 ? 1 : 2; }
 #if RMH_PERSIST_LOOP
    if (const char *v = std::getenv("RMH_PERSIST")) { c->persist = std::max(0, std::atoi(v)); } // (tuning aid)
    {
@@ -433,7 +429,10 @@ int rmh_compute_lumped_mass(rmh_ctx *c, double t, double *m)
    if (!c || !m) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
    int rc = 0;
-   RMH_DISPATCH(c, rc = (launch_ho<P, 1>(c, nullptr, nullptr, m, t)));
+   RMH_DISPATCH(c, hipLaunchKernelGGL((lumped_mass_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
+                                      (const double *)c->d_x0, (const double *)c->d_vel, (const double *)c->d_tab, t,
+                                      c->exec_mode == 1 ? 1 : 0, m));
+   RMH_HIP(hipGetLastError());
    return rc;
 }
 
@@ -483,7 +482,7 @@ int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 int rmh_lo_rd(rmh_ctx *c, const double *u, double *du_lo)
 {
    if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
-   if (c->p < 2 || c->ho_variant != 2) { return fail(RMH_ERR_INVALID, "rmh_lo_rd: the batched RD kernel is built for orders >= 2"); }
+   if (c->p < 2) { return fail(RMH_ERR_INVALID, "rmh_lo_rd: the RD kernel is built for orders >= 2"); }
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
    return lo_rd(c, u, du_lo, 3);
 }

@@ -1,0 +1,32 @@
+// Diagnostic instrumentation of ho_kernel2 (rmh_ho2.hpp), compiled in only by the diagnostic build
+// `make stamps` (-DRMH_STAMPS -> remhos_amd/librmh_stamps.so, read by tools/stamps.py); in the product build both
+// macros are empty.
+// (included inside namespace rmh by rmh_ho2.hpp)
+#pragma once
+
+#ifdef RMH_STAMPS
+// diagnostic build only: per-phase cycle shares of workgroup-thread 0.  The deltas are accumulated in LDS and
+// written once at the end of the kernel (a global atomic per stamp would be waited for by the next
+// s_waitcnt vmcnt(0) of the workgroup and show up as a phantom wait); one row of 32 counters per workgroup,
+// summed by the host.
+constexpr int RMH_STAMP_MAXWG = 1 << 18;
+__device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
+#define RMH_STAMP(k)                                                                   \
+   do {                                                                                \
+      if (threadIdx.x == 0)                                                            \
+      {                                                                                \
+         const unsigned long long now_ = clock64();                                    \
+         s_stamp[k] += now_ - stamp_prev_;                                             \
+         stamp_prev_ = now_;                                                           \
+      }                                                                                \
+   } while (0)
+#define RMH_STAMP_FLUSH()                                                              \
+   do {                                                                                \
+      __syncthreads();                                                                 \
+      if (threadIdx.x < 32 && blockIdx.x < RMH_STAMP_MAXWG) { g_stamps[blockIdx.x][threadIdx.x] += s_stamp[threadIdx.x]; } \
+   } while (0)
+#else
+#define RMH_STAMP(k)
+#define RMH_STAMP_FLUSH()
+#endif
+

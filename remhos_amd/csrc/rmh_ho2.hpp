@@ -1,6 +1,6 @@
 // HO kernel, second generation: element batching.
 //
-// Same mathematics as ho_kernel (rmh_kernels.hpp) -- du = M^-1 (K_vol + K_face) u, lumped mass,
+// du = M^-1 (K_vol + K_face) u, lumped mass,
 // element extrema -- but organised for wave64 occupancy of the "column" phases:
 //
 //   * a workgroup of 256 threads (4 wavefronts) works on NB = floor(256 / Q^2) elements at once
@@ -39,9 +39,6 @@ namespace rmh
 #define RMH_PRIO 0
 #endif
 
-#ifndef RMH_ABL_MASK
-#define RMH_ABL_MASK 0 // diagnostic builds only: bit k skips a piece of the PCG iteration
-#endif
 
 template <int P, bool LO4 = false, bool BOTH = false>
 struct K2Cfg : TabLayout<P>
@@ -433,31 +430,7 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
    }
 }
 
-#ifdef RMH_STAMPS
-// diagnostic build only: per-phase cycle shares of workgroup-thread 0.  The deltas are accumulated in LDS and
-// written once at the end of the kernel (a global atomic per stamp would be waited for by the next
-// s_waitcnt vmcnt(0) of the workgroup and show up as a phantom wait); one row of 32 counters per workgroup,
-// summed by the host.
-constexpr int RMH_STAMP_MAXWG = 1 << 18;
-__device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
-#define RMH_STAMP(k)                                                                   \
-   do {                                                                                \
-      if (threadIdx.x == 0)                                                            \
-      {                                                                                \
-         const unsigned long long now_ = clock64();                                    \
-         s_stamp[k] += now_ - stamp_prev_;                                             \
-         stamp_prev_ = now_;                                                           \
-      }                                                                                \
-   } while (0)
-#define RMH_STAMP_FLUSH()                                                              \
-   do {                                                                                \
-      __syncthreads();                                                                 \
-      if (threadIdx.x < 32 && blockIdx.x < RMH_STAMP_MAXWG) { g_stamps[blockIdx.x][threadIdx.x] += s_stamp[threadIdx.x]; } \
-   } while (0)
-#else
-#define RMH_STAMP(k)
-#define RMH_STAMP_FLUSH()
-#endif
+#include "rmh_diag.hpp" // RMH_STAMP / RMH_STAMP_FLUSH: empty unless the diagnostic build -DRMH_STAMPS
 
 // Primary global loads of one element batch (phase A): face-neighbour indices, stencil indices (fused stage), Q2
 // nodes of x0 and v, u.  The fused stage calls it for the NEXT batch of a persistent workgroup at the start of its
@@ -1452,7 +1425,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       __syncthreads();
       if (!s_flag[it & 1]) { break; } // no element of the batch is active any more
       RMH_STAMP(10);
-      if (!(RMH_ABL_MASK & 1))
       for (int k = tid; k < NB * D2; k += NT)
       {
          const int eb = k / D2, i2 = k % D2;
@@ -1471,9 +1443,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             dst[q * S2] = acc;
          }
       }
-      if (!(RMH_ABL_MASK & 16)) { __syncthreads(); }
+      __syncthreads();
       RMH_STAMP(11);
-      if (col && !(RMH_ABL_MASK & 2))
+      if (col)
       {
          const double *M1 = RMH_W(ceb) + oM1 + qx * S2;
          double Y[D];
@@ -1503,9 +1475,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int iz = 0; iz < D; iz++) { R3[iz] = rz[iz]; }
       }
-      if (!(RMH_ABL_MASK & 16)) { __syncthreads(); }
+      __syncthreads();
       RMH_STAMP(12);
-      if (!(RMH_ABL_MASK & 4))
       for (int k = tid; k < NB * Q * D; k += NT)
       {
          const int eb = k / (Q * D), rem = k % (Q * D);
@@ -1525,7 +1496,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             dst[iy] = acc;
          }
       }
-      if (!(RMH_ABL_MASK & 16)) { __syncthreads(); }
+      __syncthreads();
       RMH_STAMP(13);
       double Ad[DR];
 #pragma unroll
@@ -1541,17 +1512,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const double *R2 = RMH_W(eb) + oM1 + i2;
             double acc = 0.0;
 #pragma unroll
-            for (int jx = 0; jx < ((RMH_ABL_MASK & 8) ? 0 : Q); jx++) { acc += cBg[r][jx] * R2[jx * S2]; }
+            for (int jx = 0; jx < Q; jx++) { acc += cBg[r][jx] * R2[jx * S2]; }
             Ad[r] = acc;
             tmp[r] = dd[r] * acc;
          }
       }
       RMH_STAMP(8);
-#ifdef RMH_ABL_NODOT
-      for (int r = 0; r < DR; r++) { red[r] = nom[r]; }
-#else
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // den = d.Ad
-#endif
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -1563,11 +1530,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          tmp[r] = rg[r] * (rg[r] * dg[r]);
       }
       RMH_STAMP(14);
-#ifdef RMH_ABL_NODOT
-      for (int r = 0; r < DR; r++) { red[r] = 0.0; }
-#else
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // betanom = r.z
-#endif
       RMH_STAMP(15);
       bool any = false;
 #pragma unroll

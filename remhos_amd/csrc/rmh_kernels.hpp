@@ -122,153 +122,79 @@ __device__ inline double block_max(double v, double *s_red)
    return r;
 }
 
-// out[.., k_dir, ..] = sum_i M(i,k) in[.., i_dir, ..]  over a D x D x D tensor, direction `dir`.
-// TRANS = false : M(i,k) = mat[k*D + i]   (out_k = sum_i mat[k][i] in_i)
-// TRANS = true  : M(i,k) = mat[i*D + k]   (out_k = sum_i mat[i][k] in_i)
-template <int D, int NT, bool TRANS>
-__device__ inline void dof_tensor_apply(const double *mat, int dir, const double *in, double *out)
-{
-   constexpr int D3 = D * D * D;
-   const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D * D);
-   for (int o = threadIdx.x; o < D3; o += NT)
-   {
-      const int k = (o / stride) % D;
-      const int base = o - k * stride;
-      double acc = 0.0;
-#pragma unroll
-      for (int i = 0; i < D; i++)
-      {
-         const double mv = TRANS ? mat[i * D + k] : mat[k * D + i];
-         acc += mv * in[base + i * stride];
-      }
-      out[o] = acc;
-   }
-}
-
 // ---------------------------------------------------------------------------------------
-// HO kernel: du = M^-1 (K_vol + K_face) u, plus lumped mass and element extrema.
-//
-//   K_vol  : ConvectionIntegrator PA apply      (remhos.cpp:646-657; qdata as in
-//            remhos_lo.cpp:1155-1190, apply as in remhos_lo.cpp:1473-1612)
-//   K_face : transposed DGTraceIntegrator, upwind (remhos.cpp:659-678)
-//   M^-1   : element-local PCG in the Gauss-Legendre nodal basis with Jacobi preconditioner
-//            (DGMassInverse, remhos_ho.cpp:79-80,126)
-//   lumped mass M_HO * 1 (remhos.cpp:1632); element min/max (remhos_tools.cpp:497-523)
-//
-// MODE 0: everything.  MODE 1: lumped mass only (rmh_compute_lumped_mass).
+// Lumped mass M_HO * 1 at pseudo-time t (remhos.cpp:719-727, 1625-1632; the initial / final mass of the report,
+// remhos.cpp:1073-1076, 1394-1403): m_i = sum_q w_q detJ(q) B_i(q), sum-factorised.  One element per workgroup;
+// geometry from the 27 nodes x0 + t v like the stage kernel (rmh_ho2.hpp), without u.  Called a few times per run.
 // ---------------------------------------------------------------------------------------
-template <int P, int MODE>
-__global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
+template <int P>
+__global__ void __launch_bounds__(KCfg<P>::NT) lumped_mass_kernel(const double *x0, const double *vel, const double *gtab,
+                                                                  double t, int move, double *m)
 {
    using C = KCfg<P>;
-   constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NW = C::NW;
-
+   constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT;
    __shared__ double tab[C::N2];
-   __shared__ double sX[81], sV[81];
-   __shared__ double su[D3];
-   __shared__ double sNb[6 * D2];
-   __shared__ double sT1[9 * Q * 9];
-   __shared__ double sU1[2 * Q * D2];
-   __shared__ double sR3[3 * Q2 * D];
-   __shared__ double sR2[3 * Q * D2];
-   __shared__ double sF[6 * Q2];
-   __shared__ double s_rhs[D3], s_m[D3], s_dg[D3], s_x[D3], s_r[D3], s_d[D3], s_Ad[D3];
-   __shared__ double s_red[4];
-
-   const int tid = threadIdx.x;
-   const int e = blockIdx.x;
-   const double *tB = tab + C::oB, *tG = tab + C::oG, *tL = tab + C::oL, *tdL = tab + C::odL;
-   const double *tW = tab + C::oW, *tBg = tab + C::oBg, *tBg2 = tab + C::oBg2, *tCi = tab + C::oCi;
-
-   // ---- phase A: coalesced loads ------------------------------------------------------
-   for (int i = tid; i < C::N2; i += NT) { tab[i] = a.tab[i]; }
+   __shared__ double sX[81];
+   __shared__ double sT1[6 * Q * 9];
+   __shared__ double sR3[Q2 * D];
+   __shared__ double sR2[Q * D2];
+   const int tid = threadIdx.x, e = blockIdx.x;
+   const double *tB = tab + C::oB, *tL = tab + C::oL, *tdL = tab + C::odL, *tW = tab + C::oW;
+   for (int i = tid; i < C::N2; i += NT) { tab[i] = gtab[i]; }
    for (int i = tid; i < 81; i += NT)
    {
-      const double x0 = a.x0[(size_t)e * 81 + i];
-      const double v = a.vel[(size_t)e * 81 + i];
-      sV[i] = v;
-      sX[i] = a.move ? x0 + a.t * v : x0;
-   }
-   if (MODE != 1)
-   {
-      for (int i = tid; i < D3; i += NT) { su[i] = a.u[(size_t)e * D3 + i]; }
-      // neighbour traces: the D^2 face-layer Bernstein coefficients of the neighbour
-      for (int k = tid; k < 6 * D2; k += NT)
-      {
-         const int f = k / D2, r = k % D2;
-         const int i1 = r % D, i2 = r / D;
-         const int c = f >> 1, side = f & 1;
-         const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-         const int strc = (c == 0) ? 1 : (c == 1 ? D : D2);
-         const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
-         const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
-         const int nb = a.face_nbr[(size_t)e * 6 + f];
-         double val = 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
-         if (nb >= 0)
-         {
-            const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3
-                               : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
-            const int ic = side ? 0 : P; // the neighbour's opposite face layer
-            // (compact ghost records hold exactly that layer, ordered like this face: rmh_exchange_setup)
-            val = (a.gh_compact && nb >= a.ne_owned) ? un[r] : un[ic * strc + i1 * str1 + i2 * str2];
-         }
-         sNb[k] = val;
-      }
+      const double x = x0[(size_t)e * 81 + i];
+      sX[i] = move ? x + t * vel[(size_t)e * 81 + i] : x;
    }
    __syncthreads();
-
-   // ---- phase B: geometry, contraction along x ------------------------------------------
-   // sT1[(arr*Q + qx)*9 + ay + 3*az], arr = 3*comp + kind, kind 0: L.X, 1: dL.X, 2: L.V
-   for (int k = tid; k < 9 * Q * 9; k += NT)
+   // x-contraction of the nodes: sT1[((comp*2 + kind)*Q + qx)*9 + ay + 3*az], kind 0: L.X, 1: dL.X
+   for (int k = tid; k < 6 * Q * 9; k += NT)
    {
       const int arr = k / (Q * 9), r = k % (Q * 9);
       const int qx = r / 9, n2 = r % 9;
-      const int comp = arr / 3, kind = arr % 3;
-      const double *src = (kind == 2 ? sV : sX) + comp * 27 + 3 * n2;
-      const double *w = (kind == 1 ? tdL : tL) + qx * 3;
+      const int comp = arr / 2, kind = arr % 2;
+      const double *src = sX + comp * 27 + 3 * n2;
+      const double *w = (kind ? tdL : tL) + qx * 3;
       sT1[k] = w[0] * src[0] + w[1] * src[1] + w[2] * src[2];
    }
    __syncthreads();
-
-   // ---- phase C: column threads finish the geometry in registers --------------------------
-   const bool col = tid < Q2;
-   const int qx = tid % Q, qy = (tid / Q) % Q;
-   double Dq[3][Q], wd[Q];
-   if (col)
+   // column (qx, qy): Jacobian at the Q points of the column, w detJ tested with the Bernstein basis along z
+   if (tid < Q2)
    {
-      double A[3][4][3];
+      const int qx = tid % Q, qy = tid / Q;
+      double A[3][3][3]; // [comp][d/dxi, d/deta, value for d/dzeta][az]
 #pragma unroll
       for (int comp = 0; comp < 3; comp++)
       {
 #pragma unroll
          for (int az = 0; az < 3; az++)
          {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            double a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
             for (int ay = 0; ay < 3; ay++)
             {
                const double Ly = tL[qy * 3 + ay], dLy = tdL[qy * 3 + ay];
-               const int n2 = ay + 3 * az;
-               const double xl = sT1[((comp * 3 + 0) * Q + qx) * 9 + n2];
-               const double xd = sT1[((comp * 3 + 1) * Q + qx) * 9 + n2];
-               const double vl = sT1[((comp * 3 + 2) * Q + qx) * 9 + n2];
-               a0 += Ly * xd;  // d/dxi
-               a1 += dLy * xl; // d/deta
-               a2 += Ly * xl;  // d/dzeta (with dL_z)
-               a3 += Ly * vl;  // velocity value
+               const double xl = sT1[((comp * 2 + 0) * Q + qx) * 9 + ay + 3 * az];
+               const double xd = sT1[((comp * 2 + 1) * Q + qx) * 9 + ay + 3 * az];
+               a0 += Ly * xd;
+               a1 += dLy * xl;
+               a2 += Ly * xl;
             }
-            A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2; A[comp][3][az] = a3;
+            A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2;
          }
       }
+      double r1[D];
+#pragma unroll
+      for (int iz = 0; iz < D; iz++) { r1[iz] = 0.0; }
       const double wxy = tW[qx] * tW[qy];
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
-         double J[3][3], v[3];
+         double J[3][3];
 #pragma unroll
          for (int comp = 0; comp < 3; comp++)
          {
-            double j0 = 0, j1 = 0, j2 = 0, vv = 0;
+            double j0 = 0, j1 = 0, j2 = 0;
 #pragma unroll
             for (int az = 0; az < 3; az++)
             {
@@ -276,551 +202,37 @@ __global__ void __launch_bounds__(KCfg<P>::NT) ho_kernel(HoArgs a)
                j0 += Lz * A[comp][0][az];
                j1 += Lz * A[comp][1][az];
                j2 += dLz * A[comp][2][az];
-               vv += Lz * A[comp][3][az];
             }
-            J[comp][0] = j0; J[comp][1] = j1; J[comp][2] = j2; v[comp] = vv;
+            J[comp][0] = j0; J[comp][1] = j1; J[comp][2] = j2;
          }
-         // adj(J), rows as in remhos_lo.cpp:1168-1180 (A_cr = cofactor so that adj*J = det*I)
          const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
-         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
          const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
-         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
          const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
-         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
-         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-         const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
-         const double w3 = wxy * tW[qz];
-         const double aw = a.alpha * w3;
-         Dq[0][qz] = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
-         Dq[1][qz] = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
-         Dq[2][qz] = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
-         wd[qz] = w3 * detJ;
-      }
-   }
-
-   // ---- phase D: u contracted along x -------------------------------------------------
-   if (MODE != 1)
-   {
-      for (int k = tid; k < 2 * Q * D2; k += NT)
-      {
-         const int kind = k / (Q * D2), r = k % (Q * D2);
-         const int q = r / D2, i2 = r % D2;
-         const double *w = (kind ? tG : tB) + q * D;
-         double acc = 0.0;
+         const double wdq = wxy * tW[qz] * (J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31);
 #pragma unroll
-         for (int ix = 0; ix < D; ix++) { acc += w[ix] * su[ix + D * i2]; }
-         sU1[k] = acc; // [kind][qx][iy + D*iz]
+         for (int iz = 0; iz < D; iz++) { r1[iz] += tB[qz * D + iz] * wdq; }
       }
+#pragma unroll
+      for (int iz = 0; iz < D; iz++) { sR3[tid * D + iz] = r1[iz]; }
    }
    __syncthreads();
-
-   // ---- phase E: column threads: grad u, D.grad u, and the z-leg of the test contractions ---
-   if (col)
+   for (int k = tid; k < Q * D2; k += NT)
    {
-      double g[Q];
-      if (MODE != 1)
-      {
-         double UB[D], UG[D], UU[D];
-#pragma unroll
-         for (int iz = 0; iz < D; iz++)
-         {
-            double b0 = 0, b1 = 0, b2 = 0;
-#pragma unroll
-            for (int iy = 0; iy < D; iy++)
-            {
-               const double By = tB[qy * D + iy], Gy = tG[qy * D + iy];
-               const double ub = sU1[(0 * Q + qx) * D2 + iy + D * iz];
-               const double ug = sU1[(1 * Q + qx) * D2 + iy + D * iz];
-               b0 += By * ug; // d/dxi
-               b1 += Gy * ub; // d/deta
-               b2 += By * ub; // value along x,y
-            }
-            UB[iz] = b0; UG[iz] = b1; UU[iz] = b2;
-         }
-#pragma unroll
-         for (int qz = 0; qz < Q; qz++)
-         {
-            double gx = 0, gy = 0, gz = 0;
-#pragma unroll
-            for (int iz = 0; iz < D; iz++)
-            {
-               const double Bz = tB[qz * D + iz], Gz = tG[qz * D + iz];
-               gx += Bz * UB[iz];
-               gy += Bz * UG[iz];
-               gz += Gz * UU[iz];
-            }
-            g[qz] = Dq[0][qz] * gx + Dq[1][qz] * gy + Dq[2][qz] * gz;
-         }
-      }
-      // test along z: r=0: phi_i * (D.grad u); r=1: phi_i * w detJ (lumped mass);
-      //               r=2: psi_k^2 * w detJ (Jacobi diagonal of the GL-basis mass matrix)
-#pragma unroll
-      for (int iz = 0; iz < D; iz++)
-      {
-         double r0 = 0, r1 = 0, r2 = 0;
-#pragma unroll
-         for (int qz = 0; qz < Q; qz++)
-         {
-            const double Bz = tB[qz * D + iz];
-            if (MODE != 1) { r0 += Bz * g[qz]; r2 += tBg2[qz * D + iz] * wd[qz]; }
-            r1 += Bz * wd[qz];
-         }
-         sR3[(0 * Q2 + qx + Q * qy) * D + iz] = r0;
-         sR3[(1 * Q2 + qx + Q * qy) * D + iz] = r1;
-         sR3[(2 * Q2 + qx + Q * qy) * D + iz] = r2;
-      }
-   }
-   __syncthreads();
-
-   // ---- phase F/G: remaining legs of the test contractions -----------------------------------
-   for (int k = tid; k < 3 * Q * D2; k += NT)
-   {
-      const int r = k / (Q * D2), rem = k % (Q * D2);
-      const int q = rem / D2, i2 = rem % D2;
+      const int q = k / D2, i2 = k % D2;
       const int iy = i2 % D, iz = i2 / D;
-      const double *w = (r == 2) ? tBg2 : tB;
       double acc = 0.0;
 #pragma unroll
-      for (int jy = 0; jy < Q; jy++) { acc += w[jy * D + iy] * sR3[(r * Q2 + q + Q * jy) * D + iz]; }
-      sR2[k] = acc; // [r][qx][iy + D*iz]
+      for (int jy = 0; jy < Q; jy++) { acc += tB[jy * D + iy] * sR3[(q + Q * jy) * D + iz]; }
+      sR2[k] = acc;
    }
    __syncthreads();
-   for (int k = tid; k < 3 * D3; k += NT)
+   for (int i = tid; i < D3; i += NT)
    {
-      const int r = k / D3, i = k % D3;
       const int ix = i % D, i2 = i / D;
-      const double *w = (r == 2) ? tBg2 : tB;
       double acc = 0.0;
 #pragma unroll
-      for (int jx = 0; jx < Q; jx++) { acc += w[jx * D + ix] * sR2[(r * Q + jx) * D2 + i2]; }
-      if (r == 0) { s_rhs[i] = acc; }
-      else if (r == 1) { s_m[i] = acc; }
-      else { s_dg[i] = acc; }
-   }
-   __syncthreads();
-
-   if (MODE == 1)
-   {
-      for (int i = tid; i < D3; i += NT) { a.m[(size_t)e * D3 + i] = s_m[i]; }
-      return;
-   }
-
-   // ---- phase H: faces ------------------------------------------------------------------------
-   // every element integrates its own six faces with its own outward normal:
-   //   y_i += sum_q w_q max(0, upw * v.n_out) (u_nbr - u_own)(q) phi_i(q)     
-   for (int k = tid; k < 6 * Q2; k += NT)
-   {
-      const int f = k / Q2, r = k % Q2;
-      const int q1 = r % Q, q2 = r / Q;
-      const int c = f >> 1, side = f & 1;
-      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-      const int nc = (c == 0) ? 1 : (c == 1 ? 3 : 9);
-      const int n1 = (c1 == 0) ? 1 : (c1 == 1 ? 3 : 9);
-      const int n2 = (c2 == 0) ? 1 : (c2 == 1 ? 3 : 9);
-      const int nbase = side ? 2 * nc : 0;
-      double t1[3] = {0, 0, 0}, t2[3] = {0, 0, 0}, vf[3] = {0, 0, 0};
-#pragma unroll
-      for (int a2 = 0; a2 < 3; a2++)
-      {
-         const double L2 = tL[q2 * 3 + a2], dL2 = tdL[q2 * 3 + a2];
-#pragma unroll
-         for (int a1 = 0; a1 < 3; a1++)
-         {
-            const double L1 = tL[q1 * 3 + a1], dL1 = tdL[q1 * 3 + a1];
-            const int n = nbase + a1 * n1 + a2 * n2;
-            const double w1 = dL1 * L2, w2 = L1 * dL2, w0 = L1 * L2;
-#pragma unroll
-            for (int comp = 0; comp < 3; comp++)
-            {
-               const double x = sX[comp * 27 + n];
-               t1[comp] += w1 * x;
-               t2[comp] += w2 * x;
-               vf[comp] += w0 * sV[comp * 27 + n];
-            }
-         }
-      }
-      // t1 x t2 = row c of adj(J): area-weighted normal pointing towards +xi_c
-      const double nx = t1[1] * t2[2] - t1[2] * t2[1];
-      const double ny = t1[2] * t2[0] - t1[0] * t2[2];
-      const double nz = t1[0] * t2[1] - t1[1] * t2[0];
-      double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
-      if (!side) { vn = -vn; }
-      const double s = fmax(0.0, a.upw * vn) * tW[q1] * tW[q2];
-      // jump of the traces at the face point
-      const int dc = (c == 0) ? 1 : (c == 1 ? D : D2);
-      const int d1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
-      const int d2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
-      const int dbase = side ? P * dc : 0;
-      double jump = 0.0;
-#pragma unroll
-      for (int i2 = 0; i2 < D; i2++)
-      {
-         double rowacc = 0.0;
-#pragma unroll
-         for (int i1 = 0; i1 < D; i1++)
-         {
-            rowacc += tB[q1 * D + i1] * (sNb[f * D2 + i1 + D * i2] - su[dbase + i1 * d1 + i2 * d2]);
-         }
-         jump += tB[q2 * D + i2] * rowacc;
-      }
-      sF[k] = (MODE == 2) ? s : s * jump;
-   }
-   __syncthreads();
-   if (MODE == 2)
-   {
-      // ============ subcell residual distribution (PAResidualDistributionSubcell::CalcLOSolution,
-      // remhos_lo.cpp:1620-1802; host form remhos_lo.cpp:111-245) ============================
-      // here s_rhs = z = K_vol u (Bernstein test), s_m = lumped mass, sF = w_q max(0, upw v.n_out)
-      constexpr int NS = P * P * P; // subcells (remhos_tools.cpp:678-734)
-      // [3][D3] sub-mesh node positions at pseudo-time t live in the (unused) PCG vectors
-      auto s_xs3 = [&](int comp) -> double * { return comp == 0 ? s_x : (comp == 1 ? s_r : s_d); };
-      double *s_fl = sR3;            // [6][NS]: fluctP, fluctN, xMax, xMin, swP, swN per subcell
-      static_assert(6 * NS <= 3 * Q2 * D, "s_fl fits in sR3");
-      const double eps = 1.E-15, gamma = 1.0;
-      // (1) sub-mesh nodes: x_sub(t) = x0_sub + t * v_sub, x0_sub = Q2 map of the START mesh at the
-      //     closed-uniform points i/p (remhos.cpp:796-867, 1262-1274)
-      for (int k = tid; k < 3 * D3; k += NT)
-      {
-         const int comp = k / D3, i = k % D3;
-         const int ix = i % D, iy = (i / D) % D, iz = i / D2;
-         const double *x0 = a.x0 + (size_t)e * 81 + comp * 27;
-         const double *Lx = tab + C::oLcu + ix * 3, *Ly = tab + C::oLcu + iy * 3, *Lz = tab + C::oLcu + iz * 3;
-         double acc = 0.0;
-#pragma unroll
-         for (int az = 0; az < 3; az++)
-         {
-#pragma unroll
-            for (int ay = 0; ay < 3; ay++)
-            {
-#pragma unroll
-               for (int ax = 0; ax < 3; ax++) { acc += Lx[ax] * Ly[ay] * Lz[az] * x0[ax + 3 * (ay + 3 * az)]; }
-            }
-         }
-         const double vs = a.subvel[((size_t)e * 3 + comp) * D3 + i];
-         s_xs3(comp)[i] = a.move ? acc + a.t * vs : acc;
-      }
-      // (2) lumped upwind face fluxes (ApplyFaceTerms, remhos_lo.cpp:795-871): gathered per dof
-      double duf[C::DPT];
-#pragma unroll
-      for (int kk = 0; kk < C::DPT; kk++)
-      {
-         const int i = tid + kk * NT;
-         duf[kk] = 0.0;
-         if (i < D3)
-         {
-            const int idx[3] = {i % D, (i / D) % D, i / D2};
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-            {
-               const int ic = idx[c];
-               if (ic == 0 || ic == P)
-               {
-                  const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                  const int i1 = idx[c1], i2 = idx[c2];
-                  const int side = (ic == P) ? 1 : 0;
-                  const double *F = sF + (2 * c + side) * Q2;
-                  double coef = 0.0;
-#pragma unroll
-                  for (int q2 = 0; q2 < Q; q2++)
-                  {
-                     double rowacc = 0.0;
-#pragma unroll
-                     for (int q1 = 0; q1 < Q; q1++) { rowacc += tB[q1 * D + i1] * F[q1 + Q * q2]; }
-                     coef += tB[q2 * D + i2] * rowacc;
-                  }
-                  acc += coef * (sNb[(2 * c + side) * D2 + i1 + D * i2] - su[i]);
-               }
-            }
-            duf[kk] = acc;
-         }
-      }
-      __syncthreads();
-      // (3) subcell fluctuations F_m = sum_j W_mj u_j with the 1-point rule on the trilinear subcell
-      //     (SetupSubCellPA3D / ApplySubCellWeights, remhos_lo.cpp:1137-1192, 1313-1618) and the
-      //     subcell extrema (remhos_lo.cpp:1733-1757)
-      for (int m = tid; m < NS; m += NT)
-      {
-         const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
-         const int base = mx + D * my + D2 * mz;
-         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
-         double umax = -INFINITY, umin = INFINITY, usum = 0.0;
-#pragma unroll
-         for (int j = 0; j < 8; j++)
-         {
-            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
-            const double uj = su[i];
-            umax = fmax(umax, uj);
-            umin = fmin(umin, uj);
-            usum += uj;
-#pragma unroll
-            for (int comp = 0; comp < 3; comp++)
-            {
-               const double x = s_xs3(comp)[i];
-               J[comp][0] += ((j & 1) ? 0.25 : -0.25) * x;
-               J[comp][1] += ((j & 2) ? 0.25 : -0.25) * x;
-               J[comp][2] += ((j & 4) ? 0.25 : -0.25) * x;
-               vm[comp] += 0.125 * a.subvel[((size_t)e * 3 + comp) * D3 + i];
-            }
-         }
-         const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-         const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
-         const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
-         const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
-         const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-         const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
-         const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
-         const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
-         const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-         const double q0 = a.alpha * (A11 * vm[0] + A12 * vm[1] + A13 * vm[2]);
-         const double q1 = a.alpha * (A21 * vm[0] + A22 * vm[1] + A23 * vm[2]);
-         const double q2 = a.alpha * (A31 * vm[0] + A32 * vm[1] + A33 * vm[2]);
-         double fluct = 0.0;
-#pragma unroll
-         for (int j = 0; j < 8; j++)
-         {
-            const int i = base + (j & 1) + D * ((j >> 1) & 1) + D2 * (j >> 2);
-            const double w = ((j & 1) ? 0.25 : -0.25) * q0 + ((j & 2) ? 0.25 : -0.25) * q1 + ((j & 4) ? 0.25 : -0.25) * q2;
-            fluct += w * su[i];
-         }
-         s_fl[0 * NS + m] = fmax(0., fluct);
-         s_fl[1 * NS + m] = fmin(0., fluct);
-         s_fl[2 * NS + m] = umax;
-         s_fl[3 * NS + m] = umin;
-         s_fl[4 * NS + m] = 8 * umax - usum + eps;
-         s_fl[5 * NS + m] = 8 * umin - usum - eps;
-      }
-      __syncthreads();
-      // (4) element sums (remhos_lo.cpp:1702-1716)
-      double lmax = -INFINITY, lmin = INFINITY, lsum = 0.0, lrp = 0.0, lrn = 0.0, lfp = 0.0, lfn = 0.0;
-      for (int i = tid; i < D3; i += NT)
-      {
-         const double ui = su[i], zi = s_rhs[i];
-         lmax = fmax(lmax, ui);
-         lmin = fmin(lmin, ui);
-         lsum += ui;
-         lrp += fmax(0., zi);
-         lrn += fmin(0., zi);
-      }
-      for (int m = tid; m < NS; m += NT) { lfp += s_fl[m]; lfn += s_fl[NS + m]; }
-      const double xe_max = block_max<NW>(lmax, s_red);
-      const double xe_min = block_min<NW>(lmin, s_red);
-      const double xSum = block_sum<NW>(lsum, s_red);
-      const double rhoP = block_sum<NW>(lrp, s_red);
-      const double rhoN = block_sum<NW>(lrn, s_red);
-      const double sumFluctP = block_sum<NW>(lfp, s_red);
-      const double sumFluctN = block_sum<NW>(lfn, s_red);
-      const double sumWeightsP = D3 * xe_max - xSum + eps;
-      const double sumWeightsN = D3 * xe_min - xSum - eps;
-      // (5) nodal weights (eqs. 58-59) gathered from the <= 8 subcells around each dof, final formula
-#pragma unroll
-      for (int kk = 0; kk < C::DPT; kk++)
-      {
-         const int i = tid + kk * NT;
-         if (i < D3)
-         {
-            const int ix = i % D, iy = (i / D) % D, iz = i / D2;
-            const double ui = su[i];
-            double nwP = 0.0, nwN = 0.0;
-            // the reference accumulates over subcells m ascending; same order here
-            for (int dz = 1; dz >= 0; dz--)
-            {
-               for (int dy = 1; dy >= 0; dy--)
-               {
-                  for (int dx = 1; dx >= 0; dx--)
-                  {
-                     const int mx = ix - dx, my = iy - dy, mz = iz - dz;
-                     if (mx >= 0 && mx < P && my >= 0 && my < P && mz >= 0 && mz < P)
-                     {
-                        const int m = mx + P * (my + P * mz);
-                        nwP += s_fl[0 * NS + m] * ((s_fl[2 * NS + m] - ui) / s_fl[4 * NS + m]);
-                        nwN += s_fl[1 * NS + m] * ((s_fl[3 * NS + m] - ui) / s_fl[5 * NS + m]);
-                     }
-                  }
-               }
-            }
-            double weightP = (xe_max - ui) / sumWeightsP;
-            double weightN = (xe_min - ui) / sumWeightsN;
-            double aux = gamma / (rhoP + eps);
-            weightP *= 1. - fmin(aux * sumFluctP, 1.);
-            weightP += fmin(aux, 1. / (sumFluctP + eps)) * nwP;
-            aux = gamma / (rhoN - eps);
-            weightN *= 1. - fmin(aux * sumFluctN, 1.);
-            weightN += fmax(aux, 1. / (sumFluctN - eps)) * nwN;
-            a.du[(size_t)e * D3 + i] = (duf[kk] + weightP * rhoP + weightN * rhoN) / s_m[i];
-            a.m[(size_t)e * D3 + i] = s_m[i];
-         }
-      }
-      if (tid == 0)
-      {
-         a.xe_min[e] = xe_min;
-         a.xe_max[e] = xe_max;
-      }
-      return;
-   }
-   // test with the face-layer basis functions, gathered per dof (no atomics)
-   for (int i = tid; i < D3; i += NT)
-   {
-      const int idx[3] = {i % D, (i / D) % D, i / D2};
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-      {
-         const int ic = idx[c];
-         if (ic == 0 || ic == P)
-         {
-            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-            const int i1 = idx[c1], i2 = idx[c2];
-            // for P == 0 both faces touch the single dof
-            for (int side = (ic == 0 ? 0 : 1); side <= (ic == P ? 1 : 0); side++)
-            {
-               const double *F = sF + (2 * c + side) * Q2;
-               double fa = 0.0;
-#pragma unroll
-               for (int q2 = 0; q2 < Q; q2++)
-               {
-                  double rowacc = 0.0;
-#pragma unroll
-                  for (int q1 = 0; q1 < Q; q1++) { rowacc += tB[q1 * D + i1] * F[q1 + Q * q2]; }
-                  fa += tB[q2 * D + i2] * rowacc;
-               }
-               acc += fa;
-            }
-         }
-      }
-      s_rhs[i] += acc;
-   }
-   __syncthreads();
-
-   // ---- phase I: element-local mass solve ---------------------------------------------------------
-   // b_g = Ci^T (x) Ci^T (x) Ci^T  b   (rhs in the Gauss-Legendre nodal basis)
-   dof_tensor_apply<D, NT, true>(tCi, 0, s_rhs, s_x);
-   __syncthreads();
-   dof_tensor_apply<D, NT, true>(tCi, 1, s_x, s_d);
-   __syncthreads();
-   dof_tensor_apply<D, NT, true>(tCi, 2, s_d, s_r);
-   __syncthreads();
-
-   double part = 0.0;
-   for (int i = tid; i < D3; i += NT)
-   {
-      const double r = s_r[i];
-      const double z = r / s_dg[i];
-      s_x[i] = 0.0;
-      s_d[i] = z;
-      part += r * z;
-   }
-   double nom = block_sum<NW>(part, s_red);
-   const double tol = fmax(a.rel2 * nom, a.abs2);
-   int it = 0;
-   while (nom > tol && it < a.max_iter)
-   {
-      __syncthreads();
-      // Ad = M_g d : x leg
-      for (int k = tid; k < Q * D2; k += NT)
-      {
-         const int q = k / D2, i2 = k % D2;
-         double acc = 0.0;
-#pragma unroll
-         for (int ix = 0; ix < D; ix++) { acc += tBg[q * D + ix] * s_d[ix + D * i2]; }
-         sU1[k] = acc;
-      }
-      __syncthreads();
-      if (col)
-      {
-         double Y[D];
-#pragma unroll
-         for (int iz = 0; iz < D; iz++)
-         {
-            double acc = 0.0;
-#pragma unroll
-            for (int iy = 0; iy < D; iy++) { acc += tBg[qy * D + iy] * sU1[qx * D2 + iy + D * iz]; }
-            Y[iz] = acc;
-         }
-         double val[Q];
-#pragma unroll
-         for (int qz = 0; qz < Q; qz++)
-         {
-            double acc = 0.0;
-#pragma unroll
-            for (int iz = 0; iz < D; iz++) { acc += tBg[qz * D + iz] * Y[iz]; }
-            val[qz] = acc * wd[qz];
-         }
-#pragma unroll
-         for (int iz = 0; iz < D; iz++)
-         {
-            double acc = 0.0;
-#pragma unroll
-            for (int qz = 0; qz < Q; qz++) { acc += tBg[qz * D + iz] * val[qz]; }
-            sR3[(qx + Q * qy) * D + iz] = acc;
-         }
-      }
-      __syncthreads();
-      for (int k = tid; k < Q * D2; k += NT)
-      {
-         const int q = k / D2, i2 = k % D2;
-         const int iy = i2 % D, iz = i2 / D;
-         double acc = 0.0;
-#pragma unroll
-         for (int jy = 0; jy < Q; jy++) { acc += tBg[jy * D + iy] * sR3[(q + Q * jy) * D + iz]; }
-         sR2[k] = acc;
-      }
-      __syncthreads();
-      part = 0.0;
-      for (int i = tid; i < D3; i += NT)
-      {
-         const int ix = i % D, i2 = i / D;
-         double acc = 0.0;
-#pragma unroll
-         for (int jx = 0; jx < Q; jx++) { acc += tBg[jx * D + ix] * sR2[jx * D2 + i2]; }
-         s_Ad[i] = acc;
-         part += s_d[i] * acc;
-      }
-      const double den = block_sum<NW>(part, s_red);
-      if (!(den > 0.0)) { break; }
-      const double al = nom / den;
-      part = 0.0;
-      for (int i = tid; i < D3; i += NT)
-      {
-         s_x[i] += al * s_d[i];
-         const double r = s_r[i] - al * s_Ad[i];
-         s_r[i] = r;
-         part += r * (r / s_dg[i]);
-      }
-      const double betanom = block_sum<NW>(part, s_red);
-      const double beta = betanom / nom;
-      for (int i = tid; i < D3; i += NT) { s_d[i] = s_r[i] / s_dg[i] + beta * s_d[i]; }
-      nom = betanom;
-      it++;
-   }
-   __syncthreads();
-   // x_b = Ci (x) Ci (x) Ci  x_g
-   dof_tensor_apply<D, NT, false>(tCi, 0, s_x, s_d);
-   __syncthreads();
-   dof_tensor_apply<D, NT, false>(tCi, 1, s_d, s_r);
-   __syncthreads();
-   dof_tensor_apply<D, NT, false>(tCi, 2, s_r, s_x);
-   __syncthreads();
-
-   // ---- phase J: stores ------------------------------------------------------------------------
-   double lmin = INFINITY, lmax = -INFINITY;
-   for (int i = tid; i < D3; i += NT)
-   {
-      a.du[(size_t)e * D3 + i] = s_x[i];
-      a.m[(size_t)e * D3 + i] = s_m[i];
-      lmin = fmin(lmin, su[i]);
-      lmax = fmax(lmax, su[i]);
-   }
-   lmin = block_min<NW>(lmin, s_red);
-   lmax = block_max<NW>(lmax, s_red);
-   if (tid == 0)
-   {
-      a.xe_min[e] = lmin;
-      a.xe_max[e] = lmax;
-      // only when it can raise the maximum: atomics on one address serialise at the memory side
-      if (it > 0 && it > __builtin_nontemporal_load(a.cg_iters)) { atomicMax(a.cg_iters, it); }
+      for (int jx = 0; jx < Q; jx++) { acc += tB[jx * D + ix] * sR2[jx * D2 + i2]; }
+      m[(size_t)e * D3 + i] = acc;
    }
 }
 

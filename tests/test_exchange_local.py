@@ -54,10 +54,10 @@ def lib():
 
 
 @pytest.mark.parametrize("mesh,rs,p,part,lo,compact", [
-    ("periodic-cube", 1, 2, (2, 1, 1), 5, True),    # 6^3 elements, 3 thick: face layers + extrema only
-    ("periodic-cube", 1, 2, (2, 1, 1), 5, False),   # whole neighbour elements
-    ("cube01_hex", 1, 1, (2, 2, 1), 5, True),       # edge neighbours: extrema-only records
-    ("periodic-cube", 1, 2, (1, 2, 1), 4, True),    # subcell RD reads the same ghost traces
+    ("cube01_hex", 1, 2, (2, 1, 1), 5, True),     # 4^3 elements, blocks 2 thick: face layers + extrema only
+    ("cube01_hex", 1, 2, (2, 1, 1), 5, False),    # whole neighbour elements
+    ("cube01_hex", 1, 1, (2, 2, 1), 5, True),     # edge neighbours: extrema-only records
+    ("cube01_hex", 1, 2, (1, 2, 1), 4, True),     # subcell RD reads the same ghost traces
 ])
 def test_blocks_in_one_process_equal_single_block(lib, mesh, rs, p, part, lo, compact):
     u1, _ = run_blocks(lib, "cpu", mesh, rs, p, 10, (1, 1, 1), 1, lo=lo)
@@ -118,17 +118,17 @@ def test_partitioned_cpp_driver_equals_single_block(lib):
     from remhos_amd.case import RmhdResult, make_config
 
     one, many = RmhdResult(), RmhdResult()
-    cfg = make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, max_steps=2)
+    cfg = make_config("cube01_hex", 1, 1, 10, -1.0, 0.5, max_steps=2)
     assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
-    cfgp = make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, max_steps=2, part=(2, 1, 2))
+    cfgp = make_config("cube01_hex", 1, 1, 10, -1.0, 0.5, max_steps=2, part=(2, 1, 2))
     assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
     assert (many.steps, many.stages, many.global_dofs) == (one.steps, one.stages, one.global_dofs)
     assert many.max_value == one.max_value
     assert abs(many.final_mass - one.final_mass) < 1e-14 and abs(many.mass0 - one.mass0) < 1e-14
     # dt control: the min over the blocks drives the controller -- same accepted / repeated steps as one block
     kw = dict(bounds_type=1, dt_control=1, lo_type=4)
-    cfg = make_config("periodic-cube", 0, 2, 0, 0.06, 0.12, **kw)
-    cfgp = make_config("periodic-cube", 0, 2, 0, 0.06, 0.12, part=(1, 1, 3), **kw)
+    cfg = make_config("periodic-cube", 0, 2, 0, 0.06, 0.06, **kw)
+    cfgp = make_config("periodic-cube", 0, 2, 0, 0.06, 0.06, part=(1, 1, 3), **kw)
     assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
     assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
     assert one.repeats > 0 and (many.steps, many.repeats, many.dt) == (one.steps, one.repeats, one.dt)

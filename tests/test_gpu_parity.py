@@ -113,7 +113,8 @@ def test_stage_parity(gpu, mesh, rs, p, prob, t):
         ctypes.c_void_p(m2.data_ptr()), ctypes.c_void_p(mptr), ctypes.c_size_t(m.numel() * 8), 3
     )
     torch.cuda.synchronize()
-    assert torch.equal(m2, m)
+    # (two kernels with their own operation order: the stage kernel's by-product and lumped_mass_kernel)
+    assert _relerr(m2.cpu().numpy(), m.cpu().numpy()) < 1e-14
     ctx.close()
 
 
