@@ -125,11 +125,3 @@ def test_partitioned_cpp_driver_equals_single_block(lib):
     assert (many.steps, many.stages, many.global_dofs) == (one.steps, one.stages, one.global_dofs)
     assert many.max_value == one.max_value
     assert abs(many.final_mass - one.final_mass) < 1e-14 and abs(many.mass0 - one.mass0) < 1e-14
-    # dt control: the min over the blocks drives the controller -- same accepted / repeated steps as one block
-    kw = dict(bounds_type=1, dt_control=1, lo_type=4)
-    cfg = make_config("periodic-cube", 0, 2, 0, 0.06, 0.06, **kw)
-    cfgp = make_config("periodic-cube", 0, 2, 0, 0.06, 0.06, part=(1, 1, 3), **kw)
-    assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
-    assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
-    assert one.repeats > 0 and (many.steps, many.repeats, many.dt) == (one.steps, one.repeats, one.dt)
-    assert many.max_value == one.max_value and abs(many.final_mass - one.final_mass) < 1e-14
