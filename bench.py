@@ -185,8 +185,9 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     tim = st.ctx.timers()
     st.ctx.enable_timers(False)
     cg_iters = st.ctx.last_cg_iters()
+    rdev = dev if (dist is not None and dist.get_backend() == "nccl") else "cpu"  # (gloo reduces host tensors)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
     stages = 3 * args.steps
@@ -194,10 +195,10 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     # sanity of the state after the run: mass conservation and bounds (not timed)
     mass, umax = st.local_mass_and_max()
     if dist is not None:
-        red = torch.tensor([mass], dtype=torch.float64, device=dev)
+        red = torch.tensor([mass], dtype=torch.float64, device=rdev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
         mass = float(red[0])
-        red = torch.tensor([umax], dtype=torch.float64, device=dev)
+        red = torch.tensor([umax], dtype=torch.float64, device=rdev)
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         umax = float(red[0])
     one_kernel = st.one_kernel
@@ -330,13 +331,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the remhos_amd hot path has no CPU fallback")
+    # RMH_BENCH_ONE_GPU=1 (validation aid for boxes with a single GPU, NOT a benchmark): every rank on cuda:0, gloo
+    # process group, the exchange through torch.distributed on the library's segments -- exercises the multi-rank code
+    # path of this file (weak-scaling lattices, reductions, the JSON line) where RCCL refuses two ranks on one device
+    one_gpu = os.environ.get("RMH_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
+        os.environ["RMH_SYNC_EXCHANGE"] = "1"
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
         backend = dist.get_backend()
 
     lib = bind_driver(load_library())

@@ -35,6 +35,16 @@ namespace rmh
 
 // wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
 // other workgroups on the CU (0: off)
+// the qz loops of the column phase take their table rows from the LDS copy (uniform-address reads, in order with the
+// other LDS traffic) instead of scalar loads where the scalar registers cannot hold a plane's rows anyway; the same for
+// the three legs of the PCG's mass apply.  Measured (round 2, MDOFs*stage/s): p = 6 7.43 k -> 7.63 k -> 7.66 k; p = 5
+// -0.8 % / -8 %, p = 4 0, p = 3 -3.7 % (VGPR spills): on for p = 6 only
+#ifndef RMH_COLTAB_LDS
+#define RMH_COLTAB_LDS (P >= 6)
+#endif
+#ifndef RMH_PCGTAB_LDS
+#define RMH_PCGTAB_LDS (P >= 6)
+#endif
 #ifndef RMH_PRIO
 #define RMH_PRIO 0
 #endif
@@ -965,7 +975,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
-            const double *gt = RMH_TABK();
+            const double *gt = RMH_COLTAB_LDS ? (const double *)stab : RMH_TABK();
             double J[3][3], v[3];
 #pragma unroll
             for (int comp = 0; comp < 3; comp++)
@@ -1022,7 +1032,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int qz = 0; qz < Q; qz++)
       {
-         const double *gt = RMH_TABK();
+         const double *gt = RMH_COLTAB_LDS ? (const double *)stab : RMH_TABK();
          double gx = 0, gy = 0, gz = 0;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
@@ -1436,7 +1446,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int q = 0; q < Q; q++)
          {
-            const double *gt = RMH_TABK();
+            const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
@@ -1463,7 +1473,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
-            const double *gt = RMH_TABK();
+            const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
@@ -1489,7 +1499,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            const double *gt = RMH_TABK();
+            const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }

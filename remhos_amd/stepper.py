@@ -109,7 +109,7 @@ class Stepper:
             except Exception as e:  # noqa: BLE001 -- every rank must take the same branch below
                 self.rccl_error = str(e)
             flag = torch.tensor([ok], device=self.dev)
-            d.all_reduce(flag, op=d.ReduceOp.MIN)
+            d.all_reduce(flag, op=d.ReduceOp.MIN)  # (backend nccl here: device tensor)
             ok = int(flag[0])
         if ok:
             self.transport = "rccl"

@@ -132,3 +132,30 @@ def test_autotest_lo4_through_stepper(lib):
     assert float(f"{mass:.10g}") == 0.1197299801
     assert float(f"{umax:.10g}") == 0.9997499683
     st.close()
+
+
+def test_timing_buckets_and_fom_semantics(lib):
+    """TimingData / PrintTimingData (remhos_tools.hpp:52-64, remhos.cpp:1918-1966) as rmhd_run reports them: with the
+    reference's call sequence (fused = 0) RHS+INV is the HO kernel (bucket RHS; INV is 0 because the mass solve runs
+    inside it), LO and FCT have their own kernels; every FOM is 1e-6 * dofs * stages / bucket; the printed total FOM
+    uses T_rhs + T_LO + T_FCT (omits INV, remhos.cpp:1933); the buckets are device time inside the wall clock."""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    r = RmhdResult()
+    cfg = make_config("periodic-cube", 3, 3, 10, -1.0, 0.5, max_steps=4, fused=0)
+    assert lib.rmhd_run(C.byref(cfg), C.byref(r)) == 0, lib.rmhd_last_error()
+    assert r.stages == 3 * r.steps == 12
+    assert r.t_rhs > 0 and r.t_lo > 0 and r.t_fct > 0 and r.t_inv == 0.0
+    assert abs(r.t_total - (r.t_rhs + r.t_lo + r.t_fct)) <= 1e-12
+    ds = 1e-6 * r.global_dofs * r.stages
+    for fom, t in ((r.fom_rhs, r.t_rhs), (r.fom_lo, r.t_lo), (r.fom_fct, r.t_fct), (r.fom, r.t_total), (r.fom_wall, r.wall)):
+        assert abs(fom - ds / t) <= 1e-9 * fom
+    # device time of the three buckets fits inside the wall clock of the loop, and is most of it (bounds / min-max
+    # kernels and the RK axpys are outside the buckets, like in the reference)
+    assert r.t_total <= r.wall and r.t_total > 0.3 * r.wall
+    # one-kernel stage: everything is charged to the RHS bucket
+    cfg = make_config("periodic-cube", 3, 3, 10, -1.0, 0.5, max_steps=4, fused=1)
+    assert lib.rmhd_run(C.byref(cfg), C.byref(r)) == 0, lib.rmhd_last_error()
+    assert r.t_rhs > 0 and r.t_lo == 0.0 and r.t_fct == 0.0 and abs(r.fom - ds / r.t_rhs) <= 1e-9 * r.fom
