@@ -252,6 +252,29 @@ __device__ inline const double *tab_view()
 #define RMH_TAB() tab_view<P>()
 #define RMH_TABK() (P >= 5 ? tab_view<P>() : gtb)
 
+// Synchronisation of an LDS hand-off between the lanes that own ONE element.  Where every (round, wavefront) of the dof
+// role holds exactly one element (p = 3: 64 dofs), the lanes of the hand-off are the lanes of one wavefront: its LDS
+// operations execute in order, so only the compiler must not reorder them -- no workgroup barrier.  Other orders: barrier.
+#ifndef RMH_WAVE_LOCAL
+#define RMH_WAVE_LOCAL 1
+#endif
+template <bool WAVE_LOCAL>
+__device__ inline void sync_element()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   if (WAVE_LOCAL)
+   {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   }
+   else { __syncthreads(); }
+#elif defined(HIPEMU)
+   if (WAVE_LOCAL) { hipemu_wave_sync(); }
+   else { __syncthreads(); }
+#endif
+}
+
 // a / b for well-scaled operands (mass, dt, PCG scalars: no denormals, no overflow, b != 0): hardware reciprocal,
 // two Newton steps and one correction of the quotient -- the core of the IEEE expansion without its scaling and
 // special-case fix-up (8 instead of ~14 instructions; ~30 divisions per wavefront were 12 % of the stage kernel's
@@ -1647,7 +1670,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          RMH_W(eb)[C::PCG + 27 + s3] = hi;
       }
       }
-      __syncthreads();
+      // (p = 3: the directions hand over within the wavefront that owns the element; one workgroup barrier at the end
+      // publishes the box table)
+      constexpr bool WL = RMH_WAVE_LOCAL && C::WAVE_ALIGNED;
+      if (dir < 2) { sync_element<WL>(); }
+      else { __syncthreads(); }
    }
    RMH_STAMP(16);
 #pragma unroll
