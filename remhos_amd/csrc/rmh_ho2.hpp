@@ -255,6 +255,9 @@ __device__ inline const double *tab_view()
 // Synchronisation of an LDS hand-off between the lanes that own ONE element.  Where every (round, wavefront) of the dof
 // role holds exactly one element (p = 3: 64 dofs), the lanes of the hand-off are the lanes of one wavefront: its LDS
 // operations execute in order, so only the compiler must not reorder them -- no workgroup barrier.  Other orders: barrier.
+#ifndef RMH_EARLY_PENCILS
+#define RMH_EARLY_PENCILS 1
+#endif
 #ifndef RMH_WAVE_LOCAL
 #define RMH_WAVE_LOCAL 1
 #endif
@@ -473,6 +476,41 @@ __device__ inline void load_batch(const HoArgs &a, const bool on, const int e0, 
                                   double (&gv)[NLX], double (&gu)[NLU])
 {
    constexpr int NT = C::NT, NB = C::NB, D2 = C::D2, D3 = C::D3;
+#if !RMH_PERSIST_LOOP
+   // Straight-line loads: lanes past the end of a list load its last entry again (never stored) instead of branching
+   // around the load.  With branches the compiler cannot count the loads in flight and drains ALL of them
+   // (s_waitcnt vmcnt(0)) where only the neighbour indices -- issued first -- are needed to issue the trace loads.
+   (void)on;
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
+   {
+      const int k = min(tid + j * NT, NB * 6 * D2 - 1);
+      const int eb = k / (6 * D2), f = (k % (6 * D2)) / D2;
+      nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.e_end - 1) * 6 + f];
+   }
+#pragma unroll
+   for (int j = 0; j < NLS; j++)
+   {
+      const int k = min(tid + j * NT, NB * 27 - 1);
+      sti[j] = -1;
+      if (FUSED) { sti[j] = a.stencil27[(size_t)min(e0 + k / 27, a.e_end - 1) * 27 + k % 27]; }
+   }
+#pragma unroll
+   for (int j = 0; j < NLX; j++)
+   {
+      const int k = min(tid + j * NT, NB * 81 - 1);
+      const int e = min(e0 + k / 81, a.e_end - 1);
+      gx0[j] = a.x0[(size_t)e * 81 + k % 81];
+      gv[j] = a.vel[(size_t)e * 81 + k % 81];
+   }
+#pragma unroll
+   for (int j = 0; j < NLU; j++)
+   {
+      const int k = min(tid + j * NT, NB * D3 - 1);
+      const int e = min(e0 + k / D3, a.e_end - 1);
+      gu[j] = a.u[(size_t)e * D3 + k % D3];
+   }
+#else
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
@@ -517,6 +555,7 @@ __device__ inline void load_batch(const HoArgs &a, const bool on, const int e0, 
          gu[j] = a.u[(size_t)e * D3 + k % D3];
       }
    }
+#endif
 }
 
 // FUSED = false: HOSolver::CalcHOSolution (writes du_HO, lumped mass, element extrema of u).
@@ -602,14 +641,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    constexpr int NLT = (C::N2 + NT - 1) / NT;
    double gtab[NLT];
 #pragma unroll
-   for (int j = 0; j < NLT; j++) { gtab[j] = (tid + j * NT < C::N2) ? a.tab[tid + j * NT] : 0.0; }
+   for (int j = 0; j < NLT; j++) { gtab[j] = a.tab[min(tid + j * NT, C::N2 - 1)]; }
    double gn[NLN];
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
-      const int k = tid + j * NT;
-      gn[j] = 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
-      if (k < NB * 6 * D2 && nbi[j] >= 0)
+      // (straight-line like load_batch: boundary faces and lanes past the list load a valid entry and drop it)
+      const int k = min(tid + j * NT, NB * 6 * D2 - 1);
       {
          const int r6 = k % (6 * D2);
          const int f = r6 / D2, r = r6 % D2;
@@ -619,12 +657,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int strc = (c == 0) ? 1 : (c == 1 ? D : D2);
          const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
          const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
-         const int nb = nbi[j];
+         const int nb = max(nbi[j], 0);
          const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
          // the neighbour's opposite face layer (compact ghost records hold exactly that layer, ordered like this face:
          // rmh_exchange_setup)
          const int off = (a.gh_compact && nb >= a.ne_owned) ? r : (side ? 0 : P) * strc + i1 * str1 + i2 * str2;
-         gn[j] = un[off];
+         const double v = un[off];
+         gn[j] = nbi[j] >= 0 ? v : 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
       }
    }
 #pragma unroll
@@ -644,12 +683,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       const int k = tid + j * NT;
       if (k < NB * D3) { RMH_W(k / D3)[oU + k % D3] = gu[j]; }
    }
+#if !RMH_EARLY_PENCILS
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
       const int k = tid + j * NT;
       if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
    }
+#endif
 #pragma unroll
    for (int j = 0; j < NLT; j++) { if (tid + j * NT < C::N2) { stab[tid + j * NT] = gtab[j]; } }
    if (FUSED)
@@ -798,7 +839,19 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          fl[3 * NS + m] = (fluct > 0.) ? fluct / (8 * umax - usum + eps) : fmin(0., fluct) / (8 * umin - usum - eps);
       }
    }
+#if RMH_EARLY_PENCILS
+   // The neighbour traces are the only loads that depend on another load (the neighbour index): they are not waited
+   // for at the first barrier but here, behind the x-pencils of u, which need none of them.
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
+   {
+      const int k = tid + j * NT;
+      if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
+   }
+   __syncthreads();
+#else
    if (LO4) { __syncthreads(); }
+#endif
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
@@ -906,7 +959,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[C::oF2 + (f * Q + q1) * D + k2] = tq2[k2]; }
       }
    }
+#if RMH_EARLY_PENCILS
+   // (the column phase reads the nodes and U1, both complete since the barrier above; the face rows' output is read
+   // after the next barrier -- only the lumped face fluxes of the RD scheme need it here)
+   if (LO4) { __syncthreads(); }
+#else
    __syncthreads();
+#endif
 
    if (LO4)
    {
