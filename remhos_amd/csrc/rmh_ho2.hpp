@@ -610,7 +610,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    const int nblk = (a.e_end - a.e_begin + NB - 1) / NB;
    int nbi[NLN], sti[NLS];
    double gx0[NLX], gv[NLX], gu[NLU];
-   int itmax = 0;
+   int itmax = 0, cg_known = 0;
    bool prefetched = false;
    // (only the fused stage is launched with a persistent grid: the other modes get one batch per workgroup and no
    // loop -- a back edge costs them registers in the column phase for nothing)
@@ -666,6 +666,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          gn[j] = nbi[j] >= 0 ? v : 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
       }
    }
+   // diagnostic: the largest iteration count so far, read here -- behind the element loads, a uniform load whose
+   // latency is covered by theirs -- so that a workgroup that does not raise it issues no atomic and waits for nothing
+   // (a stale value only costs a redundant atomicMax)
+   cg_known = HAS_HO ? *a.cg_iters : 0;
 #pragma unroll
    for (int j = 0; j < NLX; j++)
    {
@@ -1773,7 +1777,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       double mass[DR], vol[DR];
 #pragma unroll
       for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
-      if ((tid & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(L.cg_iters)) { atomicMax(L.cg_iters, itmax); }
+      if ((tid & 63) == 0 && itmax > cg_known) { atomicMax(L.cg_iters, itmax); }
       batch_dot2<C>(tid, tmp, mm, mass, vol, lds, s_acc, ring);
       RMH_STAMP(22);
       RMH_STAMP(17);
@@ -1933,7 +1937,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // address serialises at the memory side (~5 ns each: 3 ms per launch at 500 k wavefronts), so the
    // atomic is issued only when it can raise the (monotone) maximum.
    // (fused stage: done at the start of the limiter phase, in front of the L2 warm-up loads)
-   if (!FUSED && (tid0 & 63) == 0 && itmax > 0 && itmax > __builtin_nontemporal_load(a.cg_iters)) { atomicMax(a.cg_iters, itmax); }
+   if (!FUSED && (tid0 & 63) == 0 && itmax > cg_known) { atomicMax(a.cg_iters, itmax); }
    RMH_STAMP(7);
    RMH_STAMP_FLUSH();
 }
