@@ -1014,16 +1014,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    for (int qz = 0; qz < Q; qz++) { wd[qz] = 0; }
    if (col)
    {
-      double Ly[3], dLy[3], By[D], Gy[D];
+      double Ly[3], dLy[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) { Ly[k] = stab[oL + qy * 3 + k]; dLy[k] = stab[odL + qy * 3 + k]; }
-#pragma unroll
-      for (int k = 0; k < D; k++)
-      {
-         By[k] = stab[oB + qy * D + k];
-         Gy[k] = stab[oG + qy * D + k];
-         Bgy[k] = stab[oBg + qy * D + k];
-      }
       double Lx[3], dLx[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) { Lx[k] = stab[oL + qx * 3 + k]; dLx[k] = stab[odL + qx * 3 + k]; }
@@ -1099,6 +1092,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       // pass 2: grad u, D.grad u and the z-leg of the three test contractions
       const double *U1 = RMH_W(ceb) + oU1;
+      double By[D], Gy[D]; // (rows of qy for the u contractions: read behind the geometry pass, whose registers they would take)
+#pragma unroll
+      for (int k = 0; k < D; k++)
+      {
+         By[k] = stab[oB + qy * D + k];
+         Gy[k] = stab[oG + qy * D + k];
+      }
       double UB[D], UG[D], UU[D];
 #pragma unroll
       for (int iz = 0; iz < D; iz++)
@@ -1152,6 +1152,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          R3[(1 * Q2 + cc) * D + iz] = r1[iz];
          R3[(2 * Q2 + cc) * D + iz] = r2[iz];
       }
+      // (read here, not with the other rows of qy: it is first used by the mass apply and would only occupy registers
+      // through the column phase)
+#pragma unroll
+      for (int k = 0; k < D; k++) { Bgy[k] = stab[oBg + qy * D + k]; }
    }
    __syncthreads();
 
