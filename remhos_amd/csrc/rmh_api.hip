@@ -92,6 +92,19 @@ int create_tables(rmh_ctx *c)
    return upload(&c->d_tab, tab.data(), tab.size());
 }
 
+// face speed table of the kernels that read one (FaceGeo<P>::used): made on the context's stream the first time such
+// a kernel is launched
+template <int P>
+int ensure_face_table(rmh_ctx *c)
+{
+   if (c->d_fgeo) { return 0; }
+   RMH_HIP(hipMalloc((void **)&c->d_fgeo, (size_t)c->ne * FaceGeo<P>::PER_ELEM * sizeof(double)));
+   hipLaunchKernelGGL((face_geom_kernel<P>), dim3(c->ne), dim3(256), 0, c->stream, (const double *)c->d_x0,
+                      (const double *)c->d_vel, (const double *)c->d_tab, c->exec_mode == 1 ? 1 : 0, c->d_fgeo);
+   RMH_HIP(hipGetLastError());
+   return 0;
+}
+
 template <int P, int MODE>
 int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
 {
@@ -107,6 +120,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.tab = c->d_tab;
    a.subvel = c->d_subvel;
    a.subx0 = c->d_subx0;
+   a.fgeo = nullptr;
    a.subvmid = c->d_subvmid;
    a.du = du;
    a.m = m;
@@ -141,11 +155,21 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    {
       constexpr int P2 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the callers)
       constexpr int NB = K2Cfg<P2, true>::NB;
+      if (FaceGeo<P2>::used(2))
+      {
+         if (int rc = ensure_face_table<P2>(c)) { return rc; }
+         a.fgeo = c->d_fgeo;
+      }
       hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
    else
    {
       constexpr int NB = K2Cfg<P>::NB;
+      if (FaceGeo<P>::used(0))
+      {
+         if (int rc = ensure_face_table<P>(c)) { return rc; }
+         a.fgeo = c->d_fgeo;
+      }
       hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
@@ -168,6 +192,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.tab = c->d_tab;
    a.subvel = c->d_subvel;
    a.subx0 = c->d_subx0;
+   a.fgeo = nullptr;
    a.subvmid = c->d_subvmid;
    a.du = du;
    a.m = c->d_m;
@@ -206,6 +231,11 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P4, true, true>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = c->persist > 0 ? std::min(nblk, c->n_cu * C::WG_PER_CU * c->persist) : nblk;
+      if (FaceGeo<P4>::used(3))
+      {
+         if (int rc = ensure_face_table<P4>(c)) { return rc; }
+         a.fgeo = c->d_fgeo;
+      }
       hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3(grid), dim3(C::NT), 0, c->stream, a);
    }
    else
@@ -213,6 +243,11 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = c->persist > 0 ? std::min(nblk, c->n_cu * C::WG_PER_CU * c->persist) : nblk;
+      if (FaceGeo<P>::used(1))
+      {
+         if (int rc = ensure_face_table<P>(c)) { return rc; }
+         a.fgeo = c->d_fgeo;
+      }
       hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3(grid), dim3(C::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
@@ -354,7 +389,7 @@ void rmh_destroy(rmh_ctx *c)
    if (!c) { return; }
    (void)hipSetDevice(c->device);
    exchange_free(c);
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {

@@ -44,6 +44,7 @@ struct rmh_ctx
    double t = 0.0;
    double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
    double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
+   double *d_fgeo = nullptr;                        // face speed coefficients (face_geom_kernel)
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
    double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
    const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold

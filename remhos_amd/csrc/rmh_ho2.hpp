@@ -255,6 +255,14 @@ __device__ inline const double *tab_view()
 // Synchronisation of an LDS hand-off between the lanes that own ONE element.  Where every (round, wavefront) of the dof
 // role holds exactly one element (p = 3: 64 dofs), the lanes of the hand-off are the lanes of one wavefront: its LDS
 // operations execute in order, so only the compiler must not reorder them -- no workgroup barrier.  Other orders: barrier.
+// The upwind face speeds can come from a table made once per context (face_geom_kernel): w_q v.n_out(q, t) is a quadratic
+// in the pseudo-time t (the mesh moves linearly), three coefficients per face quadrature point.
+//   0: never; 1: in every kernel; 2: where it pays -- everywhere but the p = 3 HO / lo 5 kernels, which run at the
+//   board's power limit: there the FP64 work saved and the HBM bytes added cancel (tools/power_probe.py: same
+//   throughput at 130 MHz lower clocks), and the table would more than double the stage's HBM traffic.
+#ifndef RMH_FACE_COEF
+#define RMH_FACE_COEF 2
+#endif
 #ifndef RMH_EARLY_PENCILS
 #define RMH_EARLY_PENCILS 1
 #endif
@@ -468,6 +476,81 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
 
 #include "rmh_diag.hpp" // RMH_STAMP / RMH_STAMP_FLUSH: empty unless the diagnostic build -DRMH_STAMPS
 
+// Lane-dependent axis arithmetic without select chains: n^c for an axis c in {0, 1, 2} (n^2 < 256) is a byte of one
+// packed constant, (c + 1) % 3 and (c + 2) % 3 two bits of another (one shift-and-mask each; the ternaries they
+// replace were a third of the integer instructions of phase A).
+template <int N>
+__device__ inline int axis_stride(const int c)
+{
+   static_assert(N * N < 256, "stride does not fit a byte");
+   return ((1u | (unsigned)N << 8 | (unsigned)(N * N) << 16) >> (8 * c)) & 0xffu;
+}
+__device__ inline int axis_next(const int c) { return (0x09u >> (2 * c)) & 3u; }  // (c + 1) % 3
+__device__ inline int axis_next2(const int c) { return (0x12u >> (2 * c)) & 3u; } // (c + 2) % 3
+
+// Face geometry table.  On face f of an element, at the face quadrature point (q1, q2),
+//    w_q1 w_q2 (v . n_out)(t),   n_out = +-(dX/dxi1 x dX/dxi2),  X(t) = x0 + t v,
+// is the quadratic c0 + c1 t + c2 t^2 with c_k = +-w v.n_k, n_0 = T1x x T2x, n_1 = T1x x T2v + T1v x T2x, n_2 = T1v x T2v
+// (T1x, T1v: tangents of x0 and of v); a static mesh (transport) has c1 = c2 = 0.  What the face rows of ho_kernel2
+// evaluated from the 27 nodes every stage (DGTraceIntegrator set-up, remhos.cpp:651-657) is read from
+//    fgeo[e][q2][k][f*Q + q1]    (3 Q * 6 Q doubles per element)
+// instead: 2 FMAs per point in place of ~50, for HBM bytes the stage has to spare.
+template <int P>
+struct FaceGeo
+{
+   static constexpr int Q = K2Cfg<P>::Q, R = 6 * Q, PER_ELEM = 3 * Q * R;
+   // does ho_kernel2<P, MODE> read the table?
+   static constexpr bool used(int mode) { return RMH_FACE_COEF == 1 || (RMH_FACE_COEF == 2 && !(P == 3 && mode <= 1)); }
+};
+
+template <int P>
+__global__ void face_geom_kernel(const double *x0, const double *vel, const double *tab, const int move, double *fgeo)
+{
+   using C = K2Cfg<P>;
+   constexpr int Q = C::Q, R = 6 * Q;
+   const size_t e = blockIdx.x;
+   const double *X = x0 + e * 81, *V = vel + e * 81;
+   for (int pt = threadIdx.x; pt < R * Q; pt += blockDim.x)
+   {
+      const int q2 = pt / R, r = pt % R;
+      const int f = r / Q, q1 = r % Q;
+      const int c = f >> 1, side = f & 1;
+      const int n0 = side ? 2 * axis_stride<3>(c) : 0, n1 = axis_stride<3>(axis_next(c)), n2 = axis_stride<3>(axis_next2(c));
+      double t1x[3], t1v[3], t2x[3], t2v[3], vf[3];
+      for (int comp = 0; comp < 3; comp++)
+      {
+         double s1x = 0, s1v = 0, s2x = 0, s2v = 0, sv = 0;
+         for (int a2 = 0; a2 < 3; a2++)
+         {
+            const double L2 = tab[C::oL + q2 * 3 + a2], dL2 = tab[C::odL + q2 * 3 + a2];
+            for (int a1 = 0; a1 < 3; a1++)
+            {
+               const double L1 = tab[C::oL + q1 * 3 + a1], dL1 = tab[C::odL + q1 * 3 + a1];
+               const double x = X[comp * 27 + n0 + a1 * n1 + a2 * n2], v = V[comp * 27 + n0 + a1 * n1 + a2 * n2];
+               s1x += dL1 * L2 * x;
+               s2x += L1 * dL2 * x;
+               s1v += dL1 * L2 * v;
+               s2v += L1 * dL2 * v;
+               sv += L1 * L2 * v;
+            }
+         }
+         t1x[comp] = s1x; t2x[comp] = s2x; vf[comp] = sv;
+         t1v[comp] = move ? s1v : 0.0;
+         t2v[comp] = move ? s2v : 0.0;
+      }
+      double ck[3] = {0, 0, 0};
+      for (int comp = 0; comp < 3; comp++)
+      {
+         const int i = (comp + 1) % 3, j = (comp + 2) % 3;
+         ck[0] += vf[comp] * (t1x[i] * t2x[j] - t1x[j] * t2x[i]);
+         ck[1] += vf[comp] * (t1x[i] * t2v[j] - t1x[j] * t2v[i] + t1v[i] * t2x[j] - t1v[j] * t2x[i]);
+         ck[2] += vf[comp] * (t1v[i] * t2v[j] - t1v[j] * t2v[i]);
+      }
+      const double w = (side ? 1.0 : -1.0) * tab[C::oW + q1] * tab[C::oW + q2];
+      for (int k = 0; k < 3; k++) { fgeo[e * FaceGeo<P>::PER_ELEM + (size_t)(q2 * 3 + k) * R + r] = w * ck[k]; }
+   }
+}
+
 // Primary global loads of one element batch (phase A): face-neighbour indices, stencil indices (fused stage), Q2
 // nodes of x0 and v, u.  The fused stage calls it for the NEXT batch of a persistent workgroup at the start of its
 // limiter phase, so that the loads are in flight while the current batch finishes (see ho_kernel2).
@@ -653,10 +736,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int f = r6 / D2, r = r6 % D2;
          const int i1 = r % D, i2 = r / D;
          const int c = f >> 1, side = f & 1;
-         const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-         const int strc = (c == 0) ? 1 : (c == 1 ? D : D2);
-         const int str1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
-         const int str2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
+         const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
          const int nb = max(nbi[j], 0);
          const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
          // the neighbour's opposite face layer (compact ghost records hold exactly that layer, ordered like this face:
@@ -664,6 +744,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int off = (a.gh_compact && nb >= a.ne_owned) ? r : (side ? 0 : P) * strc + i1 * str1 + i2 * str2;
          const double v = un[off];
          gn[j] = nbi[j] >= 0 ? v : 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
+      }
+   }
+   // face speed coefficients of this thread's face rows (youngest loads: first used after the second barrier)
+   constexpr bool FC = FaceGeo<P>::used(MODE);
+   constexpr int NFR = (NB * 6 * Q + NT - 1) / NT;
+   double fgc[NFR][3 * Q];
+   if constexpr (FC)
+   {
+#pragma unroll
+      for (int jp = 0; jp < NFR; jp++)
+      {
+         const int fr = min(tid + jp * NT, NB * 6 * Q - 1);
+         const double *fg = a.fgeo + (size_t)min(e0 + fr / (6 * Q), a.e_end - 1) * FaceGeo<P>::PER_ELEM + fr % (6 * Q);
+#pragma unroll
+         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[k * 6 * Q]; }
       }
    }
    // diagnostic: the largest iteration count so far, read here -- behind the element loads, a uniform load whose
@@ -859,44 +954,48 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
-   for (int fr = tid; fr < NB * 6 * Q; fr += NT)
+#pragma unroll
+   for (int jp = 0; jp < NFR; jp++)
    {
+      const int fr = tid + jp * NT;
+      if (fr >= NB * 6 * Q) { break; }
       const int eb = fr / (6 * Q), r = fr % (6 * Q);
       const int f = r / Q, q1 = r % Q;
       const int c = f >> 1, side = f & 1;
-      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-      const int nc = (c == 0) ? 1 : (c == 1 ? 3 : 9);
-      const int n1 = (c1 == 0) ? 1 : (c1 == 1 ? 3 : 9);
-      const int n2s = (c2 == 0) ? 1 : (c2 == 1 ? 3 : 9);
-      const double *X = RMH_W(eb) + oXV + (side ? 2 * nc : 0);
-      const double *V = X + 81;
-      double L1[3], dL1[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) { L1[k] = stab[oL + q1 * 3 + k]; dL1[k] = stab[odL + q1 * 3 + k]; }
-      // contraction along a1 for the three node rows a2
+      const int c1 = axis_next(c), c2 = axis_next2(c);
       double xd[3][3], xl[3][3], vl[3][3]; // [comp][a2]
-#pragma unroll
-      for (int comp = 0; comp < 3; comp++)
+      double w1 = 0.0;
+      if constexpr (!FC)
       {
+         // geometry of the face from the nodes: contraction along a1 for the three node rows a2
+         const int nc = axis_stride<3>(c), n1 = axis_stride<3>(c1), n2s = axis_stride<3>(c2);
+         const double *X = RMH_W(eb) + oXV + (side ? 2 * nc : 0);
+         const double *V = X + 81;
+         double L1[3], dL1[3];
 #pragma unroll
-         for (int a2 = 0; a2 < 3; a2++)
+         for (int k = 0; k < 3; k++) { L1[k] = stab[oL + q1 * 3 + k]; dL1[k] = stab[odL + q1 * 3 + k]; }
+#pragma unroll
+         for (int comp = 0; comp < 3; comp++)
          {
-            double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-            for (int a1 = 0; a1 < 3; a1++)
+            for (int a2 = 0; a2 < 3; a2++)
             {
-               const double x = X[comp * 27 + a1 * n1 + a2 * n2s];
-               s0 += dL1[a1] * x;
-               s1 += L1[a1] * x;
-               s2 += L1[a1] * V[comp * 27 + a1 * n1 + a2 * n2s];
+               double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+               for (int a1 = 0; a1 < 3; a1++)
+               {
+                  const double x = X[comp * 27 + a1 * n1 + a2 * n2s];
+                  s0 += dL1[a1] * x;
+                  s1 += L1[a1] * x;
+                  s2 += L1[a1] * V[comp * 27 + a1 * n1 + a2 * n2s];
+               }
+               xd[comp][a2] = s0; xl[comp][a2] = s1; vl[comp][a2] = s2;
             }
-            xd[comp][a2] = s0; xl[comp][a2] = s1; vl[comp][a2] = s2;
          }
+         w1 = stab[oW + q1];
       }
       // traces: contraction of (u_nbr - u_own) along i1
-      const int dc = (c == 0) ? 1 : (c == 1 ? D : D2);
-      const int d1 = (c1 == 0) ? 1 : (c1 == 1 ? D : D2);
-      const int d2 = (c2 == 0) ? 1 : (c2 == 1 ? D : D2);
+      const int dc = axis_stride<D>(c), d1 = axis_stride<D>(c1), d2 = axis_stride<D>(c2);
       const double *uo = RMH_W(eb) + oU + (side ? P * dc : 0);
       const double *un = RMH_W(eb) + oNb + f * D2;
       double jr[D];
@@ -908,7 +1007,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * (un[i1 + D * i2] - uo[i1 * d1 + i2 * d2]); }
          jr[i2] = acc;
       }
-      const double w1 = stab[oW + q1];
       double tq[D], tq2[D];
 #pragma unroll
       for (int k2 = 0; k2 < D; k2++) { tq[k2] = 0.0; tq2[k2] = 0.0; }
@@ -916,30 +1014,38 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int q2 = 0; q2 < Q; q2++)
       {
          const double *gt = RMH_TABK();
-         double t1[3], t2[3], vf[3];
-#pragma unroll
-         for (int comp = 0; comp < 3; comp++)
+         double sq; // w_q1 w_q2 max(0, upw * v.n_out) at time t
+         if constexpr (FC)
          {
-            double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-            for (int a2 = 0; a2 < 3; a2++)
-            {
-               const double L2 = gt[oL + q2 * 3 + a2], dL2 = gt[odL + q2 * 3 + a2];
-               s0 += L2 * xd[comp][a2];
-               s1 += dL2 * xl[comp][a2];
-               s2 += L2 * vl[comp][a2];
-            }
-            t1[comp] = s0; t2[comp] = s1; vf[comp] = s2;
+            sq = fmax(0.0, a.upw * (fgc[jp][3 * q2] + a.t * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
          }
-         const double nx = t1[1] * t2[2] - t1[2] * t2[1];
-         const double ny = t1[2] * t2[0] - t1[0] * t2[2];
-         const double nz = t1[0] * t2[1] - t1[1] * t2[0];
-         double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
-         if (!side) { vn = -vn; }
+         else
+         {
+            double t1[3], t2[3], vf[3];
+#pragma unroll
+            for (int comp = 0; comp < 3; comp++)
+            {
+               double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+               for (int a2 = 0; a2 < 3; a2++)
+               {
+                  const double L2 = gt[oL + q2 * 3 + a2], dL2 = gt[odL + q2 * 3 + a2];
+                  s0 += L2 * xd[comp][a2];
+                  s1 += dL2 * xl[comp][a2];
+                  s2 += L2 * vl[comp][a2];
+               }
+               t1[comp] = s0; t2[comp] = s1; vf[comp] = s2;
+            }
+            const double nx = t1[1] * t2[2] - t1[2] * t2[1];
+            const double ny = t1[2] * t2[0] - t1[0] * t2[2];
+            const double nz = t1[0] * t2[1] - t1[1] * t2[0];
+            double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
+            if (!side) { vn = -vn; }
+            sq = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2];
+         }
          double jump = 0.0;
 #pragma unroll
          for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
-         const double sq = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2];
          if (HAS_HO)
          {
             const double val = sq * jump;

@@ -47,6 +47,7 @@ struct HoArgs
    const double *subvel;   // [ne][3][D3] sub-mesh node velocity (lo 4) or null
    const double *subx0;    // [ne][3][D3] sub-mesh start positions (set up once by subcell_setup_kernel)
    const double *subvmid;  // [ne][3][P^3] subcell midpoint velocity = mean of the 8 corner values
+   const double *fgeo;     // [ne][Q][3][6 Q] face speed coefficients (face_geom_kernel, rmh_ho2.hpp)
    double *du;             // [ne][D3]
    double *m;              // [ne][D3] lumped mass
    double *xe_min, *xe_max; // [ne]
