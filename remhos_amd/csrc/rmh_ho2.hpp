@@ -358,6 +358,28 @@ __device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double
       const double x = wave_sum((tid < C::NB * C::D3) ? v[0] : 0.0);
       if ((tid & 63) == 63 && (tid >> 6) < C::NB) { cur[tid >> 6] = x; }
    }
+   else if (C::NB == 1)
+   {
+      // one element per workgroup (p = 6): every thread adds its rounds, every wavefront reduces by DPP, the
+      // wavefront totals are added in order -- one barrier and no round trip of the values through LDS (the order of
+      // the sum is fixed by the dof -> (thread, round) map, which does not depend on where the element is)
+      constexpr int NW = C::NT / 64;
+      static_assert(C::NB != 1 || 4 * NW <= C::PART, "partial-sum ring does not fit");
+      double *slot = s_acc3 + 4 * C::NB + 8 + C::N2 + ring * NW;
+      double x = 0.0;
+#pragma unroll
+      for (int r = 0; r < C::DR; r++) { x += (tid + r * C::NT < C::D3) ? v[r] : 0.0; }
+      x = wave_sum(x);
+      if ((tid & 63) == 63) { slot[tid >> 6] = x; }
+      __syncthreads();
+      double tot = slot[0];
+#pragma unroll
+      for (int w = 1; w < NW; w++) { tot += slot[w]; }
+#pragma unroll
+      for (int r = 0; r < C::DR; r++) { out[r] = (tid + r * C::NT < C::D3) ? tot : 0.0; }
+      ring = (ring + 1) % 4;
+      return;
+   }
    else
    {
       // generic orders: deterministic two-level sum (no atomics: the result must not depend on the
@@ -464,6 +486,36 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
          const int t = tid + r * C::NT;
          outv[r] = (t < C::NB * C::D3) ? curv[t / C::D3] : 0.0;
          outw[r] = (t < C::NB * C::D3) ? curw[t / C::D3] : 0.0;
+      }
+      ring = (ring + 2) % 4;
+   }
+   else if (C::NB == 1)
+   {
+      // (see batch_dot: both sums behind one barrier)
+      constexpr int NW = C::NT / 64;
+      double *slotv = s_acc3 + 4 * C::NB + 8 + C::N2 + ring * NW;
+      double *slotw = s_acc3 + 4 * C::NB + 8 + C::N2 + ((ring + 1) % 4) * NW;
+      double x = 0.0, y = 0.0;
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const bool in = tid + r * C::NT < C::D3;
+         x += in ? v[r] : 0.0;
+         y += in ? w[r] : 0.0;
+      }
+      x = wave_sum(x);
+      y = wave_sum(y);
+      if ((tid & 63) == 63) { slotv[tid >> 6] = x; slotw[tid >> 6] = y; }
+      __syncthreads();
+      double totv = slotv[0], totw = slotw[0];
+#pragma unroll
+      for (int k = 1; k < NW; k++) { totv += slotv[k]; totw += slotw[k]; }
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const bool in = tid + r * C::NT < C::D3;
+         outv[r] = in ? totv : 0.0;
+         outw[r] = in ? totw : 0.0;
       }
       ring = (ring + 2) % 4;
    }
