@@ -39,6 +39,10 @@ namespace rmh
 // other LDS traffic) instead of scalar loads where the scalar registers cannot hold a plane's rows anyway; the same for
 // the three legs of the PCG's mass apply.  Measured (round 2, MDOFs*stage/s): p = 6 7.43 k -> 7.63 k -> 7.66 k; p = 5
 // -0.8 % / -8 %, p = 4 0, p = 3 -3.7 % (VGPR spills): on for p = 6 only
+// y-leg of the test contractions in place (p = 6: 30 -> 20 KB of LDS per workgroup, the sixth workgroup per CU)
+#ifndef RMH_INPLACE_Y
+#define RMH_INPLACE_Y (P == 6)
+#endif
 #ifndef RMH_COLTAB_LDS
 #define RMH_COLTAB_LDS (P >= 6)
 #endif
@@ -109,7 +113,9 @@ struct K2Cfg : TabLayout<P>
    // volume rhs by the 1-D change of test basis Cf in each direction (phi^B_i = sum_k C[k][i] l_k), not by a
    // fourth tensor through phases C-G.
    static constexpr int NR = 3;
-   static constexpr int oR3 = 0, oR2 = NR * Q2 * D, PF = oR2 + NR * Q * D2;
+   // INPLACE_Y: the y-leg writes its D outputs over the first D of the Q inputs of its own line (R2 inside R3)
+   static constexpr bool INPLACE_Y = RMH_INPLACE_Y;
+   static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * Q2 * D, PF = INPLACE_Y ? NR * Q2 * D : oR2 + NR * Q * D2;
    static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
    // lo 4 (subcell residual distribution) extras: sub-mesh node positions behind the phase A-C data,
    // subcell data [4][NS] and the lumped face flux per dof behind the face buffer
@@ -118,7 +124,7 @@ struct K2Cfg : TabLayout<P>
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
    // the sub-mesh nodes are consumed by the subcell pass before the face rows are formed: the
    // Bernstein-tested s rows of the RD solver take their place when HO and RD share the kernel
-   static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, PCG));
+   static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, PCG + (INPLACE_Y ? 108 : 0))); // (+108: stencil and box table of the fused limiter, see phase J)
    static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
    static constexpr int oF2 = BOTH ? oXs : oF;        // s rows (Bernstein basis) of the RD solver
    static constexpr int oSub = oF + RF, oDuf = oSub + 4 * NS;
@@ -143,7 +149,13 @@ struct K2Cfg : TabLayout<P>
 #define RMH_MAXW 8
 #endif
    static constexpr int WAVES_PER_SIMD0 = cmax(1, WG_PER_CU * (NT / 64) / 4);
-   static constexpr int WAVES_PER_SIMD = WAVES_PER_SIMD0 > RMH_MAXW ? RMH_MAXW : WAVES_PER_SIMD0;
+   // p = 6: LDS admits 5 workgroups of 2 wavefronts per CU = 2.5 per SIMD, which the registers only allow at <= 168
+   // VGPRs.  Asking for 3 costs 100 B/lane of scratch in the column phase and still wins (9.65 k -> 10.0 k
+   // MDOFs*stage/s; with the x-leg basis rows in registers through the PCG loop it was 248 B/lane and -12 %).
+#ifndef RMH_WAVES6
+#define RMH_WAVES6 3
+#endif
+   static constexpr int WAVES_PER_SIMD = P == 6 ? RMH_WAVES6 : (WAVES_PER_SIMD0 > RMH_MAXW ? RMH_MAXW : WAVES_PER_SIMD0);
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
@@ -260,6 +272,10 @@ __device__ inline const double *tab_view()
 //   0: never; 1: in every kernel; 2: where it pays -- everywhere but the p = 3 HO / lo 5 kernels, which run at the
 //   board's power limit: there the FP64 work saved and the HBM bytes added cancel (tools/power_probe.py: same
 //   throughput at 130 MHz lower clocks), and the table would more than double the stage's HBM traffic.
+// x-leg basis rows of a thread's dofs in registers through the PCG loop (see ho_kernel2, phase G)
+#ifndef RMH_CBG_REG
+#define RMH_CBG_REG (DR * Q <= 12)
+#endif
 #ifndef RMH_FACE_COEF
 #define RMH_FACE_COEF 2
 #endif
@@ -1330,7 +1346,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          double in[Q];
 #pragma unroll
          for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
-         double *dst = RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz; // [r][qx][iy + D*iz]
+         // [r][qx][iy + D*iz]; in place: [r][qx + Q*iy][iz], the first D entries of the line just read
+         double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz;
+         constexpr int dstr = C::INPLACE_Y ? Q * D : 1;
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
@@ -1342,7 +1360,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                const double w = (r == 0) ? gt[(HAS_HO ? oBg : oB) + jy * D + iy] : (r == 2 ? gt[oBg2 + jy * D + iy] : gt[oB + jy * D + iy]);
                acc += w * in[jy];
             }
-            dst[iy] = acc;
+            dst[iy * dstr] = acc;
          }
       }
    }
@@ -1385,14 +1403,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       if (LO4 && t < NB * D3) { uu4[r] = a.u[(size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3]; }
    }
    double rg[DR], mm[DR], dg[DR], zb[DR];
-   double cBg[DR][Q]; // column ix of the GL basis table of each dof of this thread (x-legs)
+   // column ix of the GL basis table of each dof of this thread (x-legs): kept in registers through the PCG loop where
+   // that is cheap (p <= 4); at p = 6 the 27 doubles starve the loop of registers -- every LDS read then reuses one
+   // temporary and waits for it (read, wait, two FMAs, read, ...) -- and the x-back leg reads its row from the table
+   constexpr bool CBG_REG = RMH_CBG_REG;
+   double cBg[CBG_REG ? DR : 1][Q];
 #pragma unroll
    for (int r = 0; r < DR; r++)
    {
       const int t = tid + r * NT;
       rg[r] = 0.0; mm[r] = 1.0; dg[r] = 1.0; zb[r] = 0.0;
+      if (CBG_REG)
+      {
 #pragma unroll
-      for (int jx = 0; jx < Q; jx++) { cBg[r][jx] = 0.0; }
+         for (int jx = 0; jx < Q; jx++) { cBg[CBG_REG ? r : 0][jx] = 0.0; }
+      }
       if (t < NB * D3)
       {
          const int eb = t / D3, i = t % D3;
@@ -1403,11 +1428,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int jx = 0; jx < Q; jx++)
          {
-            cBg[r][jx] = stab[(HAS_HO ? oBg : oB) + jx * D + ix];
+            const double bgx = stab[(HAS_HO ? oBg : oB) + jx * D + ix];
+            if (CBG_REG) { cBg[CBG_REG ? r : 0][jx] = bgx; }
             const double bx = stab[oB + jx * D + ix];
-            a0 += cBg[r][jx] * R2[(0 * Q + jx) * D2 + i2];
-            a1 += bx * R2[(1 * Q + jx) * D2 + i2];
-            if (HAS_HO) { a2 += stab[oBg2 + jx * D + ix] * R2[(2 * Q + jx) * D2 + i2]; }
+            // R2[r][jx][iy + D*iz] -- in place it sits at [r][jx + Q*iy][iz] of R3
+            const int o2 = C::INPLACE_Y ? (jx + Q * idx[1]) * D + idx[2] : jx * D2 + i2;
+            constexpr int rs2 = C::INPLACE_Y ? Q2 * D : Q * D2;
+            a0 += bgx * R2[0 * rs2 + o2];
+            a1 += bx * R2[1 * rs2 + o2];
+            if (HAS_HO) { a2 += stab[oBg2 + jx * D + ix] * R2[2 * rs2 + o2]; }
          }
          const double a0vol = a0;
          // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
@@ -1768,9 +1797,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int eb = t / D3, i = t % D3;
             const int i2 = i / D;
             const double *R2 = RMH_W(eb) + oM1 + i2;
+            const double *brow = stab + (HAS_HO ? oBg : oB) + i % D;
             double acc = 0.0;
 #pragma unroll
-            for (int jx = 0; jx < Q; jx++) { acc += cBg[r][jx] * R2[jx * S2]; }
+            for (int jx = 0; jx < Q; jx++) { acc += (CBG_REG ? cBg[CBG_REG ? r : 0][jx] : brow[jx * D]) * R2[jx * S2]; }
             Ad[r] = acc;
             tmp[r] = dd[r] * acc;
          }
