@@ -33,22 +33,23 @@ namespace rmh
 #define RMH_PERSIST_LOOP 0
 #endif
 
-// wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
-// other workgroups on the CU (0: off)
-// the qz loops of the column phase take their table rows from the LDS copy (uniform-address reads, in order with the
-// other LDS traffic) instead of scalar loads where the scalar registers cannot hold a plane's rows anyway; the same for
-// the three legs of the PCG's mass apply.  Measured (round 2, MDOFs*stage/s): p = 6 7.43 k -> 7.63 k -> 7.66 k; p = 5
-// -0.8 % / -8 %, p = 4 0, p = 3 -3.7 % (VGPR spills): on for p = 6 only
-// y-leg of the test contractions in place (p = 6: 30 -> 20 KB of LDS per workgroup, the sixth workgroup per CU)
+// y-leg of the test contractions in place (p = 6: 30 -> 21 KB of LDS per workgroup, the sixth workgroup per CU)
 #ifndef RMH_INPLACE_Y
 #define RMH_INPLACE_Y (P == 6)
 #endif
+// Table rows of the qz loops of the column phase / of the three legs of the PCG's mass apply from the LDS copy
+// (uniform-address reads, in order with the other LDS traffic) instead of scalar loads.  Measured at two wavefronts
+// per SIMD: p = 6 7.43 k -> 7.63 k (column) -> 7.66 k (PCG); p = 5 -0.8 % / -8 %, p = 4 0, p = 3 -3.7 %.  At three
+// wavefronts per SIMD (p = 6 now) the column phase is better off with scalar loads again (11.1 k -> 11.9 k, 100 -> 32
+// B/lane of scratch, 17 % fewer LDS instructions); the PCG legs keep the LDS copy (scalar: -0.5 %).
 #ifndef RMH_COLTAB_LDS
-#define RMH_COLTAB_LDS (P >= 6)
+#define RMH_COLTAB_LDS 0
 #endif
 #ifndef RMH_PCGTAB_LDS
 #define RMH_PCGTAB_LDS (P >= 6)
 #endif
+// wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
+// other workgroups on the CU (0: off)
 #ifndef RMH_PRIO
 #define RMH_PRIO 0
 #endif
