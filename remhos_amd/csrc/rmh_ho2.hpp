@@ -33,9 +33,10 @@ namespace rmh
 #define RMH_PERSIST_LOOP 0
 #endif
 
-// y-leg of the test contractions in place (p = 6: 30 -> 21 KB of LDS per workgroup, the sixth workgroup per CU)
+// y-leg of the test contractions in place: less LDS per workgroup, more workgroups per CU (p = 6: 30 -> 21 KB, the sixth
+// workgroup; p = 5: 11.5 k -> 12.7 k MDOFs*stage/s, p = 4: 13.4 k -> 14.1 k; p = 3: -1.3 %, the registers limit it anyway)
 #ifndef RMH_INPLACE_Y
-#define RMH_INPLACE_Y (P == 6)
+#define RMH_INPLACE_Y (P >= 4)
 #endif
 // Table rows of the qz loops of the column phase / of the three legs of the PCG's mass apply from the LDS copy
 // (uniform-address reads, in order with the other LDS traffic) instead of scalar loads.  Measured at two wavefronts
@@ -61,17 +62,18 @@ struct K2Cfg : TabLayout<P>
    using T = TabLayout<P>;
    static constexpr int D = T::D, Q = T::Q;
    static constexpr int D2 = D * D, D3 = D * D * D, Q2 = Q * Q;
-   // threads per workgroup: 256 (4 wavefronts, one per SIMD) -- 128 where the registers allow only 2 wavefronts per
-   // SIMD anyway (p = 6: 233 VGPRs): twice as many, half as large workgroups synchronise 2 instead of 4 wavefronts at
-   // each barrier (p = 6, -rs 4: 6.45 k -> 6.9 k MDOFs*stage/s; p = 4: 9.7 k -> 10.1 k; p = 5: no change, kept at 256)
+   // threads per workgroup: 256 (4 wavefronts, one per SIMD) at p <= 3, where several elements fill the lanes of the
+   // column phases.  p = 4, 5: ONE wavefront and one element per workgroup (Q^2 = 49 and 64 columns on 64 lanes): no
+   // barrier synchronises more than a wavefront, the element sums are a thread-local sum + one DPP wave sum
+   // (p = 4, -rs 4: 12.4 k -> 13.4 k MDOFs*stage/s; p = 5: 9.6 k -> 11.6 k).  p = 6 (81 columns): two wavefronts, one element.
 #ifndef RMH_NT6
 #define RMH_NT6 128
 #endif
 #ifndef RMH_NT5
-#define RMH_NT5 256
+#define RMH_NT5 64
 #endif
 #ifndef RMH_NT4
-#define RMH_NT4 128
+#define RMH_NT4 64
 #endif
 #ifndef RMH_NT3
 #define RMH_NT3 256
@@ -81,10 +83,10 @@ struct K2Cfg : TabLayout<P>
 #define RMH_NB6 1
 #endif
 #ifndef RMH_NB5
-#define RMH_NB5 4
+#define RMH_NB5 1
 #endif
 #ifndef RMH_NB4
-#define RMH_NB4 2
+#define RMH_NB4 1
 #endif
    // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
    // footprint would otherwise limit the CU to one workgroup (measured per order)
@@ -156,7 +158,10 @@ struct K2Cfg : TabLayout<P>
 #ifndef RMH_WAVES6
 #define RMH_WAVES6 3
 #endif
-   static constexpr int WAVES_PER_SIMD = P == 6 ? RMH_WAVES6 : (WAVES_PER_SIMD0 > RMH_MAXW ? RMH_MAXW : WAVES_PER_SIMD0);
+#ifndef RMH_WAVES5
+#define RMH_WAVES5 3
+#endif
+   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4 && RMH_WAVES5 > 0) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > RMH_MAXW ? RMH_MAXW : WAVES_PER_SIMD0));
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
