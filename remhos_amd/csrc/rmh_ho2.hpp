@@ -799,6 +799,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    double gtab[NLT];
 #pragma unroll
    for (int j = 0; j < NLT; j++) { gtab[j] = a.tab[min(tid + j * NT, C::N2 - 1)]; }
+   // RD solver: sub-mesh start positions and node velocities, in flight with everything else (a load-and-store loop
+   // in front of the first barrier exposed five memory round trips: 18 % of the lo 4 workgroup's cycles)
+   constexpr int NLSUB = LO4 ? (NB * 3 * D3 + NT - 1) / NT : 1;
+   double gsx[NLSUB], gsv[NLSUB];
+   if (LO4 && a.rd_subcell)
+   {
+#pragma unroll
+      for (int j = 0; j < NLSUB; j++)
+      {
+         const int k = min(tid + j * NT, NB * 3 * D3 - 1);
+         const size_t g = (size_t)min(e0 + k / (3 * D3), a.e_end - 1) * 3 * D3 + k % (3 * D3);
+         gsx[j] = a.subx0[g];
+         gsv[j] = a.move ? a.subvel[g] : 0.0;
+      }
+   }
    double gn[NLN];
 #pragma unroll
    for (int j = 0; j < NLN; j++)
@@ -880,12 +895,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    if (LO4 && a.rd_subcell)
    {
       // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
-      for (int k = tid; k < NB * 3 * D3; k += NT)
+#pragma unroll
+      for (int j = 0; j < NLSUB; j++)
       {
-         const int eb = k / (3 * D3), r3 = k % (3 * D3);
-         const size_t g = (size_t)min(e0 + eb, a.e_end - 1) * 3 * D3 + r3;
-         const double xs0 = a.subx0[g];
-         RMH_W(eb)[C::oXs + r3] = a.move ? xs0 + a.t * a.subvel[g] : xs0;
+         const int k = tid + j * NT;
+         if (k < NB * 3 * D3) { RMH_W(k / (3 * D3))[C::oXs + k % (3 * D3)] = a.move ? fma(a.t, gsv[j], gsx[j]) : gsx[j]; }
       }
    }
    __syncthreads();
