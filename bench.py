@@ -13,8 +13,8 @@ Workload (config.workload): BASELINE.json configs[1] -- 3D periodic-cube remap (
 Taylor-Green mesh motion, erfc bump), p = 3, -pa -ho 3 -lo 5 -fct 2 (the combination the reference
 itself allows on a device, remhos.cpp:391-397), refined to --rs levels (default 5: 884 736 hex,
 56.6 M dofs).  At N = 1 the same JSON line carries a "p6" block: BASELINE.json configs[2]
-(periodic-cube -rs 4 -o 6, 37.9 M dofs), timed after the p = 3 region with the same K and W, and
-"reference_mass_tol" side figures: the same runs with the element-local PCG stopped at the literal DGMassInverse
+(periodic-cube -rs 4 -o 6, 37.9 M dofs), timed after the p = 3 region with the same K and W.  `--side-figures` adds
+"reference_mass_tol" blocks: the same runs with the element-local PCG stopped at the literal DGMassInverse
 tolerance of remhos_ho.cpp:79-80 (abs 1e-8) instead of converged to rel 1e-14 (never `value`).
 
 N > 1 (one process per GPU, RCCL): `--scaling weak` (default) keeps one -rs 5 block per GPU -- the lattice is
@@ -312,6 +312,10 @@ def main():
     ap.add_argument("--ref-mass-tol", action="store_true",
                     help="local mass solve with the reference's DGMassInverse tolerances (abs 1e-8, rel 0: remhos_ho.cpp:79-80) "
                          "instead of rel 1e-14 (see DESIGN.md 4)")
+    ap.add_argument("--side-figures", action="store_true",
+                    help="add `reference_mass_tol` blocks: the same runs with the local PCG stopped at the literal tolerance of "
+                         "remhos_ho.cpp:79-80 (off by default: their launches would mix into the per-kernel averages of a profile "
+                         "of the default command)")
     ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
     args = ap.parse_args()
     if args.gpus not in PART:
@@ -373,7 +377,7 @@ def main():
                 "avg_launch_ms": r["roofline"]["avg_launch_ms"]}
 
     ref_tol, ref_tol6 = None, None
-    if world == 1 and default_case and not args.ref_mass_tol and not args.no_p6:
+    if world == 1 and default_case and not args.ref_mass_tol and not args.no_p6 and args.side_figures:
         ref_tol = with_reference_tolerance(args.order, args.rs)
         ref_tol6 = with_reference_tolerance(6, 4)
 
