@@ -44,6 +44,20 @@ if f:
     print("\n== per-kernel durations from kernel_trace (all launches; ms) ==")
     for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         print(f"{k[:90]:90s} n={len(v):5d} avg={sum(v)/len(v):9.4f} min={min(v):9.4f} max={max(v):9.4f} total={sum(v):10.3f}")
+    # the timed region of bench.py: the last 3 * steps launches of each stage kernel (the warm-up launches before it
+    # run colder and slower, and at p = 3 the first launch after the synchronisation that opens the region pays for
+    # the power ramp: about twice the steady duration)
+    try:
+        steps = json.loads([l for l in open(os.path.join(out, "bench_traced.json")) if l.startswith("{")][-1])["steps"]
+    except Exception:  # noqa: BLE001
+        steps = None
+    if steps:
+        print(f"\n== stage kernels, timed region only (last {3 * steps} launches; ms) ==")
+        for k, v in by.items():
+            if "ho_kernel2" in k and len(v) >= 3 * steps:
+                t = v[-3 * steps:]
+                med = sorted(t)[len(t) // 2]
+                print(f"{k[:60]:60s} n={len(t):4d} avg={sum(t)/len(t):8.4f} median={med:8.4f} first={t[0]:8.4f} max={max(t):8.4f}")
     r0 = next((r for r in rows if "ho_kernel" in r["Kernel_Name"]), None)
     if r0:
         keys = [k for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r0]
