@@ -279,6 +279,10 @@ __device__ inline const double *tab_view()
 //   board's power limit: there the FP64 work saved and the HBM bytes added cancel (tools/power_probe.py: same
 //   throughput at 130 MHz lower clocks), and the table would more than double the stage's HBM traffic.
 // x-leg basis rows of a thread's dofs in registers through the PCG loop (see ho_kernel2, phase G)
+// p = 6: pencil-type phases split over the two wavefronts (see split_outputs)
+#ifndef RMH_SPLIT2
+#define RMH_SPLIT2 1
+#endif
 #ifndef RMH_CBG_REG
 #define RMH_CBG_REG (DR * Q <= 12)
 #endif
@@ -550,6 +554,29 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
 
 #include "rmh_diag.hpp" // RMH_STAMP / RMH_STAMP_FLUSH: empty unless the diagnostic build -DRMH_STAMPS
 
+// Two-wavefront workgroups with one element (p = 6): the pencil-type phases have fewer tasks than a wavefront has
+// lanes (49 x-pencils, 63 (q, iz) lines), so the second wavefront would only wait at the next barrier.  Instead both
+// wavefronts take every task and each computes HALF of its outputs: the instruction stream of the phase halves.
+// split_outputs<SPL, N>(wv, f) calls f(lo, hi) with compile-time bounds: [0, N) without splitting, [0, H) on wavefront 0
+// and [H, N) on wavefront 1 otherwise (wv is wavefront-uniform: a scalar branch).
+template <int V>
+struct IntC
+{
+   static constexpr int value = V;
+   constexpr operator int() const { return V; }
+};
+template <bool SPL, int N, class F>
+__device__ inline void split_outputs(const int wv, F &&f)
+{
+   if constexpr (!SPL) { f(IntC<0>{}, IntC<N>{}); }
+   else
+   {
+      constexpr int H = (N + 1) / 2;
+      if (wv == 0) { f(IntC<0>{}, IntC<H>{}); }
+      else { f(IntC<H>{}, IntC<N>{}); }
+   }
+}
+
 // Lane-dependent axis arithmetic without select chains: n^c for an axis c in {0, 1, 2} (n^2 < 256) is a byte of one
 // packed constant, (c + 1) % 3 and (c + 2) % 3 two bits of another (one shift-and-mask each; the ternaries they
 // replace were a third of the integer instructions of phase A).
@@ -785,6 +812,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    asm volatile("" : "+s"(zt_));
 #endif
    const int tid = tid_;
+   // (p = 6) split of the pencil-type phases over the two wavefronts of the workgroup, see split_outputs
+   constexpr bool SPL = RMH_SPLIT2 && NT == 128 && NB == 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+   const int wv = SPL ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+#else
+   const int wv = SPL ? tid >> 6 : 0;
+#endif
+   const int ptid = SPL ? (tid & 63) : tid; // task index of this thread in a split phase
+   constexpr int PNT = SPL ? 64 : NT;
    const double *gtb = c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
    const double *gt = gtb;
    (void)gt;
@@ -935,7 +971,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
    }
    // U1[eb][(kind*Q + qx)*S2 + i2], kind 0: B.u, 1: G.u; pencil tasks (eb, i2)
-   for (int k = tid; k < NB * D2; k += NT)
+   static_assert(!SPL || NB * D2 <= 64, "split phases: one task per lane");
+   for (int k = ptid; k < NB * D2; k += PNT)
    {
       const int eb = k / D2, i2 = k % D2;
       const double *src = RMH_W(eb) + oU + D * i2;
@@ -943,20 +980,22 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int ix = 0; ix < D; ix++) { uu[ix] = src[ix]; }
       double *dst = RMH_W(eb) + oU1 + i2;
+      split_outputs<SPL, Q>(wv, [&](auto qlo, auto qhi) {
 #pragma unroll
-      for (int q = 0; q < Q; q++)
-      {
-         const double *gt = RMH_TABK();
-         double ub = 0.0, ug = 0.0;
-#pragma unroll
-         for (int ix = 0; ix < D; ix++)
+         for (int q = qlo; q < qhi; q++)
          {
-            ub += gt[oB + q * D + ix] * uu[ix];
-            ug += gt[oG + q * D + ix] * uu[ix];
+            const double *gt = RMH_TABK();
+            double ub = 0.0, ug = 0.0;
+#pragma unroll
+            for (int ix = 0; ix < D; ix++)
+            {
+               ub += gt[oB + q * D + ix] * uu[ix];
+               ug += gt[oG + q * D + ix] * uu[ix];
+            }
+            dst[(0 * Q + q) * S2] = ub;
+            dst[(1 * Q + q) * S2] = ug;
          }
-         dst[(0 * Q + q) * S2] = ub;
-         dst[(1 * Q + q) * S2] = ug;
-      }
+      });
    }
    RMH_STAMP(1);
    if (LO4)
@@ -1355,12 +1394,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 
    RMH_STAMP(3);
    // ---- phase F: y-leg of the three test contractions (R2 overlays U1) ---------------------------------
-   for (int k = tid; k < NB * Q * D; k += NT)
+   // (split workgroups: the three tensors are divided between the wavefronts -- r = 0, 1 / r = 2 -- not the outputs of
+   // a line: in place, a line's outputs overwrite its own inputs)
+   for (int k = ptid; k < NB * Q * D; k += PNT)
    {
       const int eb = k / (Q * D), rem = k % (Q * D);
       const int q = rem / D, iz = rem % D;
+      split_outputs<SPL, C::NR>(wv, [&](auto rlo, auto rhi) {
 #pragma unroll
-      for (int r = 0; r < C::NR; r++)
+      for (int r = rlo; r < rhi; r++)
       {
          const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
          double in[Q];
@@ -1383,6 +1425,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             dst[iy * dstr] = acc;
          }
       }
+      });
    }
    if (HAS_HO)
    {
@@ -1732,7 +1775,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       __syncthreads();
       if (!s_flag[it & 1]) { break; } // no element of the batch is active any more
       RMH_STAMP(10);
-      for (int k = tid; k < NB * D2; k += NT)
+      for (int k = ptid; k < NB * D2; k += PNT)
       {
          const int eb = k / D2, i2 = k % D2;
          const double *src = RMH_W(eb) + oSA + D * i2;
@@ -1740,15 +1783,17 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int ix = 0; ix < D; ix++) { in[ix] = src[ix]; }
          double *dst = RMH_W(eb) + oM1 + i2;
+         split_outputs<SPL, Q>(wv, [&](auto qlo, auto qhi) {
 #pragma unroll
-         for (int q = 0; q < Q; q++)
-         {
-            const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
-            double acc = 0.0;
+            for (int q = qlo; q < qhi; q++)
+            {
+               const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
+               double acc = 0.0;
 #pragma unroll
-            for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
-            dst[q * S2] = acc;
-         }
+               for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
+               dst[q * S2] = acc;
+            }
+         });
       }
       __syncthreads();
       RMH_STAMP(11);
@@ -1784,7 +1829,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       __syncthreads();
       RMH_STAMP(12);
-      for (int k = tid; k < NB * Q * D; k += NT)
+      static_assert(!SPL || NB * Q * D <= 64, "split phases: one task per lane");
+      for (int k = ptid; k < NB * Q * D; k += PNT)
       {
          const int eb = k / (Q * D), rem = k % (Q * D);
          const int q = rem / D, iz = rem % D;
@@ -1793,15 +1839,17 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
          double *dst = RMH_W(eb) + oM1 + q * S2 + D * iz;
+         split_outputs<SPL, D>(wv, [&](auto ylo, auto yhi) {
 #pragma unroll
-         for (int iy = 0; iy < D; iy++)
-         {
-            const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
-            double acc = 0.0;
+            for (int iy = ylo; iy < yhi; iy++)
+            {
+               const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
+               double acc = 0.0;
 #pragma unroll
-            for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
-            dst[iy] = acc;
-         }
+               for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
+               dst[iy] = acc;
+            }
+         });
       }
       __syncthreads();
       RMH_STAMP(13);
