@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root: python tests/sweep_parity.py
 from oracle.remhos_oracle import Config, Remhos  # noqa: E402
 from remhos_amd.capi import Context, load_library  # noqa: E402
 from tests.helpers import layout_from_oracle, perturbed  # noqa: E402
