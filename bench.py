@@ -273,7 +273,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
             "alg_bytes_per_launch": ho_bytes,
             "achieved_is": "ALGORITHMIC bytes of SURVEY 8(d) (matrix-free model) / launch time -- a model figure, not measured HBM GB/s; "
                            "the measured HBM bytes per launch are `traffic`",
-            "binding_resource": "fp64 valu (volume geometry is recomputed from the 27 nodes per stage: ~150 kflop/element at p=3); the p=3 stage runs at the board power limit (tools/power_probe.py); see roofline_fp64 and DESIGN.md 3.1",
+            "binding_resource": "fp64 valu (volume geometry is recomputed from the 27 nodes per stage: ~150 kflop/element at p=3); the p=3 stage runs at or near the board power limit (tools/power_probe.py); see roofline_fp64 and DESIGN.md 3.1",
         },
         "roofline_fp64": fp64,
         "buckets_s": {"ho_rhs_plus_inv_or_stage": tim[0], "lo": tim[2], "fct_or_fused_limiter": tim[3]},
