@@ -186,7 +186,9 @@ def test_lo_rdsubcell_parity(gpu, mesh, rs, p, prob, t):
 @pytest.mark.parametrize("mesh,rs,p,prob,t", [("cube01_hex", 2, 3, 10, 0.5), ("periodic-cube", 1, 3, 10, 0.4),
                                              ("cube01_hex", 1, 2, 10, 0.3), ("periodic-cube", 1, 1, 10, 0.6),
                                              ("periodic-cube", 1, 3, 0, 0.0), ("cube01_hex", 1, 4, 10, 0.3),
-                                             ("cube01_hex", 0, 6, 10, 0.3)])
+                                             ("cube01_hex", 0, 6, 10, 0.3),
+                                             # one-wavefront workgroups + face speed table on a periodic mesh (p = 5)
+                                             ("periodic-cube", 0, 5, 10, 0.4), ("periodic-cube", 0, 5, 0, 0.0)])
 def test_one_kernel_stage(gpu, mesh, rs, p, prob, t):
     """rmh_stage_fused: HO + MassBasedAvg + bounds + ClipScale + RK update in one kernel, against the
     oracle's stage and against the multi-kernel path; also the element extrema it leaves for the next
@@ -238,7 +240,8 @@ def test_one_kernel_stage(gpu, mesh, rs, p, prob, t):
 
 
 @pytest.mark.parametrize("mesh,rs,p,prob,t", [("cube01_hex", 2, 3, 10, 0.5), ("periodic-cube", 1, 3, 0, 0.0),
-                                             ("cube01_hex", 1, 2, 10, 0.3), ("cube01_hex", 1, 4, 10, 0.3)])
+                                             ("cube01_hex", 1, 2, 10, 0.3), ("cube01_hex", 1, 4, 10, 0.3),
+                                             ("cube01_hex", 0, 6, 10, 0.3), ("periodic-cube", 0, 5, 10, 0.4)])
 def test_one_kernel_stage_lo4(gpu, mesh, rs, p, prob, t):
     """rmh_stage_fused with rmh_set_lo_type(4): HO + subcell RD + bounds + ClipScale + RK update in one kernel
     (geometry and face data shared by the two solvers) against the oracle's lo 4 stage."""
