@@ -146,6 +146,58 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+class SmiSampler:
+    """Shader clock and socket power from rocm-smi while the timed region runs (a host-side subprocess in its own
+    thread; best effort: any failure just leaves the list empty)."""
+
+    def __init__(self):
+        import threading
+
+        self.samples, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def allowed():
+        """Not under a profiler: its preloaded tool library would be inherited by the child process."""
+        env = os.environ
+        pre = env.get("LD_PRELOAD", "").lower()
+        return not (any(w in pre for w in ("rocprof", "roctracer", "rocprofiler")) or env.get("HSA_TOOLS_LIB")
+                    or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in env))
+
+    def _run(self):
+        import re
+        import shutil
+
+        smi = shutil.which("rocm-smi")
+        if not smi:
+            return
+        smi = os.path.realpath(smi)
+        # (the script is started with this interpreter directly: no `env` hop; a plain environment)
+        cmd = [sys.executable, smi] if smi.endswith(".py") else [smi]
+        env = dict(os.environ)
+        while not self._stop.is_set():
+            try:
+                t = time.perf_counter()
+                txt = subprocess.run(cmd + ["--showclocks", "--showpower"], capture_output=True, text=True, timeout=3, env=env).stdout
+                sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
+                if sclk and pw:
+                    self.samples.append((0.5 * (t + time.perf_counter()), int(sclk.group(1)), float(pw.group(1))))
+            except Exception:  # noqa: BLE001
+                return
+            self._stop.wait(0.02)
+
+    def start(self):
+        self._thread.start()
+
+    def stop(self, t0, t1):
+        self._stop.set()
+        self._thread.join(timeout=5)
+        inside = [s for s in self.samples if t0 <= s[0] <= t1]
+        return {"samples_in_timed_region": len(inside), "sclk_MHz": [s[1] for s in inside], "power_W": [s[2] for s in inside],
+                "source": "rocm-smi --showclocks --showpower, sampled from a host thread during the timed region"}
+
+
 def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters=True):
     """Set up one configuration, time K steps after W warm-up steps, return the result fields."""
     import torch
@@ -173,6 +225,9 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
             dist.barrier()
         torch.cuda.synchronize()
 
+    smi = SmiSampler() if (world == 1 and not args.no_smi and SmiSampler.allowed()) else None
+    if smi:
+        smi.start()
     for _ in range(args.warmup):
         st.step(dt)
     st.ctx.last_cg_iters()  # reset
@@ -184,6 +239,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
         st.step(dt)
     barrier()
     elapsed = time.perf_counter() - t0
+    smi_info = smi.stop(t0, t0 + elapsed) if smi else None
     tim = st.ctx.timers()
     st.ctx.enable_timers(False)
     cg_iters = st.ctx.last_cg_iters()
@@ -276,6 +332,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
             "binding_resource": "fp64 valu (volume geometry is recomputed from the 27 nodes per stage: ~150 kflop/element at p=3); the p=3 stage runs at or near the board power limit (tools/power_probe.py); see roofline_fp64 and DESIGN.md 3.1",
         },
         "roofline_fp64": fp64,
+        "smi": smi_info,
         "buckets_s": {"ho_rhs_plus_inv_or_stage": tim[0], "lo": tim[2], "fct_or_fused_limiter": tim[3]},
         # the reference's figures of merit (remhos.cpp:1918-1966): 1e-6 * dofs * stages / bucket time of rank 0; its
         # printed total uses T_rhs + T_LO + T_FCT.  Here RHS and INV are one kernel (bucket 0); with the one-kernel
@@ -312,6 +369,7 @@ def main():
     ap.add_argument("--ref-mass-tol", action="store_true",
                     help="local mass solve with the reference's DGMassInverse tolerances (abs 1e-8, rel 0: remhos_ho.cpp:79-80) "
                          "instead of rel 1e-14 (see DESIGN.md 4)")
+    ap.add_argument("--no-smi", action="store_true", help="do not sample rocm-smi (clock, power) during the timed region")
     ap.add_argument("--side-figures", action="store_true",
                     help="add `reference_mass_tol` blocks: the same runs with the local PCG stopped at the literal tolerance of "
                          "remhos_ho.cpp:79-80 (off by default: their launches would mix into the per-kernel averages of a profile "
