@@ -113,11 +113,17 @@ public:
    TimingData *timer = nullptr;
 };
 
-// remhos_ho.hpp:56-68, PA branch remhos_ho.cpp:119-128
+// remhos_ho.hpp:56-68, remhos_ho.cpp:72-128.  The reference's constructor looks at the assembly level of M: partial
+// assembly -> DGMassInverse with SetAbsTol(1e-8), SetRelTol(0) (remhos_ho.cpp:79-80), otherwise the exact dense inverse of
+// every element (:104-115).  Here the level is a constructor argument and selects the rule of the same element-local PCG:
+//   partial_assembly = true : stop at (D^-1 r, r) <= (1e-8)^2 like DGMassInverse, then the two completion steps of
+//                             rmh_set_mass_completion (one Jacobi step on the left-over residual, constant mode) -- no
+//                             further mass apply, mass conserved to round-off per stage;
+//   partial_assembly = false: converged to rel. 1e-14, the stand-in for the exact inverse.
 class LocalInverseHOSolver : public HOSolver
 {
 public:
-   LocalInverseHOSolver(ParFiniteElementSpace &space) : HOSolver(space) {}
+   LocalInverseHOSolver(ParFiniteElementSpace &space, bool partial_assembly = true);
    void CalcHOSolution(const Vector &u, Vector &du) const override;
 };
 

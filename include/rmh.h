@@ -307,6 +307,16 @@ int rmh_last_cg_iters(rmh_ctx *ctx, int *max_iters);
  * the reference's abs 1e-8. */
 int rmh_set_mass_tol(rmh_ctx *ctx, double rel_tol, double abs_tol, int max_iter);
 int rmh_get_mass_tol(rmh_ctx *ctx, double *rel_tol, double *abs_tol, int *max_iter);
+/* Completion of the local mass solve (no counterpart in the reference: DGMassInverse::Mult, remhos_ho.cpp:126, returns
+ * whatever its stopping rule leaves).  Two steps behind the PCG loop, neither needs another mass apply:
+ *   jacobi_step   = 1: x += D^-1 r with the residual r the PCG recurrence leaves (D: the Jacobi diagonal it preconditions
+ *                      with).  On the nearly affine elements of a refined mesh D^-1 M = I + O(h): about one more order
+ *                      of accuracy for free; a converged solve is not changed.
+ *   constant_mode = 1: du_HO += (1^T b - sum_i m_i du_HO,i) / |element|.  Both bases sum to one, so 1^T b is the exact
+ *                      integral of M^-1 b over the element and sum m du_HO that of the computed one: every stage then
+ *                      conserves the mass to round-off for ANY stopping rule (rmh_set_mass_tol).
+ * Default: both off (the solve is converged to rel_tol 1e-14 instead). */
+int rmh_set_mass_completion(rmh_ctx *ctx, int jacobi_step, int constant_mode);
 
 #ifdef __cplusplus
 }

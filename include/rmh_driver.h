@@ -34,6 +34,10 @@ typedef struct {
    int save;          /* -save: write meshHO_init/final.mesh and sltn_init/final.gf (cwd)        */
    int rs_extra[3];   /* additional uniform refinements per direction (0: the reference's meshes;
                          bench.py's weak-scaling lattices refine the partitioned directions once more) */
+   int pa;            /* -pa : which local mass solve -ho 3 stands for (remhos_ho.cpp:72-82, 90-128):
+                         0 full assembly -- the exact element inverse (here: PCG converged to rel. 1e-14);
+                         1 partial assembly -- DGMassInverse with abs. tolerance 1e-8, rel. 0 (here: the same stopping
+                           rule, completed by rmh_set_mass_completion(1, 1))                                        */
 } rmhd_config;
 
 typedef struct {

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_lo_rd", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range",
     "rmh_halo_pack_records", "rmh_set_ghost_records", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
-    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
+    "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_mass_completion", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
     "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
     "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce",
@@ -106,6 +106,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_last_cg_iters.argtypes = [p, C.POINTER(i)]
     lib.rmh_set_mass_tol.argtypes = [p, d, d, i]
     lib.rmh_get_mass_tol.argtypes = [p, C.POINTER(d), C.POINTER(d), C.POINTER(i)]
+    lib.rmh_set_mass_completion.argtypes = [p, i, i]
     lib.rmh_set_lo_type.argtypes = [p, i]
     lib.rmh_set_bounds_type.argtypes = [p, i]
     lib.rmh_invalidate_extrema.argtypes = [p]
@@ -367,3 +368,6 @@ class Context:
 
     def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
         self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))
+
+    def set_mass_completion(self, jacobi_step=True, constant_mode=True):
+        self._check(self.lib.rmh_set_mass_completion(self.h, int(bool(jacobi_step)), int(bool(constant_mode))))

@@ -51,7 +51,8 @@ int main(int argc, char **argv)
       else if (a == "-rank") { c.rank = std::atoi(next()); }
       else if (a == "-dev") { device = std::atoi(next()); }
       else if (a == "-comm-file") { comm_file = next(); }
-      else if (a == "-pa" || a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
+      else if (a == "-pa") { c.pa = 1; }
+      else if (a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { if (std::atoi(next()) != 3) { std::fprintf(stderr, "only -s 3 (RK3 SSP)\n"); return 3; } }
       else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
    }

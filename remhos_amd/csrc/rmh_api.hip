@@ -140,6 +140,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.rel2 = c->rel_tol * c->rel_tol;
    a.abs2 = c->abs_tol * c->abs_tol;
    a.max_iter = c->max_iter;
+   a.mass_fix = c->mass_fix;
+   a.jacobi_step = c->jacobi_step;
    a.stencil27 = c->d_st27;
    a.gh_min = c->gh_min;
    a.gh_max = c->gh_max;
@@ -209,6 +211,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.rel2 = c->rel_tol * c->rel_tol;
    a.abs2 = c->abs_tol * c->abs_tol;
    a.max_iter = c->max_iter;
+   a.mass_fix = c->mass_fix;
+   a.jacobi_step = c->jacobi_step;
    a.stencil27 = c->d_st27;
    a.gh_min = c->gh_min;
    a.gh_max = c->gh_max;
@@ -850,6 +854,17 @@ int rmh_set_mass_tol(rmh_ctx *c, double rel_tol, double abs_tol, int max_iter)
    c->rel_tol = rel_tol;
    c->abs_tol = abs_tol;
    c->max_iter = max_iter;
+   return RMH_OK;
+}
+
+int rmh_set_mass_completion(rmh_ctx *c, int jacobi_step, int constant_mode)
+{
+   if (!c || jacobi_step < 0 || jacobi_step > 1 || constant_mode < 0 || constant_mode > 1)
+   {
+      return fail(RMH_ERR_INVALID, "mass completion: flags are 0 or 1");
+   }
+   c->jacobi_step = jacobi_step;
+   c->mass_fix = constant_mode;
    return RMH_OK;
 }
 

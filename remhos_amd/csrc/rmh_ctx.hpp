@@ -54,6 +54,7 @@ struct rmh_ctx
    int gh_compact = 0; // 1: ghost records are [min | max | D^2 face trace] cells (rmh_exchange_setup, compact)
    double rel_tol = 1e-14, abs_tol = 0.0;
    int max_iter = 100;
+   int jacobi_step = 0, mass_fix = 0; // completion of the local mass solve (rmh_set_mass_completion)
    bool ho_done = false;
    int bounds_type = 0; // DofInfo bounds type (-bt): 0 overlap, 1 face neighbours
    double *d_dt_est = nullptr; // running minimum of UpdateTimeStepEstimate; null while dt control is off

@@ -106,6 +106,21 @@ void TimingData::Update(rmh_ctx *ctx)
 }
 
 // ---- solvers: forward to the C ABI ------------------------------------------------------------
+LocalInverseHOSolver::LocalInverseHOSolver(ParFiniteElementSpace &space, bool partial_assembly) : HOSolver(space)
+{
+   // remhos_ho.cpp:77-81 (M_inv->SetAbsTol(1e-8), M_inv->SetRelTol(0.0)) / :104-115 (exact element inverse)
+   if (partial_assembly)
+   {
+      RMH_CALL(rmh_set_mass_tol(pfes.Ctx(), 0.0, 1e-8, 100));
+      RMH_CALL(rmh_set_mass_completion(pfes.Ctx(), 1, 1));
+   }
+   else
+   {
+      RMH_CALL(rmh_set_mass_tol(pfes.Ctx(), 1e-14, 0.0, 100));
+      RMH_CALL(rmh_set_mass_completion(pfes.Ctx(), 0, 0));
+   }
+}
+
 void LocalInverseHOSolver::CalcHOSolution(const Vector &u, Vector &du) const
 {
    RMH_VERIFY(timer, "Timer not set."); // remhos_ho.cpp:86
@@ -334,7 +349,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       // solver factory of remhos.cpp:912-925, 927-995 for the options on the path
       HOSolver *ho_solver = nullptr;
       if (cfg->ho_type == 2) { ho_solver = new CGHOSolver(pfes); }
-      else { ho_solver = new LocalInverseHOSolver(pfes); }
+      else { ho_solver = new LocalInverseHOSolver(pfes, cfg->pa != 0); }
       LOSolver *lo_solver = nullptr;
       if (cc.lo_type == 5) { lo_solver = new MassBasedAvg(pfes, *ho_solver, nullptr); }
       else if (cc.lo_type == 3) { lo_solver = new PAResidualDistribution(pfes); }
@@ -566,6 +581,12 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       RMHD_TRY(rmh_set_bounds_type(b.ctx, cfg->bounds_type));
       if (cfg->dt_control) { RMHD_TRY(rmh_set_dt_control(b.ctx, 1)); }
       if (cfg->ho_type == 2) { RMHD_TRY(rmh_set_mass_tol(b.ctx, 1e-12, 0.0, 500)); }
+      else if (cfg->pa)
+      {
+         // LocalInverseHOSolver on a partially assembled M (remhos_ho.cpp:77-81): DGMassInverse's rule, completed
+         RMHD_TRY(rmh_set_mass_tol(b.ctx, 0.0, 1e-8, 100));
+         RMHD_TRY(rmh_set_mass_completion(b.ctx, 1, 1));
+      }
       b.vsize = b.cd.ne_owned * b.cd.ndof;
       const size_t bytes = sizeof(double) * (size_t)b.vsize;
       RMHD_HIP(hipMalloc((void **)&b.x, bytes));

@@ -127,7 +127,10 @@ struct K2Cfg : TabLayout<P>
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
    // the sub-mesh nodes are consumed by the subcell pass before the face rows are formed: the
    // Bernstein-tested s rows of the RD solver take their place when HO and RD share the kernel
-   static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, PCG + (INPLACE_Y ? 108 : 0))); // (+108: stencil and box table of the fused limiter, see phase J)
+   // (+108: stencil and box table of the fused limiter, see phase J; +2: the element's sum of the right-hand side and
+   // its volume, kept from the PCG prelude to the constant-mode completion, see batch_dot_keep2)
+   static constexpr int oKeep = PCG + 108;
+   static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, oKeep + 2));
    static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
    static constexpr int oF2 = BOTH ? oXs : oF;        // s rows (Bernstein basis) of the RD solver
    static constexpr int oSub = oF + RF, oDuf = oSub + 4 * NS;
@@ -549,6 +552,107 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
    {
       batch_dot<C>(tid, v, outv, lds, s_acc3, ring);
       batch_dot<C>(tid, w, outw, lds, s_acc3, ring);
+   }
+}
+
+// Three element sums behind one barrier, for the prelude of the mass solve: v -> outv (broadcast to the dof threads
+// like batch_dot), and w, z -> the two KEPT doubles of the element block (oKeep, oKeep + 1), which later phases read
+// from LDS (no registers held through the PCG loop).  The next reduction must be separated from this call by a barrier
+// (three ring slots are in use in the one-element path): the PCG loop starts with one.
+template <class C>
+__device__ inline void batch_dot_keep2(const int tid, const double (&v)[C::DR], const double (&w)[C::DR], const double (&z)[C::DR],
+                                       double (&outv)[C::DR], double *lds, double *s_acc3, int &ring)
+{
+   if (C::WAVE_ALIGNED && C::DR == 2)
+   {
+      const int lane = tid & 63, wave = tid >> 6;
+      double *cur = s_acc3 + ring * C::NB;
+      const bool has1 = tid + C::NT < C::NB * C::D3;
+      double v0 = v[0], v1 = has1 ? v[C::DR == 2 ? 1 : 0] : 0.0;
+      double w0 = w[0], w1 = has1 ? w[C::DR == 2 ? 1 : 0] : 0.0;
+      double z0 = z[0], z1 = has1 ? z[C::DR == 2 ? 1 : 0] : 0.0;
+      swap32(v0, v1);
+      swap32(w0, w1);
+      swap32(z0, z1);
+      double x = v0 + v1;
+      double xa = w0 + w1, xb = z0 + z1;
+      swap16(xa, xb);
+      double y = xa + xb; // rows: {w round 0, z round 0, w round 1, z round 1}
+      x = dpp_add_all<0xB1>(x);
+      y = dpp_add_all<0xB1>(y);
+      x = dpp_add_all<0x4E>(x);
+      y = dpp_add_all<0x4E>(y);
+      x = dpp_add_all<0x141>(x);
+      y = dpp_add_all<0x141>(y);
+      x = dpp_add_all<0x140>(x);
+      y = dpp_add_all<0x140>(y);
+      x = dpp_add<0x142, 0xA>(x);
+      const int e1 = C::NT / C::D3 + wave;
+      if (lane == 31) { cur[wave] = x; }
+      if (lane == 63 && e1 < C::NB) { cur[e1] = x; }
+      if (lane == 15) { (lds + wave * C::EL)[C::oKeep] = y; }
+      if (lane == 31) { (lds + wave * C::EL)[C::oKeep + 1] = y; }
+      if (lane == 47 && e1 < C::NB) { (lds + e1 * C::EL)[C::oKeep] = y; }
+      if (lane == 63 && e1 < C::NB) { (lds + e1 * C::EL)[C::oKeep + 1] = y; }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const int t = tid + r * C::NT;
+         outv[r] = (t < C::NB * C::D3) ? cur[t / C::D3] : 0.0;
+      }
+      ring = (ring + 1) % 4;
+   }
+   else if (C::NB == 1)
+   {
+      constexpr int NW = C::NT / 64;
+      double *slot = s_acc3 + 4 * C::NB + 8 + C::N2;
+      double *sv = slot + ring * NW, *sw = slot + ((ring + 1) % 4) * NW, *sz = slot + ((ring + 2) % 4) * NW;
+      double x = 0.0, y = 0.0, q = 0.0;
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const bool in = tid + r * C::NT < C::D3;
+         x += in ? v[r] : 0.0;
+         y += in ? w[r] : 0.0;
+         q += in ? z[r] : 0.0;
+      }
+      x = wave_sum(x);
+      y = wave_sum(y);
+      q = wave_sum(q);
+      if ((tid & 63) == 63) { sv[tid >> 6] = x; sw[tid >> 6] = y; sz[tid >> 6] = q; }
+      __syncthreads();
+      double totv = sv[0];
+#pragma unroll
+      for (int k = 1; k < NW; k++) { totv += sv[k]; }
+      if (tid == 0)
+      {
+         double totw = sw[0], totz = sz[0];
+#pragma unroll
+         for (int k = 1; k < NW; k++) { totw += sw[k]; totz += sz[k]; }
+         lds[C::oKeep] = totw;
+         lds[C::oKeep + 1] = totz;
+      }
+#pragma unroll
+      for (int r = 0; r < C::DR; r++) { outv[r] = (tid + r * C::NT < C::D3) ? totv : 0.0; }
+      ring = (ring + 3) % 4;
+   }
+   else
+   {
+      double ow[C::DR], oz[C::DR];
+      batch_dot<C>(tid, v, outv, lds, s_acc3, ring);
+      batch_dot<C>(tid, w, ow, lds, s_acc3, ring);
+      batch_dot<C>(tid, z, oz, lds, s_acc3, ring);
+#pragma unroll
+      for (int r = 0; r < C::DR; r++)
+      {
+         const int t = tid + r * C::NT;
+         if (t < C::NB * C::D3 && t % C::D3 == 0)
+         {
+            (lds + (t / C::D3) * C::EL)[C::oKeep] = ow[r];
+            (lds + (t / C::D3) * C::EL)[C::oKeep + 1] = oz[r];
+         }
+      }
    }
 }
 
@@ -1748,7 +1852,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       tmp[r] = rg[r] * dd[r];
       its[r] = 0;
    }
-   batch_dot<C>(tid, tmp, nom, lds, s_acc, ring);
+   // nom = r.z; kept for the constant-mode completion behind the back-transform: the sum of the right-hand side (the
+   // element's exact mass rate 1^T b, both bases sum to one) and the element's volume 1^T M 1 = sum of the lumped mass
+   batch_dot_keep2<C>(tid, tmp, rg, mm, nom, lds, s_acc, ring);
    bool act[DR];
    {
       bool any = false;
@@ -1886,6 +1992,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          tmp[r] = rg[r] * (rg[r] * dg[r]);
       }
       RMH_STAMP(14);
+      // capped solve (rmh_set_mass_tol with max_iter applies): the last admitted iteration ends with the update of x and
+      // r -- its r.z would only decide about an iteration that is not going to happen
+      if (it == a.max_iter - 1)
+      {
+#pragma unroll
+         for (int r = 0; r < DR; r++) { its[r] += act[r] ? 1 : 0; }
+         break;
+      }
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // betanom = r.z
       RMH_STAMP(15);
       bool any = false;
@@ -1906,6 +2020,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    }
 
    RMH_STAMP(6);
+   // Completion of the solve, part 1 (rmh_set_mass_completion): one Jacobi step x += D^-1 r with the residual the PCG
+   // recurrence leaves behind -- no mass apply, no reduction; on the nearly affine elements of a refined mesh, where
+   // D^-1 M = I + O(h), it gains the solve about one more order in h (nothing for a converged solve).
+   if (HAS_HO && L.jacobi_step)
+   {
+#pragma unroll
+      for (int r = 0; r < DR; r++) { xg[r] += rg[r] * dg[r]; }
+   }
    // ---- phase J: back to Bernstein coefficients x_b = Ci (x) Ci (x) Ci x_g, stores --------------------------
    // (no barrier before the sA slot is overwritten: the PCG loop is left by all threads at the same point -- after
    // the barrier that follows its sA write, or after the barrier of its last reduction -- and nothing reads sA
@@ -2002,8 +2124,24 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    RMH_STAMP(16);
 #pragma unroll
    for (int r = 0; r < DR; r++) { itmax = max(itmax, its[r]); }
+   // Completion of the solve, part 2: the constant mode.  The integral of du_HO over the element is sum_i m_i x_i
+   // (m: lumped mass, x: Bernstein coefficients), that of the exact solution 1^T b; the constant (1^T b - sum m x) /
+   // |element| closes the gap, so that every stage conserves the mass to round-off for ANY stopping rule of the PCG --
+   // and whatever the round-off of the back-transform was.  Both kept sums come from the PCG prelude.
    if (!FUSED)
    {
+      if (L.mass_fix)
+      {
+#pragma unroll
+         for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * xg[r]; }
+         batch_dot<C>(tid, tmp, red, lds, s_acc, ring);
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            if (t < NB * D3) { xg[r] += fdiv(RMH_W(t / D3)[C::oKeep] - red[r], RMH_W(t / D3)[C::oKeep + 1]); }
+         }
+      }
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -2034,11 +2172,26 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       RMH_STAMP(21);
       // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
+      // (with the constant-mode completion: du_HO += c, and the element's new mass is sum m u + dt 1^T b)
       double mass[DR], vol[DR];
 #pragma unroll
-      for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * (uu[r] + L.dt * xg[r]); }
+      for (int r = 0; r < DR; r++)
+      {
+         tmp[r] = mm[r] * uu[r];
+         red[r] = mm[r] * xg[r];
+      }
       if ((tid & 63) == 0 && itmax > cg_known) { atomicMax(L.cg_iters, itmax); }
-      batch_dot2<C>(tid, tmp, mm, mass, vol, lds, s_acc, ring);
+      batch_dot2<C>(tid, tmp, red, mass, vol, lds, s_acc, ring);
+#pragma unroll
+      for (int r = 0; r < DR; r++)
+      {
+         const int t = tid + r * NT;
+         const double sb = (t < NB * D3) ? RMH_W(t / D3)[C::oKeep] : 0.0, ev = (t < NB * D3) ? RMH_W(t / D3)[C::oKeep + 1] : 1.0;
+         const double rate = L.mass_fix ? sb : vol[r]; // integral of du_HO over the element
+         xg[r] += L.mass_fix ? fdiv(sb - vol[r], ev) : 0.0;
+         mass[r] += L.dt * rate;
+         vol[r] = ev;
+      }
       RMH_STAMP(22);
       RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];

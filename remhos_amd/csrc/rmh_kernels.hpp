@@ -60,6 +60,8 @@ struct HoArgs
    double upw;             // upwind sign: s = max(0, upw * v.n_out): -1 transport, +1 remap
    double rel2, abs2;      // squared tolerances of the local PCG
    int max_iter;
+   int jacobi_step;        // completion of the local solve (rmh_set_mass_completion): 1: x += D^-1 r behind the PCG loop
+   int mass_fix;           //   1: constant mode -- du_HO += (1^T b - sum m du_HO) / |element| behind the back-transform
    // fused stage (ho_kernel2<P, true>): LimitMult for -lo 5 -fct 2 and the RK update in the same kernel
    const int *stencil27;            // [ne][27]
    const double *gh_min, *gh_max;   // ghost element extrema, element g at [g * gh_mstride]

@@ -41,6 +41,11 @@ class Stepper:
             self.ctx.set_lo_type(self.lo)
         if getattr(case.cfg, "ho_type", 3) == 2:
             self.ctx.set_mass_tol(1e-12, 0.0, 500)  # CGHOSolver (-ho 2, remhos_ho.cpp:60-63): see solvers.hpp
+        elif getattr(case.cfg, "pa", 0):
+            # LocalInverseHOSolver on a partially assembled M: DGMassInverse's stopping rule (remhos_ho.cpp:79-80),
+            # completed by one Jacobi step and the constant mode (include/remhos_amd/solvers.hpp)
+            self.ctx.set_mass_tol(0.0, 1e-8, 100)
+            self.ctx.set_mass_completion(True, True)
         self.dtc = bool(getattr(case.cfg, "dt_control", 0))
         if getattr(case.cfg, "bounds_type", 0):
             self.ctx.set_bounds_type(case.cfg.bounds_type)
@@ -101,16 +106,28 @@ class Stepper:
         want_rccl = d.get_backend() == "nccl" and _os.environ.get("RMH_EXCHANGE", "rccl") == "rccl"
         ok = 0
         if want_rccl:
+            # Every collective below is entered by every rank whatever happened locally (a rank that skipped one while
+            # the others wait in it would hang the job).  1. can this rank reach RCCL at all?  rmh_comm_unique_id goes
+            # through the same dlopen / symbol table as rmh_comm_init; the id of ranks other than 0 is discarded.
+            my_id = None
             try:
-                box = [self.ctx.comm_unique_id() if d.get_rank() == 0 else None]
-                d.broadcast_object_list(box, src=0)
-                self.ctx.comm_init(box[0], d.get_world_size(), d.get_rank())
-                ok = 1
-            except Exception as e:  # noqa: BLE001 -- every rank must take the same branch below
+                my_id = self.ctx.comm_unique_id()
+            except Exception as e:  # noqa: BLE001
                 self.rccl_error = str(e)
-            flag = torch.tensor([ok], device=self.dev)
+            flag = torch.tensor([1 if my_id is not None else 0], device=self.dev)
             d.all_reduce(flag, op=d.ReduceOp.MIN)  # (backend nccl here: device tensor)
-            ok = int(flag[0])
+            if int(flag[0]):
+                # 2. all ranks can: rank 0's id to everybody, then the communicator (ncclCommInitRank is itself collective)
+                box = [my_id if d.get_rank() == 0 else None]
+                d.broadcast_object_list(box, src=0)
+                try:
+                    self.ctx.comm_init(box[0], d.get_world_size(), d.get_rank())
+                    ok = 1
+                except Exception as e:  # noqa: BLE001
+                    self.rccl_error = str(e)
+                flag = torch.tensor([ok], device=self.dev)
+                d.all_reduce(flag, op=d.ReduceOp.MIN)
+                ok = int(flag[0])
         if ok:
             self.transport = "rccl"
             return
