@@ -206,3 +206,39 @@ def test_bounds_type_1_and_dt_control(lib):
     res = RmhdResult()
     assert lib.rmhd_run(C.byref(make_config(mesh, rs, p, prob, dt, tf, lo_type=4, dt_control=1)), C.byref(res)) != 0
     assert b"requires -bt 1" in lib.rmhd_last_error()
+
+
+@pytest.mark.parametrize("p", [2, 3, 4])
+def test_mass_completion_emulated(lib, p):
+    """rmh_set_mass_completion under the host emulation: with the constant mode the element's mass rate sum m du equals
+    the converged solve's for a solve capped at one PCG iteration and for the reference's rule (abs 1e-8,
+    remhos_ho.cpp:79-80), stand-alone HO kernel and one-kernel stage; the Jacobi step moves the field towards the
+    converged one.  (GPU twin: tests/test_gpu_mass_completion.py.)"""
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh="cube01_hex", rs=0, order=p, problem=10, dt=0.02, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    u = perturbed(r.u)
+    t = 0.5
+    ctx.setup(t)
+    m = np.zeros_like(u)
+    ctx.compute_lumped_mass(t, m)
+    res = {}
+    rules = dict(conv=(1e-14, 0, 100, 0, 0), cap1=(0, 0, 1, 0, 0), cap1fix=(0, 0, 1, 0, 1), cap1all=(0, 0, 1, 1, 1), refall=(0, 1e-8, 100, 1, 1))
+    for name, (rel, ab, it, jac, fix) in rules.items():
+        ctx.set_mass_tol(rel, ab, it)
+        ctx.set_mass_completion(jac, fix)
+        du, y, d2 = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+        ctx.ho_apply(u, du)
+        ctx.stage_fused(u, cfg.dt, y, du=d2)
+        res[name] = (du, (m * du).sum(axis=1), (m * d2).sum(axis=1))
+    ref = res["conv"]
+    sc = np.abs(ref[1]).max()
+    for k in ("cap1fix", "cap1all", "refall"):
+        assert np.abs(res[k][1] - ref[1]).max() < 1e-13 * sc and np.abs(res[k][2] - ref[2]).max() < 1e-13 * sc, k
+    assert np.abs(res["cap1"][1] - ref[1]).max() > 1e-4 * sc
+    assert np.abs(res["cap1all"][0] - ref[0]).max() < 0.5 * np.abs(res["cap1fix"][0] - ref[0]).max()
+    ctx.close()

@@ -34,10 +34,14 @@ KAT = [
 
 @pytest.mark.parametrize("name,kw,mass_ref,rtol", KAT, ids=[k[0] for k in KAT])
 @pytest.mark.parametrize("fused", [1, 0])
-def test_reference_final_mass(lib, name, kw, mass_ref, rtol, fused):
+@pytest.mark.parametrize("pa", [0, 1])
+def test_reference_final_mass(lib, name, kw, mass_ref, rtol, fused, pa):
+    """pa = 0: the local mass solve converged (the reference's exact element inverse, ctest #3's path); pa = 1:
+    DGMassInverse's stopping rule abs 1e-8 (remhos_ho.cpp:79-80, ctest #7's path) completed by the Jacobi step and
+    the constant mode (rmh_set_mass_completion).  Both must give the reference's 17-digit masses."""
     from remhos_amd.case import RmhdResult, make_config
 
-    cfg = make_config(fused=fused, **kw)
+    cfg = make_config(fused=fused, pa=pa, **kw)
     res = RmhdResult()
     assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, lib.rmhd_last_error()
     assert res.steps == kw["max_steps"]
@@ -96,6 +100,20 @@ AUTOTEST_LO3 = [
     ("cube01_hex remap -ho 2 -lo 4", dict(mesh="cube01_hex", rs=1, order=2, problem=10, dt=0.02, t_final=0.7, lo_type=4, ho_type=2),
      0.1197299801, 0.9997499683, 50),
 ]
+
+
+@pytest.mark.parametrize("name,kw,mass,umax,steps", AUTOTEST_LO4, ids=[k[0] for k in AUTOTEST_LO4])
+def test_autotest_baseline_lo4_pa_rule(lib, name, kw, mass, umax, steps):
+    """The same printed digits with the -pa rule of the local mass solve (DGMassInverse's abs 1e-8 + completion): the
+    coarse cube01_hex mesh takes up to 8 PCG iterations under it instead of 14."""
+    from remhos_amd.case import RmhdResult, make_config
+
+    cfg = make_config(fused=1, pa=1, **kw)
+    res = RmhdResult()
+    assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, lib.rmhd_last_error()
+    assert res.steps == steps
+    assert float(f"{res.final_mass:.10g}") == mass
+    assert float(f"{res.max_value:.10g}") == umax
 
 
 @pytest.mark.parametrize("fused", [0, 1])

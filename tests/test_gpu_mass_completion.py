@@ -1,0 +1,102 @@
+"""The completion of the element-local mass solve (rmh_set_mass_completion, include/rmh.h): one Jacobi step on the
+residual the PCG leaves and the constant mode.  Reference semantics: LocalInverseHOSolver on a partially assembled mass
+matrix stops DGMassInverse at abs 1e-8 (remhos_ho.cpp:79-80, 126); its mass defect per element and stage is the sum of the
+left-over residual.  What is checked here, on the GPU through the C ABI:
+  * with the constant mode, sum_i m_i du_i of every element equals that of the converged solve to round-off for ANY
+    stopping rule (capped at one iteration, the reference's rule), stand-alone HO kernel and one-kernel stage, all orders;
+  * without it the same rules leave the defect the reference's rule has (so the test can fail);
+  * the Jacobi step brings the loosely solved field closer to the converged one, and neither step changes a converged
+    solve beyond round-off;
+  * whole runs at the -pa rule: final mass within 1e-12 relative of the converged run's, field within 1e-9.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+
+    assert torch.cuda.is_available()
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+
+    return bind_driver(load_library())
+
+
+RULES = {  # rel_tol, abs_tol, max_iter, jacobi_step, constant_mode
+    "converged": (1e-14, 0.0, 100, 0, 0),
+    "converged+completion": (1e-14, 0.0, 100, 1, 1),
+    "cap1": (0.0, 0.0, 1, 0, 0),
+    "cap1+constant": (0.0, 0.0, 1, 0, 1),
+    "cap1+completion": (0.0, 0.0, 1, 1, 1),
+    "reference": (0.0, 1e-8, 100, 0, 0),
+    "reference+completion": (0.0, 1e-8, 100, 1, 1),
+}
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6])
+def test_element_mass_rate_is_exact_for_any_rule(lib, p):
+    import torch
+
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(lib, make_config("cube01_hex", 2, p, 10, -1.0, 0.5))
+    st = Stepper(lib, case, device="cuda:0")
+    for _ in range(2):
+        st.step(case.dt)  # a state with some structure
+    u = st.x.clone()
+    t = st.t
+    ctx = st.ctx
+    ctx.setup(t)
+    m = torch.empty_like(u)
+    ctx.compute_lumped_mass(t, m)
+    out = {}
+    for name, (rel, ab, it, jac, fix) in RULES.items():
+        ctx.set_mass_tol(rel, ab, it)
+        ctx.set_mass_completion(jac, fix)
+        du_ho, y, du = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+        ctx.ho_apply(u, du_ho)
+        ctx.invalidate_extrema()
+        ctx.stage_fused(u, case.dt, y, du=du)
+        torch.cuda.synchronize()
+        out[name] = (du_ho.cpu().numpy(), (m * du_ho).sum(dim=1).cpu().numpy(), (m * du).sum(dim=1).cpu().numpy())
+    ref = out["converged"]
+    scale = np.abs(ref[1]).max()
+    dev = {k: (np.abs(v[0] - ref[0]).max() / np.abs(ref[0]).max(), np.abs(v[1] - ref[1]).max() / scale,
+               np.abs(v[2] - ref[2]).max() / scale) for k, v in out.items()}
+    print(p, {k: tuple(f"{x:.1e}" for x in v) for k, v in dev.items()})
+    cond = {1: 1, 2: 1, 3: 10, 4: 30, 5: 300, 6: 3000}[p]  # conditioning of the GL <-> Bernstein change of basis
+    for k in ("converged+completion", "cap1+constant", "cap1+completion", "reference+completion"):
+        assert dev[k][1] < 5e-14 * cond and dev[k][2] < 5e-14 * cond, (k, dev[k])
+    # the constant mode is what does it: the capped solve alone is off by orders of magnitude more
+    assert dev["cap1"][1] > 1e3 * dev["cap1+constant"][1]
+    # the Jacobi step improves the loose solve; a converged one is not changed beyond round-off
+    assert dev["cap1+completion"][0] < 0.5 * dev["cap1+constant"][0]
+    assert dev["converged+completion"][0] < 1e-12 * cond
+    st.close()
+
+
+@pytest.mark.parametrize("mesh,rs,p,steps", [("periodic-cube", 3, 3, 6), ("cube01_hex", 3, 4, 4), ("periodic-cube", 2, 2, 8)])
+def test_pa_rule_run_against_converged_run(lib, mesh, rs, p, steps):
+    """Whole runs: the -pa rule (remhos_ho.cpp:79-80 + completion) against the converged solve on the same mesh."""
+    import torch
+
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    res = {}
+    for pa in (0, 1):
+        st = Stepper(lib, Case(lib, make_config(mesh, rs, p, 10, -1.0, 0.5, pa=pa)), device="cuda:0")
+        st.run(max_steps=steps)
+        torch.cuda.synchronize()
+        res[pa] = (st.local_mass_and_max(), st.x.clone(), st.ctx.last_cg_iters())
+        st.close()
+    (m0, x0, it0), (m1, x1, it1) = res[0], res[1]
+    print(mesh, rs, p, "iterations", it0, it1, "mass rel dev", (m1[0] - m0[0]) / m0[0], "field", float((x1 - x0).abs().max()))
+    assert it1 < it0
+    assert abs(m1[0] - m0[0]) <= 1e-12 * abs(m0[0])
+    assert float((x1 - x0).abs().max()) < 1e-9

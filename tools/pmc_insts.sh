@@ -5,8 +5,8 @@ tag=$1; shift
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $out/a -o pmc -- python3 bench.py "$@" --no-cpu-baseline --no-smi > /dev/null 2> $out/a.err
-rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $out/b -o pmc -- python3 bench.py "$@" --no-cpu-baseline --no-smi > /dev/null 2> $out/b.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $out/a -o pmc -- python3 bench.py "$@" --no-extras --no-cpu-baseline > /dev/null 2> $out/a.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $out/b -o pmc -- python3 bench.py "$@" --no-extras --no-cpu-baseline > /dev/null 2> $out/b.err
 python3 - <<PY
 import csv, glob, collections
 for d in ("a","b"):

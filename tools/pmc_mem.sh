@@ -8,7 +8,7 @@ mkdir -p $out
 i=0
 for set in "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $set --output-format csv -d $out/p$i -o pmc -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2> $out/p$i.err || echo "pass $i failed"
+  timeout 150 rocprofv3 --pmc $set --output-format csv -d $out/p$i -o pmc -- python3 bench.py "$@" --no-extras --no-cpu-baseline > /dev/null 2> $out/p$i.err || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections

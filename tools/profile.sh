@@ -8,11 +8,11 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py "$@" > $out/bench_plain.json 2> $out/bench_plain.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py "$@" --no-smi > $out/bench_traced.json 2> $out/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py "$@" --no-cpu-baseline --no-smi > /dev/null 2> $out/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py "$@" --no-cpu-baseline --no-smi > /dev/null 2> $out/pmc_write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/pmc_sq -o pmc -- python3 bench.py "$@" --no-cpu-baseline --no-smi > /dev/null 2> $out/pmc_sq.err
+python3 bench.py "$@" --no-extras > $out/bench_plain.json 2> $out/bench_plain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py "$@" --no-extras > $out/bench_traced.json 2> $out/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py "$@" --no-extras --no-cpu-baseline > /dev/null 2> $out/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py "$@" --no-extras --no-cpu-baseline > /dev/null 2> $out/pmc_write.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/pmc_sq -o pmc -- python3 bench.py "$@" --no-extras --no-cpu-baseline > /dev/null 2> $out/pmc_sq.err
 python3 tools/profile_summary.py $out > $out/summary.txt 2>&1
 cat $out/summary.txt
 # keep the merge-back small: raw per-dispatch CSVs can be large

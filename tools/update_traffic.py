@@ -2,7 +2,7 @@
 file bench.py reads `roofline.traffic` and `roofline_fp64` from.  Every entry is stamped with the hash of the kernel
 sources it was measured on (bench.py refuses an entry whose hash differs), the mass tolerance and the LO solver.
 
-    python tools/update_traffic.py <tag>         (reads gpurun_out/prof_<tag>/ and gpurun_out/pmc_<tag>/)
+    python tools/update_traffic.py <tag> [mass-solve] [round]        (reads gpurun_out/prof_<tag>/ and gpurun_out/pmc_<tag>/)
 
 FETCH_SIZE on gfx950 under-reports coalesced reads (MI355X_MICROARCH.md: exactly 1/2 for 16-byte-per-lane streams); for
 this kernel's 8-byte-per-lane loads the factor was calibrated in round 1 on limit_fused_kernel, whose read bytes are
@@ -16,10 +16,12 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import kernel_source_hash, stage_alg_bytes_per_dof  # noqa: E402
+from bench import MASS_SOLVE, kernel_source_hash, stage_alg_bytes_per_dof  # noqa: E402
 
 FETCH_CAL = 1.771
 tag = sys.argv[1]
+solve = sys.argv[2] if len(sys.argv) > 2 else "pa"  # --mass-solve of the profiled bench command
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
 
 
 def counters(pattern):
@@ -45,11 +47,11 @@ for order, rs, ne in ((3, 5, 884736), (6, 4, 110592)):
     ndof = (order + 1) ** 3
     ent = {
         "kernel": f"ho_kernel2<{order},1> (whole RK stage, -lo 5)",
-        "kernel_src_sha": kernel_source_hash(), "mass_tol": "rel 1e-14", "lo": 5,
+        "kernel_src_sha": kernel_source_hash(), "mass_tol": MASS_SOLVE[solve][1], "lo": 5,
         "fetch_size_kib": f_kib, "write_size_kib": w_kib, "fetch_calibration": FETCH_CAL,
         "hbm_bytes_per_launch": int(1024 * (FETCH_CAL * f_kib + w_kib)),
         "algorithmic_bytes_per_launch": int(stage_alg_bytes_per_dof(order) * ne * ndof),
-        "source": f"profiles/r02_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh {tag})",
+        "source": f"profiles/{rnd}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh {tag})",
     }
     if kname in insts and "SQ_INSTS_VALU_FMA_F64" in insts[kname]:
         ent["fp64_wave_insts_per_launch"] = {
