@@ -386,6 +386,73 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     return res
 
 
+def measure_cpp_loop(args, lib, world, rank, device, comm_file):
+    """N > 1: the C++ stage loop (rmhd_run_partitioned, remhos_amd/csrc/rmh_driver.hip) -- one process per GPU, the
+    halo exchange as grouped RCCL send/recv inside the library, no Python between the launches (at N = 8 strong
+    scaling a block's stage takes ~0.5 ms).  W warm-up steps, then K timed steps between two barriers (one-double
+    all-reduces) + device synchronisations; wall = max over ranks.  comm_file = None: all blocks in THIS process on one
+    GPU, device copies instead of RCCL (RMH_BENCH_ONE_GPU=1, validation of this code path on a 1-GPU box)."""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    part = PART[world]
+    weak = args.scaling == "weak" and world > 1
+    extra = tuple(1 if (weak and part[d] == 2) else 0 for d in range(3))
+    (rel, ab, mit, jac, fix), mass_tol = MASS_SOLVE[args.mass_solve]
+    if args.mass_solve not in ("pa", "exact"):
+        raise SystemExit("--gpus N > 1 runs the C++ loop: --mass-solve pa or exact")
+    cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, max_steps=args.warmup + args.steps, lo_type=args.lo,
+                      part=part, rank=rank, rs_extra=extra, pa=1 if args.mass_solve == "pa" else 0, warmup_steps=args.warmup)
+    res = RmhdResult()
+    t0 = time.perf_counter()
+    rc = lib.rmhd_run_partitioned(C.byref(cfg), comm_file.encode() if comm_file else None, device, C.byref(res))
+    if rc != 0:
+        raise SystemExit(f"rank {rank}: rmhd_run_partitioned: {lib.rmhd_last_error().decode()}")
+    total_s = time.perf_counter() - t0
+    order, D = args.order, args.order + 1
+    stages = res.timed_stages
+    ne_global = res.global_dofs // D**3
+    ho_avg_s = res.t_rhs / stages  # (interior + halo-shell launch of a stage, HIP events on the context's stream, max over ranks)
+    ho_bytes = int(stage_alg_bytes_per_dof(order) * res.global_dofs / world)
+    achieved = ho_bytes / ho_avg_s / 1e9
+    return {
+        "value": 1e-6 * res.global_dofs * stages / res.wall,
+        "ms_per_step": 1e3 * res.wall / args.steps,
+        "config": {
+            "workload": f"{args.mesh} -rs {args.rs}{'+' + ''.join(str(k) for k in extra) if any(extra) else ''} -o {order} -p {args.problem} "
+                        f"{'remap' if args.problem >= 10 else 'transport'}, -pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP"
+                        + (" (BASELINE configs[3])" if (args.mesh, order, args.problem, args.lo) == ("periodic-cube", 3, 10, 5) else "")
+                        + f"; {ne_global} hex, {res.global_dofs} dofs",
+            "global_dofs": res.global_dofs, "elements": ne_global, "dofs_per_gpu": res.global_dofs // world,
+            "partition": "x".join(str(k) for k in part), "limiter": "inside the stage kernel", "dt": res.dt,
+            "mass_cg_max_iters": res.cg_iters_max, "mass_solve": args.mass_solve, "mass_tol": mass_tol,
+            "final_mass": res.final_mass, "max_value": res.max_value, "mass_loss": res.mass_loss,
+            "stage_loop": "C++ (rmhd_run_partitioned)", "setup_and_run_s": total_s,
+        },
+        "roofline": {
+            "kernel": f"rmh::ho_kernel2<{order}, {3 if args.lo in (3, 4) else 1}> (whole RK stage; interior + halo-shell launch)",
+            "bound": "fp64-valu", "model": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": "PMC passes are single-GPU (profiles/)", "avg_launch_ms": 1e3 * ho_avg_s,
+            "alg_bytes_per_launch": ho_bytes,
+            "achieved_is": "ALGORITHMIC bytes of SURVEY 8(d) (matrix-free model) per GPU and stage / stage kernel time (max over ranks)",
+        },
+        "fom_reference_style": {"rhs_plus_inv": res.fom_rhs, "total_rhs_lo_fct": res.fom},
+        "exchange": {
+            "transport": {1: "RCCL grouped ncclSend/ncclRecv inside the library (rmh_exchange_begin/_end), exchange stream with priority",
+                          2: "same-process device copies (all blocks on one GPU: validation mode)"}.get(res.transport, "none"),
+            "ghost_records": "compact (face layer + extrema; extrema only for edge/vertex neighbours)",
+            "neighbour_ranks": res.n_peers, "send_bytes_per_stage_rank0": res.send_bytes_per_stage,
+            "recv_bytes_per_stage_rank0": res.recv_bytes_per_stage,
+        },
+        "stage_roofline": {
+            "alg_bytes_per_dof": stage_alg_bytes_per_dof(order),
+            "achieved_GBs": 1e-6 * res.global_dofs * stages / res.wall * 1e6 * stage_alg_bytes_per_dof(order) / 1e9,
+            "frac_of_hbm_peak": 1e-6 * res.global_dofs * stages / res.wall * 1e6 * stage_alg_bytes_per_dof(order) / 1e9 / (HBM_PEAK_GBS * world),
+        },
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,6 +479,8 @@ def main():
     ap.add_argument("--no-smi", action="store_true", help=argparse.SUPPRESS)  # (accepted for old recipes: sampling is opt-in now)
     ap.add_argument("--sustained-steps", type=int, default=200)
     ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
+    ap.add_argument("--py-loop", action="store_true",
+                    help="N > 1: drive the stages from Python (remhos_amd/stepper.py over torch.distributed) instead of the C++ loop")
     args = ap.parse_args()
     if args.gpus not in PART:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
@@ -425,17 +494,36 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
 
-    import torch
-
     from remhos_amd.capi import load_library
     from remhos_amd.case import bind_driver
+
+    one_gpu = os.environ.get("RMH_BENCH_ONE_GPU", "0") == "1"
+    if args.gpus > 1 and not args.py_loop:
+        # the C++ loop: nothing of torch is needed (RCCL is reached by the library itself); one rank per GPU as launched,
+        # the ncclUniqueId through a file named after this launch's MASTER_PORT
+        lib = bind_driver(load_library())
+        if one_gpu:
+            if rank == 0:
+                out = measure_cpp_loop(args, lib, world, 0, 0, None)
+        else:
+            port = os.environ.get("MASTER_PORT", "0")
+            os.environ.setdefault("RMH_COMM_NONCE", port)
+            out = measure_cpp_loop(args, lib, world, rank, local_rank, os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rmh_bench_{port}.id"))
+        if rank == 0:
+            line = {"metric": "MDOFs*RK-stage/s, 3D hex remap", "value": out["value"], "unit": "MDOFs*RK-stage/s", "n_gpus": args.gpus,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": out["ms_per_step"], "higher_is_better": True,
+                    "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "rccl_ranks": world}
+            line.update({k: v for k, v in out.items() if k not in ("value", "ms_per_step")})
+            print(json.dumps(line), flush=True)
+        return
+
+    import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the remhos_amd hot path has no CPU fallback")
     # RMH_BENCH_ONE_GPU=1 (validation aid for boxes with a single GPU, NOT a benchmark): every rank on cuda:0, gloo
     # process group, the exchange through torch.distributed on the library's segments -- exercises the multi-rank code
     # path of this file (weak-scaling lattices, reductions, the JSON line) where RCCL refuses two ranks on one device
-    one_gpu = os.environ.get("RMH_BENCH_ONE_GPU", "0") == "1"
     if one_gpu:
         local_rank = 0
         os.environ["RMH_SYNC_EXCHANGE"] = "1"

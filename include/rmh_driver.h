@@ -38,6 +38,10 @@ typedef struct {
                          0 full assembly -- the exact element inverse (here: PCG converged to rel. 1e-14);
                          1 partial assembly -- DGMassInverse with abs. tolerance 1e-8, rel. 0 (here: the same stopping
                            rule, completed by rmh_set_mass_completion(1, 1))                                        */
+   int self_wrap;     /* validation of the neighbour exchange on ONE rank: 1 + d turns the periodic wrap of direction d
+                         into a halo whose ghosts are owned by this rank itself (RCCL send / recv to the own rank); the
+                         run must reproduce the plain periodic one bit for bit.  0: off                               */
+   int warmup_steps;  /* rmhd_run_partitioned: steps taken before the stopwatches and the wall clock start (bench.py)  */
 } rmhd_config;
 
 typedef struct {
@@ -85,6 +89,12 @@ typedef struct {
    double wall, fom_wall;                     /* whole stage loop, everything included    */
    int cg_iters_max;
    int repeats;                               /* steps repeated by the dt control         */
+   /* rmhd_run_partitioned: */
+   int timed_stages;                          /* stages inside the stopwatches / the wall clock (all but the warm-up) */
+   int n_peers;                               /* neighbour ranks of this rank's block                                  */
+   int transport;                             /* 0 none, 1 RCCL send/recv, 2 same-process device copies               */
+   int pad_;
+   long long send_bytes_per_stage, recv_bytes_per_stage; /* this rank's halo records per RK stage                     */
 } rmhd_result;
 
 /* remhos() on one GPU (px = py = pz = 1): setup, RK3-SSP loop, report.  0 on success. */

@@ -24,7 +24,7 @@ class RmhdConfig(C.Structure):
         ("dt", C.c_double), ("t_final", C.c_double), ("max_steps", C.c_int), ("lo_type", C.c_int),
         ("fused", C.c_int), ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int), ("rank", C.c_int),
         ("bounds_type", C.c_int), ("dt_control", C.c_int), ("ho_type", C.c_int), ("save", C.c_int),
-        ("rs_extra", C.c_int * 3), ("pa", C.c_int),
+        ("rs_extra", C.c_int * 3), ("pa", C.c_int), ("self_wrap", C.c_int), ("warmup_steps", C.c_int),
     ]
 
 
@@ -45,12 +45,14 @@ class RmhdResult(C.Structure):
         ("t_rhs", C.c_double), ("t_inv", C.c_double), ("t_lo", C.c_double), ("t_fct", C.c_double), ("t_total", C.c_double),
         ("fom_rhs", C.c_double), ("fom_inv", C.c_double), ("fom_lo", C.c_double), ("fom_fct", C.c_double), ("fom", C.c_double),
         ("wall", C.c_double), ("fom_wall", C.c_double), ("cg_iters_max", C.c_int), ("repeats", C.c_int),
+        ("timed_stages", C.c_int), ("n_peers", C.c_int), ("transport", C.c_int), ("pad_", C.c_int),
+        ("send_bytes_per_stage", C.c_longlong), ("recv_bytes_per_stage", C.c_longlong),
     ]
 
 
 def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=-1, lo_type=5,
                 fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0, ho_type=3, save=0,
-                rs_extra=(0, 0, 0), pa=0) -> RmhdConfig:
+                rs_extra=(0, 0, 0), pa=0, self_wrap=0, warmup_steps=0) -> RmhdConfig:
     c = RmhdConfig()
     c.mesh = mesh.encode()
     c.rs, c.order, c.problem = rs, order, problem
@@ -60,6 +62,8 @@ def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_fina
     c.bounds_type, c.dt_control, c.ho_type, c.save = bounds_type, dt_control, ho_type, save
     c.rs_extra[0], c.rs_extra[1], c.rs_extra[2] = (int(k) for k in rs_extra)
     c.pa = int(pa)
+    c.self_wrap = int(self_wrap)
+    c.warmup_steps = int(warmup_steps)
     return c
 
 

@@ -421,6 +421,7 @@ int rmh_setup(rmh_ctx *c, double t)
 int rmh_set_ghost_u(rmh_ctx *c, const double *ug)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   if (c->xch) { return fail(RMH_ERR_STATE, "the ghosts of this context belong to its exchange plan (rmh_exchange_setup)"); }
    c->u_ghost = ug;
    c->gh_ustride = c->ndof;
    return RMH_OK;
@@ -429,6 +430,7 @@ int rmh_set_ghost_u(rmh_ctx *c, const double *ug)
 int rmh_set_ghost_minmax(rmh_ctx *c, const double *gmin, const double *gmax)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   if (c->xch) { return fail(RMH_ERR_STATE, "the ghosts of this context belong to its exchange plan (rmh_exchange_setup)"); }
    c->gh_min = gmin;
    c->gh_max = gmax;
    c->gh_mstride = 1;
@@ -438,6 +440,7 @@ int rmh_set_ghost_minmax(rmh_ctx *c, const double *gmin, const double *gmax)
 int rmh_set_ghost_records(rmh_ctx *c, const double *rec)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
+   if (c->xch) { return fail(RMH_ERR_STATE, "the ghosts of this context belong to its exchange plan (rmh_exchange_setup)"); }
    c->u_ghost = rec;
    c->gh_min = rec ? rec + c->ndof : nullptr;
    c->gh_max = rec ? rec + c->ndof + 1 : nullptr;

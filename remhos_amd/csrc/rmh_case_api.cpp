@@ -35,6 +35,7 @@ CaseConfig to_config(const rmhd_config &c)
    k.pz = c.pz > 0 ? c.pz : 1;
    k.rank = c.rank;
    for (int d = 0; d < 3; d++) { k.rs_extra[d] = c.rs_extra[d]; }
+   k.self_wrap = c.self_wrap;
    return k;
 }
 } // namespace remhos

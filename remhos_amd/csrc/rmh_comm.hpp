@@ -179,11 +179,47 @@ void exchange_free(rmh_ctx *c)
 
 extern "C" {
 
+} // extern "C"
+
+namespace rmh
+{
+// (tables_rewritten: the device copies of face_nbr / stencil27 were re-indexed to ghost cells; saved_*: their originals)
+static int exchange_setup_impl(rmh_ctx *c, const rmh_exchange_desc *d, int compact, bool &tables_rewritten, std::vector<int> &saved_nbr,
+                               std::vector<int> &saved_st27);
+}
+
+extern "C" {
+
 int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
 {
    if (!c || !d || d->n_peers < 0) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (c->xch) { return fail(RMH_ERR_STATE, "rmh_exchange_setup: the exchange of this context is already set up"); }
    RMH_ENTER(c);
+   bool rewritten = false;
+   std::vector<int> saved_nbr, saved_st27;
+   const int rc = exchange_setup_impl(c, d, compact, rewritten, saved_nbr, saved_st27);
+   if (rc != RMH_OK)
+   {
+      // a failed set-up leaves the context as it was: no plan, the neighbour tables in ghost-slot indexing
+      const std::string msg = rmh_last_error();
+      exchange_free(c);
+      if (rewritten)
+      {
+         (void)hipMemcpy(c->d_nbr, saved_nbr.data(), saved_nbr.size() * sizeof(int), hipMemcpyHostToDevice);
+         (void)hipMemcpy(c->d_st27, saved_st27.data(), saved_st27.size() * sizeof(int), hipMemcpyHostToDevice);
+      }
+      return fail(rc, msg);
+   }
+   return RMH_OK;
+}
+
+} // extern "C"
+
+namespace rmh
+{
+static int exchange_setup_impl(rmh_ctx *c, const rmh_exchange_desc *d, int compact, bool &tables_rewritten, std::vector<int> &saved_nbr,
+                               std::vector<int> &saved_st27)
+{
    const int ne = c->ne, ng = c->ng, D2 = (c->p + 1) * (c->p + 1), nd = c->ndof;
    // ---- validate the plan: ghost ranges of the neighbours tile [0, ne_ghost) -----------------------------------
    std::vector<int> ghost_peer(ng, -1);
@@ -240,7 +276,6 @@ int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
             auto key = std::make_pair(e, ghost_peer[g]);
             if (elem_face_to_peer.count(key))
             {
-               exchange_free(c);
                return fail(RMH_ERR_INVALID, "rmh_exchange_setup: an element is adjacent to one neighbour rank through two faces "
                                             "(block one element thin): use compact = 0 on all ranks");
             }
@@ -251,7 +286,6 @@ int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
       {
          if (ghost_face[g] > 1)
          {
-            exchange_free(c);
             return fail(RMH_ERR_INVALID, "rmh_exchange_setup: a ghost element is seen through two faces: use compact = 0 on all ranks");
          }
       }
@@ -293,9 +327,12 @@ int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
       // re-index the device tables: ghost slot g -> ne + first cell of its record
       st27.resize((size_t)ne * 27);
       RMH_HIP(hipMemcpy(st27.data(), c->d_st27, st27.size() * sizeof(int), hipMemcpyDeviceToHost));
-      if (2 * cell / 2 + (long long)ne > 0x7fffffffLL) { exchange_free(c); return fail(RMH_ERR_INVALID, "rmh_exchange_setup: too many ghost cells"); }
+      if (2 * cell / 2 + (long long)ne > 0x7fffffffLL) { return fail(RMH_ERR_INVALID, "rmh_exchange_setup: too many ghost cells"); }
+      saved_nbr = nbr;
+      saved_st27 = st27;
       for (int &v : nbr) { if (v >= ne) { v = ne + (int)ghost_cell[v - ne]; } }
       for (int &v : st27) { if (v >= ne) { v = ne + (int)ghost_cell[v - ne]; } }
+      tables_rewritten = true;
       RMH_HIP(hipMemcpy(c->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
       RMH_HIP(hipMemcpy(c->d_st27, st27.data(), st27.size() * sizeof(int), hipMemcpyHostToDevice));
    }
@@ -331,7 +368,18 @@ int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
    RMH_HIP(hipMalloc((void **)&x->d_send, std::max<long long>(1, x->send_doubles) * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&x->d_ghost, std::max<long long>(1, x->ghost_doubles) * sizeof(double)));
    RMH_HIP(hipMemset(x->d_ghost, 0, std::max<long long>(1, x->ghost_doubles) * sizeof(double)));
-   RMH_HIP(hipStreamCreate(&x->xs));
+   // (non-blocking: a blocking stream would synchronise implicitly with the legacy default stream, i.e. with the
+   // interior launch of a caller that runs the context there, and the exchange would not overlap it; everything that
+   // must be ordered is ordered by ev_packed / ev_done)
+   // Highest priority: the RCCL send / recv kernel is enqueued a few microseconds AFTER the interior launch has filled
+   // every CU; at equal priority its workgroups were placed only when the interior kernel drained (kernel trace of the
+   // one-rank self-loop: 400 us for 0.66 MB, ending with the interior kernel), so the halo shell always waited for the
+   // whole interior.  With priority they take the first slots that free up.
+   {
+      int pr_least = 0, pr_greatest = 0;
+      RMH_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+      RMH_HIP(hipStreamCreateWithPriority(&x->xs, hipStreamNonBlocking, pr_greatest));
+   }
    RMH_HIP(hipEventCreateWithFlags(&x->ev_packed, hipEventDisableTiming));
    RMH_HIP(hipEventCreateWithFlags(&x->ev_done, hipEventDisableTiming));
    // the kernels read the ghosts from the library's buffer from now on
@@ -354,6 +402,9 @@ int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
    }
    return RMH_OK;
 }
+} // namespace rmh
+
+extern "C" {
 
 int rmh_comm_unique_id(char id[128])
 {
@@ -448,14 +499,25 @@ int rmh_exchange_begin(rmh_ctx *c, const double *u)
       // the exchange stream starts behind the pack kernel -- and thereby behind every kernel of the previous stage
       // that still read the ghosts it is about to overwrite
       RMH_HIP(hipStreamWaitEvent(x->xs, x->ev_packed, 0));
-      RMH_NCCL(rccl().GroupStart());
-      for (PeerPlan &p : x->peers)
+      // (a failing call must not leave the group open or the generation counter advanced: the context stays usable)
+      int rc = rccl().GroupStart();
+      const char *what = "ncclGroupStart";
+      if (rc == 0)
       {
-         if (p.local) { continue; }
-         if (p.send_n > 0) { RMH_NCCL(rccl().Send(x->d_send + p.send_off, (size_t)p.send_n, Rccl::kDouble, p.rank, x->comm, x->xs)); }
-         if (p.recv_n > 0) { RMH_NCCL(rccl().Recv(x->d_ghost + p.recv_off, (size_t)p.recv_n, Rccl::kDouble, p.rank, x->comm, x->xs)); }
+         for (PeerPlan &p : x->peers)
+         {
+            if (p.local) { continue; }
+            if (rc == 0 && p.send_n > 0) { rc = rccl().Send(x->d_send + p.send_off, (size_t)p.send_n, Rccl::kDouble, p.rank, x->comm, x->xs); what = "ncclSend"; }
+            if (rc == 0 && p.recv_n > 0) { rc = rccl().Recv(x->d_ghost + p.recv_off, (size_t)p.recv_n, Rccl::kDouble, p.rank, x->comm, x->xs); what = "ncclRecv"; }
+         }
+         const int rc_end = rccl().GroupEnd();
+         if (rc == 0 && rc_end != 0) { rc = rc_end; what = "ncclGroupEnd"; }
       }
-      RMH_NCCL(rccl().GroupEnd());
+      if (rc != 0)
+      {
+         x->gen_begin--;
+         return fail(RMH_ERR_HIP, std::string(what) + ": " + rccl().GetErrorString(rc));
+      }
    }
    return RMH_OK;
 }

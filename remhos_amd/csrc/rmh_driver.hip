@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <ctime>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -509,28 +512,55 @@ struct Block
    rmh_ctx *ctx = nullptr;
    double *x = nullptr, *y1 = nullptr, *y2 = nullptr, *xold = nullptr, *m = nullptr;
    int vsize = 0;
+   hipStream_t stream = nullptr; // the context's stream: a non-blocking one, so that the exchange stream overlaps it
 };
+
+// ncclUniqueId rendezvous through a file.  Record = magic, launch tag, id.  The launch tag is what tells this launch's
+// file from a stale one (a path reused by a later run, or left by a crashed one): RMH_COMM_NONCE if the launcher exports
+// it, else the parent process id (ranks started by one shell loop / one torchrun agent share it).  Rank 0 removes a
+// stale file first, writes <path>.tmp and renames it; the others poll until they read a record with their tag that is
+// not older than five minutes.  Rank 0 deletes the file once ncclCommInitRank -- a collective -- has returned.
+struct IdRecord
+{
+   char magic[8];
+   long long tag;
+   char id[128];
+};
+
+long long launch_tag()
+{
+   if (const char *v = std::getenv("RMH_COMM_NONCE")) { return std::atoll(v); }
+   return (long long)getppid();
+}
 
 bool read_or_write_id(const char *path, bool writer, char id[128])
 {
-   // rank 0 writes the ncclUniqueId to <path>.tmp and renames it; the other ranks poll for <path>
+   IdRecord rec;
    if (writer)
    {
+      std::memcpy(rec.magic, "RMHNCCL1", 8);
+      rec.tag = launch_tag();
+      std::memcpy(rec.id, id, 128);
       const std::string tmp = std::string(path) + ".tmp";
       FILE *f = std::fopen(tmp.c_str(), "wb");
       if (!f) { return false; }
-      const bool ok = std::fwrite(id, 1, 128, f) == 128;
+      const bool ok = std::fwrite(&rec, sizeof(rec), 1, f) == 1;
       std::fclose(f);
       return ok && std::rename(tmp.c_str(), path) == 0;
    }
-   for (int tries = 0; tries < 6000; tries++)
+   for (int tries = 0; tries < 12000; tries++)
    {
+      struct stat sb;
       FILE *f = std::fopen(path, "rb");
       if (f)
       {
-         const bool ok = std::fread(id, 1, 128, f) == 128;
+         const bool ok = std::fread(&rec, sizeof(rec), 1, f) == 1 && fstat(fileno(f), &sb) == 0;
          std::fclose(f);
-         if (ok) { return true; }
+         if (ok && std::memcmp(rec.magic, "RMHNCCL1", 8) == 0 && rec.tag == launch_tag() && std::time(nullptr) - sb.st_mtime < 300)
+         {
+            std::memcpy(id, rec.id, 128);
+            return true;
+         }
       }
       std::this_thread::sleep_for(std::chrono::milliseconds(10));
    }
@@ -552,6 +582,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       {
          (void)hipFree(b.x); (void)hipFree(b.y1); (void)hipFree(b.y2); (void)hipFree(b.xold); (void)hipFree(b.m);
          if (b.ctx) { rmh_destroy(b.ctx); }
+         if (b.stream) { (void)hipStreamDestroy(b.stream); }
       }
    };
 #define RMHD_TRY(expr)                                                          \
@@ -577,6 +608,8 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       L.subcell_vel = b.cd.subcell_vel.empty() ? nullptr : b.cd.subcell_vel.data();
       L.device = device;
       RMHD_TRY(rmh_create(&L, &b.ctx));
+      RMHD_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+      RMHD_TRY(rmh_set_stream(b.ctx, b.stream));
       RMHD_TRY(rmh_set_lo_type(b.ctx, cc.lo_type));
       RMHD_TRY(rmh_set_bounds_type(b.ctx, cfg->bounds_type));
       if (cfg->dt_control) { RMHD_TRY(rmh_set_dt_control(b.ctx, 1)); }
@@ -617,9 +650,14 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    if (rccl)
    {
       char id[128];
-      if (cc0.rank == 0) { RMHD_TRY(rmh_comm_unique_id(id)); }
+      if (cc0.rank == 0)
+      {
+         std::remove(comm_id_file); // (a stale record: see read_or_write_id)
+         RMHD_TRY(rmh_comm_unique_id(id));
+      }
       if (!read_or_write_id(comm_id_file, cc0.rank == 0, id)) { g_driver_error = "cannot exchange the RCCL unique id through the file"; cleanup(); return -1; }
       RMHD_TRY(rmh_comm_init(blocks[0].ctx, id, nranks, cc0.rank));
+      if (cc0.rank == 0) { std::remove(comm_id_file); } // (every rank has read it: ncclCommInitRank is collective)
    }
    else
    {
@@ -640,7 +678,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    auto reduce = [&](double v, int op) -> double
    {
       // over the blocks of this process, then over the ranks of the communicator
-      if (rccl && nranks > 1) { if (rmh_allreduce(blocks[0].ctx, &v, 1, op) != 0) { reduce_failed = true; } }
+      if (rccl) { if (rmh_allreduce(blocks[0].ctx, &v, 1, op) != 0) { reduce_failed = true; } }
       return v;
    };
    auto mass_and_max = [&](double t, double &mass, double &umax) -> bool
@@ -649,6 +687,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       for (Block &b : blocks)
       {
          if (rmh_compute_lumped_mass(b.ctx, b.cd.exec_mode == 1 ? t : 0.0, b.m) != 0) { return false; }
+         if (hipStreamSynchronize(b.stream) != hipSuccess) { return false; } // (a non-blocking stream: the copies below do not wait for it)
          std::vector<double> hm(b.vsize), hu(b.vsize);
          if (hipMemcpy(hm.data(), b.m, sizeof(double) * b.vsize, hipMemcpyDeviceToHost) != hipSuccess) { return false; }
          if (hipMemcpy(hu.data(), b.x, sizeof(double) * b.vsize, hipMemcpyDeviceToHost) != hipSuccess) { return false; }
@@ -667,7 +706,8 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    bool done = false;
    for (Block &b : blocks) { RMHD_TRY(rmh_enable_timers(b.ctx, 1)); }
    RMHD_HIP(hipDeviceSynchronize());
-   const auto w0 = std::chrono::steady_clock::now();
+   auto w0 = std::chrono::steady_clock::now();
+   int timed_from = 0; // steps taken before the stopwatches (re)started (rmhd_config.warmup_steps)
    // one RK stage of all blocks: post every exchange, run the elements that reach no ghost while the messages are
    // in flight, complete the exchanges, run the halo-dependent shells
    auto stage = [&](int which, double ts, double dt_real, double ra, double rb) -> bool
@@ -691,13 +731,22 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    };
    while (!done)
    {
+      if (cfg->warmup_steps > 0 && ti_total == cfg->warmup_steps)
+      {
+         // the timed region starts here: everything before is finished on every rank (the reduction is the barrier)
+         RMHD_HIP(hipDeviceSynchronize());
+         (void)reduce(0.0, 0);
+         for (Block &b : blocks) { RMHD_TRY(rmh_reset_timers(b.ctx)); }
+         timed_from = ti_total;
+         w0 = std::chrono::steady_clock::now();
+      }
       const double dt_real = std::min(dt, t_final - t);
       if (cfg->dt_control)
       {
          for (Block &b : blocks)
          {
             RMHD_TRY(rmh_dt_estimate_reset(b.ctx));
-            RMHD_HIP(hipMemcpyAsync(b.xold, b.x, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, nullptr));
+            RMHD_HIP(hipMemcpyAsync(b.xold, b.x, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, b.stream));
          }
          RMHD_HIP(hipDeviceSynchronize());
       }
@@ -722,7 +771,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
             t -= dt_real;
             for (Block &b : blocks)
             {
-               RMHD_HIP(hipMemcpyAsync(b.x, b.xold, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, nullptr));
+               RMHD_HIP(hipMemcpyAsync(b.x, b.xold, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, b.stream));
                RMHD_TRY(rmh_invalidate_extrema(b.ctx));
             }
             RMHD_HIP(hipDeviceSynchronize());
@@ -737,6 +786,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       if (ti_total == cc0.max_steps) { done = true; }
    }
    RMHD_HIP(hipDeviceSynchronize());
+   (void)reduce(0.0, 0); // (every rank has finished its last stage)
    const auto w1 = std::chrono::steady_clock::now();
    double mass = 0, umax = 0;
    if (!mass_and_max(t, mass, umax)) { g_driver_error = "final mass"; cleanup(); return -1; }
@@ -765,7 +815,16 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    res->global_dofs = blocks[0].cd.ne_global * blocks[0].cd.ndof;
    res->t_rhs = tk; // the whole stage is one kernel: everything is in the RHS bucket
    res->t_total = tk;
-   const double dofs_steps = 1e-6 * (double)res->global_dofs * res->stages;
+   res->timed_stages = 3 * (ti_total - timed_from);
+   res->n_peers = (int)blocks[0].cd.peers.size();
+   res->transport = rccl ? 1 : (nranks > 1 ? 2 : 0);
+   {
+      long long sd = 0, gd = 0;
+      if (res->n_peers > 0) { (void)rmh_exchange_buffers(blocks[0].ctx, nullptr, &sd, nullptr, &gd); }
+      res->send_bytes_per_stage = 8 * sd;
+      res->recv_bytes_per_stage = 8 * gd;
+   }
+   const double dofs_steps = 1e-6 * (double)res->global_dofs * res->timed_stages;
    res->fom_rhs = tk > 0 ? dofs_steps / tk : 0;
    res->fom = res->fom_rhs;
    res->wall = reduce(std::chrono::duration<double>(w1 - w0).count(), 2);

@@ -210,6 +210,9 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
       Nd[d] = (int)vertsd[d].size() - 1;
       if (P[d] > Nd[d]) { return "more partition blocks than elements in a direction"; }
    }
+   const int sw = cfg.self_wrap - 1; // direction whose periodic wrap is exchanged with the own rank, or -1
+   if (cfg.self_wrap < 0 || cfg.self_wrap > 3) { return "bad self_wrap"; }
+   if (sw >= 0 && (!md.periodic || P[sw] != 1 || Nd[sw] < 3)) { return "self_wrap needs a periodic mesh, one block and >= 3 elements in that direction"; }
    const int Nx = Nd[0], Ny = Nd[1];
    out = CaseData();
    out.order = cfg.order;
@@ -404,10 +407,12 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    out.face_nbr.assign((size_t)ne * 6, -1);
    std::map<std::pair<int, long long>, int> ghost_slot; // (owner, gid) -> slot, ordered
    std::map<int, std::vector<long long>> send_sets;       // peer -> gids of owned elements it needs
+   bool seam = false; // did the last stencil entry cross the seam of the self-wrapped direction?
    auto wrap = [&](int d, int g, bool &ok)
    {
       if (g >= 0 && g < Nd[d]) { return g; }
       if (!md.periodic) { ok = false; return 0; }
+      if (d == sw) { seam = true; }
       return (g % Nd[d] + Nd[d]) % Nd[d];
    };
    // pass 1: collect ghosts and send sets (only elements near the box surface have remote neighbours)
@@ -424,11 +429,14 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
             {
                const int o[3] = {s % 3 - 1, (s / 3) % 3 - 1, s / 9 - 1};
                bool ok = true;
+               seam = false;
                const int g[3] = {wrap(0, out.lo[0] + lx + o[0], ok), wrap(1, out.lo[1] + ly + o[1], ok),
                                  wrap(2, out.lo[2] + lz + o[2], ok)};
                if (!ok) { continue; }
                const int owner = owner_1d(0, g[0]) + cfg.px * (owner_1d(1, g[1]) + cfg.py * owner_1d(2, g[2]));
-               if (owner == cfg.rank) { continue; }
+               // (self-loop: an element reached across the seam is a ghost copy owned by this very rank; the layers on
+               // the two sides of the seam are distinct elements, so the global id still names the copy)
+               if (owner == cfg.rank && !seam) { continue; }
                const long long gid = g[0] + (long long)Nx * (g[1] + (long long)Ny * g[2]);
                ghost_slot[{owner, gid}] = 0;
                send_sets[owner].push_back(mygid);
@@ -478,12 +486,13 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
             {
                const int o[3] = {s % 3 - 1, (s / 3) % 3 - 1, s / 9 - 1};
                bool ok = true;
+               seam = false;
                const int g[3] = {wrap(0, out.lo[0] + lx + o[0], ok), wrap(1, out.lo[1] + ly + o[1], ok),
                                  wrap(2, out.lo[2] + lz + o[2], ok)};
                if (!ok) { continue; }
                int idx;
                const int l[3] = {g[0] - out.lo[0], g[1] - out.lo[1], g[2] - out.lo[2]};
-               if (l[0] >= 0 && l[0] < nlx && l[1] >= 0 && l[1] < nly && l[2] >= 0 && l[2] < nlz)
+               if (!seam && l[0] >= 0 && l[0] < nlx && l[1] >= 0 && l[1] < nly && l[2] >= 0 && l[2] < nlz)
                {
                   idx = l[0] + nlx * (l[1] + nly * l[2]);
                }

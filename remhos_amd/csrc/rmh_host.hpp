@@ -22,6 +22,11 @@ struct CaseConfig
    int px = 1, py = 1, pz = 1;         // box partition of the element lattice
    int rank = 0;
    int rs_extra[3] = {0, 0, 0};        // additional refinement levels per direction (weak-scaling lattices)
+   // Self-loop (validation of the neighbour exchange on ONE rank): 1 + d makes the periodic wrap of direction d a halo
+   // -- the elements beyond the seam become ghosts whose owner is this rank itself, so that the exchange (pack kernels,
+   // ghost records, RCCL send / recv to the own rank) runs for real and must reproduce the plain periodic run bit for
+   // bit.  Needs a periodic mesh, one block in that direction and at least three elements across it.  0: off.
+   int self_wrap = 0;
 };
 
 // neighbour rank in the halo exchange: which owned elements it needs, which ghost slots it fills

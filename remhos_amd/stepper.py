@@ -86,6 +86,16 @@ class Stepper:
             self.ctx.exchange_setup(case.peers, compact=self.compact)
             if self.dist is not None:
                 self._connect(self.dist)
+            elif getattr(case.cfg, "self_wrap", 0):
+                # self-loop (rmhd_config.self_wrap): the only neighbour is this rank itself.  On the GPU the exchange
+                # goes through a one-rank RCCL communicator -- grouped ncclSend / ncclRecv to the own rank, the real
+                # transport of multi-GPU runs -- unless RMH_EXCHANGE=local asks for device copies (host emulation: always)
+                if self.dev.type == "cuda" and _os.environ.get("RMH_EXCHANGE", "rccl") == "rccl":
+                    self.ctx.comm_init(self.ctx.comm_unique_id(), 1, 0)
+                    self.transport = "rccl"
+                else:
+                    self.ctx.comm_connect_local(0, self.ctx, 0)
+                    self.transport = "local"
 
     def _buffer_tensor(self, ptr, n):
         """torch view of n doubles of a library-owned buffer (no copy)"""

@@ -1,0 +1,78 @@
+"""GPU part of tests/test_selfloop.py: the self-wrapped block exchanged through a ONE-RANK RCCL COMMUNICATOR -- the
+grouped ncclSend / ncclRecv of rmh_exchange_begin, the dlopen'd RCCL table, the exchange stream and its event ordering
+against the interior / halo launches, and rmh_allreduce run on the hardware at hand (1-GPU boxes).  Reference call
+sites replaced: remhos_ho.cpp:122, remhos_tools.cpp:449-466, remhos.cpp:1412-1421."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.test_selfloop import plain_run, selfloop_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+
+    assert torch.cuda.is_available()
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+
+    return bind_driver(load_library())
+
+
+@pytest.mark.parametrize("rs,p,wrap,lo,compact,prob,steps", [
+    (2, 3, 1, 5, True, 10, 4),    # 12^3 elements: face layers + extrema records
+    (2, 3, 2, 5, False, 10, 4),   # whole-element records
+    (1, 3, 3, 4, True, 10, 3),    # subcell RD reads the same ghost traces
+    (1, 4, 1, 5, True, 10, 2),    # generic (non wave-aligned) reductions
+    (1, 6, 2, 5, True, 10, 2),
+    (2, 3, 1, 5, True, 0, 4),     # transport: real upwind fluxes across the seam
+])
+def test_rccl_selfloop_equals_plain_periodic(lib, rs, p, wrap, lo, compact, prob, steps):
+    u0 = plain_run(lib, "cuda:0", rs, p, steps, lo=lo, prob=prob)
+    u1, tr, red = selfloop_run(lib, "cuda:0", rs, p, wrap, steps, lo=lo, compact=compact, prob=prob)
+    assert tr == "rccl"
+    assert red == [1.5, -2.0]  # rmh_allreduce over the one rank
+    assert np.array_equal(u0, u1)
+
+
+def test_rccl_selfloop_cpp_driver(lib, tmp_path):
+    """rmhd_run_partitioned in its RCCL mode (unique id through the file, communicator of one rank, C++ stage loop on a
+    non-default stream with interior / halo ranges, reductions through rmh_allreduce) against rmhd_run."""
+    from remhos_amd.case import RmhdResult, make_config
+
+    one, loop = RmhdResult(), RmhdResult()
+    kw = dict(mesh="periodic-cube", rs=2, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=5, pa=1)
+    cfg = make_config(**kw)
+    assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
+    idfile = str(tmp_path / "rmh.id").encode()
+    for attempt in range(2):  # the second run finds no stale record: rank 0 removed the file
+        cfgp = make_config(self_wrap=1, warmup_steps=2, **kw)
+        assert lib.rmhd_run_partitioned(C.byref(cfgp), idfile, 0, C.byref(loop)) == 0, lib.rmhd_last_error()
+        assert not (tmp_path / "rmh.id").exists()
+        assert (loop.steps, loop.stages, loop.global_dofs) == (one.steps, one.stages, one.global_dofs)
+        assert loop.timed_stages == 3 * (5 - 2) and loop.transport == 1 and loop.n_peers == 1
+        assert loop.send_bytes_per_stage == loop.recv_bytes_per_stage > 0
+        assert loop.max_value == one.max_value
+        assert abs(loop.final_mass - one.final_mass) < 1e-13 and abs(loop.mass0 - one.mass0) < 1e-13  # (host sums in different element orders)
+        assert loop.fom_wall > 0
+
+
+def test_ghost_setters_refused_after_exchange_setup(lib):
+    """rmh_set_ghost_* after rmh_exchange_setup would leave re-indexed tables pointing into a caller buffer"""
+    import torch
+
+    from remhos_amd.capi import RmhError
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(lib, make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, self_wrap=1))
+    st = Stepper(lib, case, device="cuda:0")
+    buf = torch.zeros(case.ne_ghost * (case.ndof + 2), dtype=torch.float64, device="cuda:0")
+    for call in (lambda: st.ctx.set_ghost_u(buf), lambda: st.ctx.set_ghost_minmax(buf, buf), lambda: st.ctx.set_ghost_records(buf)):
+        with pytest.raises(RmhError):
+            call()
+    st.close()

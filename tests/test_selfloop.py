@@ -1,0 +1,111 @@
+"""Self-loop of the neighbour exchange on ONE rank (rmhd_config.self_wrap): the periodic wrap of one direction of a
+1 x 1 x 1 block becomes a halo whose ghosts are owned by the rank itself, so that the whole exchange path -- plan, pack
+kernels, compact / full ghost records, interior + halo launch ranges, event ordering, and on the GPU the grouped
+ncclSend / ncclRecv of rmh_exchange_begin on a one-rank RCCL communicator -- runs for real on a 1-GPU box.  What it
+replaces in the reference: ParGridFunction::ExchangeFaceNbrData (remhos_ho.cpp:122) + the GroupCommunicator min/max
+of DofInfo::ComputeOverlapBounds (remhos_tools.cpp:449-466).  Expected: bit-identical to the plain periodic run.
+
+CPU part: host case builder + the kernel sources under the host emulation with the same-process transport."""
+import numpy as np
+import pytest
+
+
+def selfloop_run(lib, device, rs, p, wrap, steps, lo=5, compact=True, prob=10):
+    """final field in global element order of the self-wrapped run, and the Stepper's transport"""
+    import os
+
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    old = os.environ.get("RMH_COMPACT")
+    os.environ["RMH_COMPACT"] = "1" if compact else "0"
+    try:
+        case = Case(lib, make_config("periodic-cube", rs, p, prob, -1.0 if prob >= 10 else 0.01, 0.5, lo_type=lo, self_wrap=wrap))
+        st = Stepper(lib, case, device=device)
+    finally:
+        if old is None:
+            os.environ.pop("RMH_COMPACT", None)
+        else:
+            os.environ["RMH_COMPACT"] = old
+    assert st.compact == compact
+    for _ in range(steps):
+        st.step(case.dt)
+    if device != "cpu":
+        import torch
+
+        torch.cuda.synchronize()
+    u = st.x.cpu().numpy()[np.argsort(case.owned_gid)]
+    tr = st.transport
+    red = st.ctx.allreduce([1.5, -2.0], "sum") if tr == "rccl" else None
+    st.close()
+    return u, tr, red
+
+
+def plain_run(lib, device, rs, p, steps, lo=5, prob=10):
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(lib, make_config("periodic-cube", rs, p, prob, -1.0 if prob >= 10 else 0.01, 0.5, lo_type=lo))
+    st = Stepper(lib, case, device=device)
+    for _ in range(steps):
+        st.step(case.dt)
+    if device != "cpu":
+        import torch
+
+        torch.cuda.synchronize()
+    u = st.x.cpu().numpy()[np.argsort(case.owned_gid)]
+    st.close()
+    return u
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    from remhos_amd.case import load_host_library
+
+    return load_host_library()
+
+
+@pytest.mark.parametrize("wrap", [1, 2, 3])
+def test_selfloop_case_lists(hostlib, wrap):
+    """the builder's halo lists of a self-wrapped block: one peer = the rank itself, ghosts = the two element layers
+    at the seam, sent in ghost order; everything else is the plain periodic block"""
+    from remhos_amd.case import Case, make_config
+
+    c = Case(hostlib, make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, self_wrap=wrap))
+    n = c.n
+    d = wrap - 1
+    layer = n[0] * n[1] * n[2] // n[d]
+    assert c.ne_owned == n[0] * n[1] * n[2] and c.ne_ghost == 2 * layer
+    assert len(c.peers) == 1 and c.peers[0][0] == 0
+    _, send, recv = c.peers[0]
+    assert len(send) == len(recv) == 2 * layer and (recv == np.arange(2 * layer)).all()
+    # the k-th record sent is the element whose copy the k-th ghost slot holds
+    assert (c.owned_gid[send] == c.ghost_gid).all()
+    coord = (c.ghost_gid // (1 if d == 0 else (n[0] if d == 1 else n[0] * n[1]))) % n[d]
+    assert set(coord.tolist()) == {0, n[d] - 1}
+    # tables: ghosts are referenced exactly by the elements of the two seam layers, through the wrapped direction
+    gh = c.face_nbr >= c.ne_owned
+    assert gh.sum() == 2 * layer and not gh[:, [f for f in range(6) if f // 2 != d]].any()
+    assert c.ne_halo == 2 * layer
+    plain = Case(hostlib, make_config("periodic-cube", 1, 2, 10, -1.0, 0.5))
+    order, porder = np.argsort(c.owned_gid), np.argsort(plain.owned_gid)
+    assert np.array_equal(c.x0[order], plain.x0[porder]) and np.array_equal(c.u0[order], plain.u0[porder])
+    with pytest.raises(RuntimeError):
+        Case(hostlib, make_config("cube01_hex", 1, 2, 10, -1.0, 0.5, self_wrap=1))  # not periodic
+
+
+@pytest.fixture(scope="module")
+def emulib():
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+    from tests.helpers import emu_library_path
+
+    return bind_driver(load_library(emu_library_path()))
+
+
+@pytest.mark.parametrize("p,wrap,lo,compact", [(2, 1, 5, True), (2, 3, 5, False), (3, 2, 4, True)])
+def test_selfloop_emulated_equals_plain_periodic(emulib, p, wrap, lo, compact):
+    u0 = plain_run(emulib, "cpu", 0, p, 1, lo=lo)
+    u1, tr, _ = selfloop_run(emulib, "cpu", 0, p, wrap, 1, lo=lo, compact=compact)
+    assert tr == "local"
+    assert np.array_equal(u0, u1)
