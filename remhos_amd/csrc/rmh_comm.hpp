@@ -371,10 +371,11 @@ static int exchange_setup_impl(rmh_ctx *c, const rmh_exchange_desc *d, int compa
    // (non-blocking: a blocking stream would synchronise implicitly with the legacy default stream, i.e. with the
    // interior launch of a caller that runs the context there, and the exchange would not overlap it; everything that
    // must be ordered is ordered by ev_packed / ev_done)
-   // Highest priority: the RCCL send / recv kernel is enqueued a few microseconds AFTER the interior launch has filled
-   // every CU; at equal priority its workgroups were placed only when the interior kernel drained (kernel trace of the
-   // one-rank self-loop: 400 us for 0.66 MB, ending with the interior kernel), so the halo shell always waited for the
-   // whole interior.  With priority they take the first slots that free up.
+   // Highest priority, so that the RCCL send / recv kernel -- enqueued a few microseconds AFTER the interior launch has
+   // filled every CU -- is placed ahead of the interior kernel's remaining workgroups.  (Kernel trace of the one-rank
+   // self-loop, profiles/r03_rccl_selfloop_timeline.txt: the RCCL kernel lasts as long as the interior launch it runs
+   // beside, with or without the priority; the halo shell is behind the interior launch on the context's stream anyway,
+   // so the exchange costs nothing as long as it ends by then.)
    {
       int pr_least = 0, pr_greatest = 0;
       RMH_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));

@@ -375,8 +375,11 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       Vector masses(vsize);
       RMH_CALL(rmh_compute_lumped_mass(ctx, 0.0, masses.Write()));
       masses.CopyToHost(h_m.data());
-      double mass0 = 0.0;
-      for (int i = 0; i < vsize; i++) { mass0 += h_m[i] * cd.u0[i]; }
+      // (sums of ~1e7 terms: accumulated in extended precision so that the printed mass carries no summation error of its
+      // own -- the conservation claims are at the 1e-12 level)
+      long double mass0_acc = 0.0L;
+      for (int i = 0; i < vsize; i++) { mass0_acc += (long double)h_m[i] * cd.u0[i]; }
+      const double mass0 = (double)mass0_acc;
 
       // Print the starting mesh and initial condition (remhos.cpp:1015-1030)
       if (cfg->save)
@@ -459,12 +462,14 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
          const std::string e = save_mfem(cd, t, h_u.data(), "meshHO_final.mesh", "sltn_final.gf");
          RMH_VERIFY(e.empty(), e.c_str());
       }
-      double mass = 0.0, umax = -INFINITY;
+      long double mass_acc = 0.0L;
+      double umax = -INFINITY;
       for (int i = 0; i < vsize; i++)
       {
-         mass += h_m[i] * h_u[i];
+         mass_acc += (long double)h_m[i] * h_u[i];
          umax = std::fmax(umax, h_u[i]);
       }
+      const double mass = (double)mass_acc;
       adv.Timer().Update(ctx);
       const TimingData &T = adv.Timer();
       res->final_mass = mass;
@@ -691,7 +696,9 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
          std::vector<double> hm(b.vsize), hu(b.vsize);
          if (hipMemcpy(hm.data(), b.m, sizeof(double) * b.vsize, hipMemcpyDeviceToHost) != hipSuccess) { return false; }
          if (hipMemcpy(hu.data(), b.x, sizeof(double) * b.vsize, hipMemcpyDeviceToHost) != hipSuccess) { return false; }
-         for (int i = 0; i < b.vsize; i++) { mass += hm[i] * hu[i]; umax = std::fmax(umax, hu[i]); }
+         long double acc = 0.0L; // (extended precision: see rmhd_run)
+         for (int i = 0; i < b.vsize; i++) { acc += (long double)hm[i] * hu[i]; umax = std::fmax(umax, hu[i]); }
+         mass += (double)acc;
       }
       mass = reduce(mass, 0);  // MPI_Allreduce SUM, remhos.cpp:1412
       umax = reduce(umax, 2);  // MPI_Allreduce MAX, remhos.cpp:1415
