@@ -70,6 +70,7 @@ public:
    int Size() const { return size; }
    const T *Read() const { return data; }
    T *Write() { return data; }
+   void MakeRef(T *device_ptr, int n) { data = device_ptr; size = n; }
 };
 
 // y = a*x + b*y' helpers used by the RK solver (device axpys)
@@ -281,7 +282,9 @@ public:
    }
 };
 
-// The stage operator (remhos.cpp:115-198, 1596-1739, 1798-1916), single field u.
+// The stage operator (remhos.cpp:115-198, 1596-1739, 1798-1916).  One field u, or -- product remap, -ps -- the block
+// vector [u | us] (remhos.cpp:875-878: block_offsets of size 3): MultUnlimited then also forms the HO rate of us
+// (:1709-1738) and LimitMult limits it so that s = us / u stays in its local bounds (:1848-1915).
 class AdvectionOperator : public LimitedTimeDependentOperator
 {
    ParFiniteElementSpace &pfes;
@@ -290,12 +293,16 @@ class AdvectionOperator : public LimitedTimeDependentOperator
    LOSolver *lo_solver;
    FCTSolver *fct_solver;
    mutable Vector lumpedM, du_HO, du_LO;
+   mutable Vector d_us_HO, s_ratio, u_new;                                     // product remap
+   mutable Array<bool> s_bool_el, s_bool_dofs, s_bool_el_new, s_bool_dofs_new; // product remap
    mutable TimingData timer;
-   const bool fused; // LimitMult through rmh_limit_fused (no du_LO / bounds vectors)
+   const bool fused;   // LimitMult through rmh_limit_fused (no du_LO / bounds vectors)
+   const bool product; // block vector [u | us]
 
 public:
    AdvectionOperator(ParFiniteElementSpace &space, DofInfo &dofs_, HOSolver *hos, LOSolver *los, FCTSolver *fct,
-                     bool fused_limiter);
+                     bool fused_limiter, bool product_sync = false);
+   ~AdvectionOperator();
    void SetDt(real_t dt_) override
    {
       LimitedTimeDependentOperator::SetDt(dt_);
@@ -312,15 +319,80 @@ public:
    TimingData &Timer() const { return timer; }
 };
 
+// mfem::ODESolver as far as the driver needs it
+class ODESolver
+{
+public:
+   virtual ~ODESolver() {}
+   virtual void Init(LimitedTimeDependentOperator &op) = 0;
+   virtual void Step(Vector &x, real_t &t, real_t &dt) = 0;
+};
+
 // mfem::RK3SSPSolver (remhos.cpp:490; stage times t, t+dt, t+dt/2: SURVEY A.6)
-class RK3SSPSolver
+class RK3SSPSolver : public ODESolver
 {
    LimitedTimeDependentOperator *f = nullptr;
    Vector y, k;
 
 public:
-   void Init(LimitedTimeDependentOperator &op);
-   void Step(Vector &x, real_t &t, real_t &dt);
+   void Init(LimitedTimeDependentOperator &op) override;
+   void Step(Vector &x, real_t &t, real_t &dt) override;
+};
+
+// remhos_solvers.hpp:65-84: the IDP ("invariant domain preserving") solvers -- every stage is a LIMITED forward Euler
+// update; what the reference runs product remap with (-s 11 / 12 / 13).
+class IDPODESolver : public ODESolver
+{
+protected:
+   LimitedTimeDependentOperator *f = nullptr;
+
+public:
+   void Init(LimitedTimeDependentOperator &f_) override { f = &f_; }
+};
+
+// remhos_solvers.hpp:86-92, remhos_solvers.cpp:24-40
+class ForwardEulerIDPSolver : public IDPODESolver
+{
+   Vector dx;
+
+public:
+   void Init(LimitedTimeDependentOperator &f_) override;
+   void Step(Vector &x, real_t &t, real_t &dt) override;
+};
+
+// remhos_solvers.hpp:94-126, remhos_solvers.cpp:42-250.  The masks (UseMask / AddMasked / UpdateMask) are not built: the
+// reference's driver switches them off for every run (remhos.cpp:502-507).
+class RKIDPSolver : public IDPODESolver
+{
+   const int s;
+   const real_t *a, *b, *c;
+   real_t *d;
+   Vector *dxs;
+   // Constructs the coefficients that turn eq. (2.16) of JLG's paper into an update that only uses the previous
+   // limited updates (remhos_solvers.cpp:42-96).
+   void ConstructD();
+
+public:
+   RKIDPSolver(int s_, const real_t a_[], const real_t b_[], const real_t c_[]);
+   ~RKIDPSolver();
+   void Init(LimitedTimeDependentOperator &f_) override;
+   void Step(Vector &x, real_t &t, real_t &dt) override;
+};
+
+class RK2IDPSolver : public RKIDPSolver
+{
+   static const real_t a[], b[], c[];
+
+public:
+   RK2IDPSolver() : RKIDPSolver(2, a, b, c) {}
+};
+
+class RK3IDPSolver : public RKIDPSolver
+{
+   static const real_t a[], b[], c[];
+
+public:
+   RK3IDPSolver() : RKIDPSolver(3, a, b, c) {}
 };
 
 } // namespace remhos

@@ -42,6 +42,10 @@ typedef struct {
                          into a halo whose ghosts are owned by this rank itself (RCCL send / recv to the own rank); the
                          run must reproduce the plain periodic one bit for bit.  0: off                               */
    int warmup_steps;  /* rmhd_run_partitioned: steps taken before the stopwatches and the wall clock start (bench.py)  */
+   int ps;            /* -ps : product-field remap, (u, us) evolved together with s = us / u kept in its local bounds
+                         (remhos.cpp:888-904, 1709-1738, 1848-1915); remap mode, -fct 2, fixed dt, an IDP solver        */
+   int ode_solver;    /* -s  : 3 (or 0) RK3 SSP; 11 / 12 / 13 forward Euler / RK2 / RK3 IDP solvers
+                         (remhos_solvers.cpp; what -ps runs with in the reference's tests)                              */
 } rmhd_config;
 
 typedef struct {
@@ -64,6 +68,7 @@ int rmhd_case_get_info(const rmhd_case *c, rmhd_case_info *info);
 const double *rmhd_case_x0(const rmhd_case *c);          /* [ne_owned][3][27] */
 const double *rmhd_case_vel(const rmhd_case *c);         /* [ne_owned][3][27] */
 const double *rmhd_case_u0(const rmhd_case *c);          /* [ne_owned][ndof]  */
+const double *rmhd_case_s0(const rmhd_case *c);          /* [ne_owned][ndof] s0_function at the nodes (-ps, remhos.cpp:892-894) */
 const double *rmhd_case_subcell_vel(const rmhd_case *c); /* [ne_owned][3][ndof] or NULL */
 const int *rmhd_case_face_nbr(const rmhd_case *c);       /* [ne_owned][6]  */
 const int *rmhd_case_stencil27(const rmhd_case *c);      /* [ne_owned][27] */
@@ -95,10 +100,16 @@ typedef struct {
    int transport;                             /* 0 none, 1 RCCL send/recv, 2 same-process device copies               */
    int pad_;
    long long send_bytes_per_stage, recv_bytes_per_stage; /* this rank's halo records per RK stage                     */
+   /* -ps (remhos.cpp:1404, 1416-1434): */
+   double final_mass_us, mass0_us, mass_loss_us, s_max;
 } rmhd_result;
 
-/* remhos() on one GPU (px = py = pz = 1): setup, RK3-SSP loop, report.  0 on success. */
+/* remhos() on one GPU (px = py = pz = 1): setup, time loop (RK3 SSP, or the IDP solvers -s 11 / 12 / 13; with -ps
+ * the product field us beside u), report.  0 on success.
+ * rmhd_run_state also hands back the final fields (HOST arrays of ne * ndof doubles in the case's element order, may be
+ * NULL; us_final only with -ps) -- what -save writes, for parity checks of whole runs. */
 int rmhd_run(const rmhd_config *cfg, rmhd_result *res);
+int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *u_final, double *us_final);
 
 /* The same run on a px x py x pz box partition (ParMesh(comm, mesh, partitioning), remhos.cpp:459-463), one fused
  * kernel per RK stage and block, one neighbour exchange per stage inside the library (rmh_exchange_begin / _end):

@@ -516,6 +516,8 @@ class Config:
     bounds_type: int = 0  # -bt: 0 overlap of the CG-node patches, 1 face-neighbour elements (remhos_tools.hpp:168-182)
     dt_control: int = 0  # -dtc: 0 fixed step, 1 LOBoundsError (remhos.cpp:1968-1998, 1178-1197)
     ho_solve: str = "exact"  # 'exact' (remhos_ho.cpp:90-118) or 'cg' (DGMassInverse semantics)
+    ps: bool = False  # -ps: product-field remap, evolve (u, us) with s = us / u (remhos.cpp:888-904, 1709-1738, 1848-1915)
+    ode: int = 3  # -s: 3 RK3 SSP (remhos.cpp:490); 11 / 12 / 13 forward Euler / RK2 / RK3 IDP solvers (remhos_solvers.cpp)
 
 
 class Remhos:
@@ -565,6 +567,14 @@ class Remhos:
         self.update_geometry(0.0)
         self.masses0 = self.m.copy()
         self.mass0 = float((self.m * self.u).sum())
+        self.us = None
+        if cfg.ps:
+            # remhos.cpp:888-904: s = s0 sampled where the element is active (BoolFunctionCoefficient, remhos_sync.cpp:230-238),
+            # us = u * s node by node ("we don't target conservation at initialization")
+            el, _ = compute_bool_indicators(self.u)
+            s0 = np.where(el[:, None], s0_function(xcu), 0.0)
+            self.us = self.u * s0
+            self.mass0_us = float((self.m * self.us).sum())
 
     # ---- helpers -------------------------------------------------------------------
     def vel(self, x):
@@ -834,9 +844,12 @@ class Remhos:
     def compute_bounds(self, u):
         """ComputeElementsMinMax + ComputeOverlapBounds (remhos_tools.cpp:432-523): min/max over
         all elements that contain the dof's CG node."""
+        return self.bounds_from_extrema(u.min(-1), u.max(-1))
+
+    def bounds_from_extrema(self, xe_min, xe_max):
+        """DofInfo::ComputeBounds on given element extrema; inactive elements of the masked variant carry (+inf, -inf),
+        the identities of the reduction -- ComputeOverlapBounds(..., active_el) skips them (remhos_tools.cpp:449-461)."""
         lat, T = self.lat, self.T
-        xe_min = u.min(-1)
-        xe_max = u.max(-1)
         p = T.p
         dim = self.dim
         if self.cfg.bounds_type == 1:
@@ -848,8 +861,8 @@ class Remhos:
                 lo = np.minimum(lo, np.where(nb >= 0, xe_min[np.maximum(nb, 0)], INF))
                 hi = np.maximum(hi, np.where(nb >= 0, xe_max[np.maximum(nb, 0)], -INF))
             return np.repeat(lo[:, None], T.ndof, 1), np.repeat(hi[:, None], T.ndof, 1)
-        umin = np.full_like(u, INF)
-        umax = np.full_like(u, -INF)
+        umin = np.full((lat.ne, T.ndof), INF)
+        umax = np.full((lat.ne, T.ndof), -INF)
         import itertools
 
         for off in itertools.product((-1, 0, 1), repeat=dim):
@@ -955,8 +968,117 @@ class Remhos:
             keep.update(du_ho=du_ho, du_lo=du_lo, umin=umin, umax=umax, du=du, m=self.m.copy(), rhs=self.last_rhs)
         return du
 
+    # ---- the operator split the IDP solvers use, and the product field (-ps) ---------------------------------------
+    def mult_unlimited(self, u, us, t):
+        """AdvectionOperator::MultUnlimited (remhos.cpp:1596-1739): re-setup at time t, HO rates of u and of us."""
+        if self.exec_mode == 1:
+            self.update_geometry(t)
+        du = self.calc_ho(u)
+        dus = self.calc_ho(us) if us is not None else None  # remhos.cpp:1709-1738
+        return du, dus
+
+    def limit_mult(self, u, us, du_ho, dus_ho, dt):
+        """AdvectionOperator::LimitMult (remhos.cpp:1798-1916) on the unlimited rates MultUnlimited left (for the IDP
+        solvers: their combination, remhos_solvers.cpp:205-233) at the geometry of the last mult_unlimited; dt is the
+        operator's dt (SetDt)."""
+        cfg = self.cfg
+        du_lo = self.calc_lo_massavg(u, du_ho, dt) if cfg.lo == 5 else self.calc_lo_rd(u)
+        umin, umax = self.compute_bounds(u)
+        if cfg.fct == 4:
+            fct = lambda *a: self.element_fct_projection(a[0], self.mass_matrices(), *a[2:])  # noqa: E731
+        else:
+            fct = self.clip_scale
+        du = fct(u, self.m, du_ho, du_lo, umin, umax, dt)
+        dus = None
+        if us is not None:
+            # second block (remhos.cpp:1848-1915): ratio and active dofs of the OLD state, bounds of s over the old active
+            # dofs, active dofs of the NEW u, compatible LO product + scaled bounds + the FCT solver + empty dofs zeroed
+            s, s_el, s_dofs = compute_ratio(us, u)
+            xe_min, xe_max = elem_minmax_masked(s, s_el, s_dofs)
+            s_min, s_max = self.bounds_from_extrema(xe_min, xe_max)
+            u_new = u + dt * du
+            el_new, dofs_new = compute_bool_indicators(u_new)
+            dus, _, _ = fct_product(us, self.m, dus_ho, s_min, s_max, u_new, el_new, dofs_new, dt, fct=fct)
+        return du, dus
+
+    @staticmethod
+    def idp_factors(ode):
+        """Butcher data of the IDP RK solvers (remhos_solvers.cpp:245-260) and RKIDPSolver::ConstructD (:41-96): the
+        factors d that express the stage update through the previous LIMITED forward Euler updates."""
+        a, b, c = {12: ([0.5], [0.0, 1.0], [0.5]),
+                   13: ([1.0 / 3.0, 0.0, 2.0 / 3.0], [0.25, 0.0, 0.75], [1.0 / 3.0, 2.0 / 3.0])}[ode]
+        s = len(b)
+        d = [0.0] * (s * (s + 1) // 2)
+        an, ao, i_o, c_o = 0, 0, -1, 0.0  # offsets of the new / old coefficient line in a (or "b" when past a)
+        coef = lambda off, j: (b[j] if off == "b" else a[off + j])  # noqa: E731
+        for i in range(s):
+            c_n = c[i] if i < s - 1 else 1.0
+            dc = c_n - c_o
+            di = i * (i + 1) // 2
+            for j in range(i):
+                a_oj = coef(ao, j) if j <= i_o else 0.0
+                m = (coef(an, j) - a_oj) / dc
+                if m == 0.0:
+                    d[di + j] = 0.0
+                    continue
+                dj = j * (j + 1) // 2
+                dij = m / d[dj + j]
+                for k in range(j):
+                    d[di + k] -= d[dj + k] * dij
+                d[di + j] = dij
+            d[di + i] = coef(an, i) / dc
+            c_next = c[i + 1] if i < s - 2 else 1.0
+            if c_next > c_n:
+                i_o, c_o, ao = i, c_n, an
+            an = an + i + 1 if i < s - 2 else "b"
+        return s, c, d
+
+    def step_idp(self, dt):
+        """ForwardEulerIDPSolver::Step / RKIDPSolver::Step without masks (remhos_solvers.cpp:30-41, 171-249; the driver
+        switches the masks off, remhos.cpp:502-507)."""
+        u, us, t = self.u, self.us, self.t
+        lin = lambda x, a, y: None if x is None else x + a * y  # noqa: E731
+        if self.cfg.ode == 11:
+            du, dus = self.mult_unlimited(u, us, t)
+            du, dus = self.limit_mult(u, us, du, dus, dt)
+            self.u, self.us, self.t = u + dt * du, lin(us, dt, dus), t + dt
+            return
+        s, c, d = self.idp_factors(self.cfg.ode)
+        dxs = []
+        # first stage
+        h, hs = self.mult_unlimited(u, us, t)  # SetTime(t), SetDt(c[0] dt)
+        dxs.append(self.limit_mult(u, us, h, hs, c[0] * dt))
+        c_o = 0.0
+        c_next = c[1] if s > 2 else 1.0
+        t_op = t
+        if c_next > c[0]:
+            u, us = u + c[0] * dt * dxs[0][0], lin(us, c[0] * dt, dxs[0][1])
+            t_op = t + c[0] * dt
+            c_o = c[0]
+        for i in range(1, s):
+            c_n = c[i] if i < s - 1 else 1.0
+            dct = (c_n - c_o) * dt
+            di = d[i * (i + 1) // 2:]
+            h, hs = self.mult_unlimited(u, us, t_op)  # SetDt(dct)
+            # the stage's unlimited update through the previous limited ones (remhos_solvers.cpp:214-233)
+            h = di[i] * h
+            hs = None if hs is None else di[i] * hs
+            for j in range(i):
+                h = h + di[j] * dxs[j][0]
+                hs = lin(hs, di[j], dxs[j][1])
+            dxs.append(self.limit_mult(u, us, h, hs, dct))
+            c_next = c[i + 1] if i < s - 2 else 1.0
+            if i == s - 1 or c_next > c_n:
+                t_op = t + c_n * dt
+                u, us = u + dct * dxs[i][0], lin(us, dct, dxs[i][1])
+                c_o = c_n
+        self.u, self.us, self.t = u, us, t + dt
+
     def step(self, dt):
         """RK3SSPSolver::Step [MFEM], stage times t, t+dt, t+dt/2."""
+        if self.cfg.ode > 10:
+            return self.step_idp(dt)
+        assert not self.cfg.ps, "the product field is restated for the IDP solvers (-s 11 / 12 / 13) only"
         x = self.u
         t = self.t
         k = self.stage(x, t, dt)
@@ -1011,7 +1133,14 @@ class Remhos:
         else:
             masses = self.masses0
         mass = float((masses * self.u).sum())
+        extra = {}
+        if self.us is not None:
+            # remhos.cpp:1404, 1416-1434
+            s, _, _ = compute_ratio(self.us, self.u)
+            mass_us = float((masses * self.us).sum())
+            extra = {"mass_us": mass_us, "s_max": float(s.max()), "mass_loss_us": abs(self.mass0_us - mass_us)}
         return {
+            **extra,
             "mass": mass,
             "max": float(self.u.max()),
             "mass0": self.mass0,
@@ -1022,12 +1151,13 @@ class Remhos:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Product-field remap (-ps): restatement of the per-element functions of the second block of
-# AdvectionOperator::LimitMult (remhos.cpp:1848-1915).  Plain loops over elements, in the reference's order of
-# operations.  PARITY UNPINNED end to end: the reference's only -ps known answers are 2-D runs with -ho 1 / IDP RK
-# solvers (autotest/out_baseline.dat:188-200), which are outside this path; these functions follow the source
-# line by line instead and are the checker of the HIP kernels (rmh_product_ratio, rmh_elem_minmax_masked,
-# rmh_fct_product).
+# Product-field remap (-ps): the per-element functions of the second block of AdvectionOperator::LimitMult
+# (remhos.cpp:1848-1915), plain loops over elements in the reference's order of operations.  PINNED by the reference's
+# "Product remap 2D IDP3" known answer (autotest/out_baseline.dat:197-200: -ho 3 -lo 5 -fct 4 -ps -s 13 on inline-quad,
+# Final mass u 0.08980386855, Final mass us 0.179607829), which runs compute_ratio, elem_minmax_masked, the compatible
+# LO product, the scaled bounds and ZeroOutEmptyDofs through Remhos.limit_mult / step_idp
+# (tests/test_oracle_kat.py::test_product_remap_idp3); they are the checker of the HIP kernels rmh_product_ratio,
+# rmh_elem_minmax_masked, rmh_fct_product.
 # ---------------------------------------------------------------------------------------------------------------
 EMPTY_ZONE_TOL = 1e-12  # remhos_sync.hpp:20
 
@@ -1070,10 +1200,16 @@ def elem_minmax_masked(u, active_el, active_dofs):
     return lo, hi
 
 
-def fct_product(us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt):
-    """ClipScaleSolver::CalcFCTProduct (remhos_fct.cpp:543-566): CalcCompatibleLOProduct (:26-115), ScaleProductBounds
-    (:117-153), ClipScale (:449-541), ZeroOutEmptyDofs (remhos_sync.cpp:98-116).  Returns (d_us, s_min, s_max) --
-    the bounds are updated like the reference updates them in place."""
+def s0_function(x):
+    """remhos.cpp:2357-2361 (physical coordinates, no bounding-box map)"""
+    return 2.0 + np.sin(2 * np.pi * x[..., 0]) * np.sin(2 * np.pi * x[..., 1])
+
+
+def fct_product(us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt, fct=None):
+    """ClipScaleSolver::CalcFCTProduct (remhos_fct.cpp:543-566) -- and ElementFCTProjection::CalcFCTProduct (:733-758),
+    the same four steps around another CalcFCTSolution (fct): CalcCompatibleLOProduct (:26-115), ScaleProductBounds
+    (:117-153), the FCT solve (ClipScale :449-541 by default), ZeroOutEmptyDofs (remhos_sync.cpp:98-116).  Returns
+    (d_us, s_min, s_max) -- the bounds are updated like the reference updates them in place."""
     eps = 1e-12
     ne, nd = us.shape
     s_min, s_max = s_min.copy(), s_max.copy()
@@ -1108,7 +1244,7 @@ def fct_product(us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt)
     with np.errstate(invalid="ignore"):
         us_min = np.where(on, s_min * u_new, 0.0)
         us_max = np.where(on, s_max * u_new, 0.0)
-    d_us = Remhos.clip_scale(us, m, d_us_ho, d_us_lo, us_min, us_max, dt)
+    d_us = (fct or Remhos.clip_scale)(us, m, d_us_ho, d_us_lo, us_min, us_max, dt)
     d_us = np.where(~active_el[:, None] & ~active_dofs, 0.0, d_us)  # ZeroOutEmptyDofs
     return d_us, s_min, s_max
 

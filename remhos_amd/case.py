@@ -13,8 +13,8 @@ HOST_LIB_PATH = os.path.join(_HERE, "librmh_host.so")
 
 DRIVER_SYMBOLS = [
     "rmhd_case_create", "rmhd_case_destroy", "rmhd_last_error", "rmhd_case_get_info", "rmhd_case_x0",
-    "rmhd_case_vel", "rmhd_case_u0", "rmhd_case_subcell_vel", "rmhd_case_face_nbr", "rmhd_case_stencil27",
-    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_case_save", "rmhd_run", "rmhd_run_partitioned",
+    "rmhd_case_vel", "rmhd_case_u0", "rmhd_case_s0", "rmhd_case_subcell_vel", "rmhd_case_face_nbr", "rmhd_case_stencil27",
+    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_case_save", "rmhd_run", "rmhd_run_state", "rmhd_run_partitioned",
 ]
 
 
@@ -25,6 +25,7 @@ class RmhdConfig(C.Structure):
         ("fused", C.c_int), ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int), ("rank", C.c_int),
         ("bounds_type", C.c_int), ("dt_control", C.c_int), ("ho_type", C.c_int), ("save", C.c_int),
         ("rs_extra", C.c_int * 3), ("pa", C.c_int), ("self_wrap", C.c_int), ("warmup_steps", C.c_int),
+        ("ps", C.c_int), ("ode_solver", C.c_int),
     ]
 
 
@@ -47,12 +48,13 @@ class RmhdResult(C.Structure):
         ("wall", C.c_double), ("fom_wall", C.c_double), ("cg_iters_max", C.c_int), ("repeats", C.c_int),
         ("timed_stages", C.c_int), ("n_peers", C.c_int), ("transport", C.c_int), ("pad_", C.c_int),
         ("send_bytes_per_stage", C.c_longlong), ("recv_bytes_per_stage", C.c_longlong),
+        ("final_mass_us", C.c_double), ("mass0_us", C.c_double), ("mass_loss_us", C.c_double), ("s_max", C.c_double),
     ]
 
 
 def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=-1, lo_type=5,
                 fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0, ho_type=3, save=0,
-                rs_extra=(0, 0, 0), pa=0, self_wrap=0, warmup_steps=0) -> RmhdConfig:
+                rs_extra=(0, 0, 0), pa=0, self_wrap=0, warmup_steps=0, ps=0, ode_solver=3) -> RmhdConfig:
     c = RmhdConfig()
     c.mesh = mesh.encode()
     c.rs, c.order, c.problem = rs, order, problem
@@ -64,6 +66,7 @@ def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_fina
     c.pa = int(pa)
     c.self_wrap = int(self_wrap)
     c.warmup_steps = int(warmup_steps)
+    c.ps, c.ode_solver = int(ps), int(ode_solver)
     return c
 
 
@@ -76,7 +79,7 @@ def bind_driver(lib: C.CDLL) -> C.CDLL:
     lib.rmhd_last_error.restype = C.c_char_p
     lib.rmhd_case_get_info.argtypes = [p, C.POINTER(RmhdCaseInfo)]
     lib.rmhd_case_save.argtypes = [p, C.c_double, p, C.c_char_p, C.c_char_p]
-    for name in ("x0", "vel", "u0", "subcell_vel", "face_nbr", "stencil27", "owned_gid", "ghost_gid"):
+    for name in ("x0", "vel", "u0", "s0", "subcell_vel", "face_nbr", "stencil27", "owned_gid", "ghost_gid"):
         f = getattr(lib, "rmhd_case_" + name)
         f.argtypes = [p]
         f.restype = p
@@ -84,6 +87,7 @@ def bind_driver(lib: C.CDLL) -> C.CDLL:
                                    C.POINTER(C.c_int), C.POINTER(p)]
     if hasattr(lib, "rmhd_run"):
         lib.rmhd_run.argtypes = [C.POINTER(RmhdConfig), C.POINTER(RmhdResult)]
+        lib.rmhd_run_state.argtypes = [C.POINTER(RmhdConfig), C.POINTER(RmhdResult), p, p]
         lib.rmhd_run_partitioned.argtypes = [C.POINTER(RmhdConfig), C.c_char_p, C.c_int, C.POINTER(RmhdResult)]
     return lib
 
@@ -124,6 +128,7 @@ class Case:
         self.x0 = _view(lib.rmhd_case_x0(h), (ne, 3, 27), np.float64)
         self.vel = _view(lib.rmhd_case_vel(h), (ne, 3, 27), np.float64)
         self.u0 = _view(lib.rmhd_case_u0(h), (ne, nd), np.float64)
+        self.s0 = _view(lib.rmhd_case_s0(h), (ne, nd), np.float64)
         sv = lib.rmhd_case_subcell_vel(h)
         self.subcell_vel = _view(sv, (ne, 3, nd), np.float64) if sv else None
         self.face_nbr = _view(lib.rmhd_case_face_nbr(h), (ne, 6), np.int32)

@@ -53,7 +53,8 @@ int main(int argc, char **argv)
       else if (a == "-comm-file") { comm_file = next(); }
       else if (a == "-pa") { c.pa = 1; }
       else if (a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
-      else if (a == "-s") { if (std::atoi(next()) != 3) { std::fprintf(stderr, "only -s 3 (RK3 SSP)\n"); return 3; } }
+      else if (a == "-s") { c.ode_solver = std::atoi(next()); }
+      else if (a == "-ps") { c.ps = 1; }
       else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
    }
    if ((ho != 2 && ho != 3) || fct != 2 || c.lo_type < 3 || c.lo_type > 5)
@@ -81,5 +82,9 @@ int main(int argc, char **argv)
                "(megadofs x time steps / second)\n---\n", r.fom_rhs, r.fom_inv, r.fom_lo, r.fom_fct, r.fom);
    std::printf("FOM wall (everything included): %.8g\nmax local PCG iterations: %d\n", r.fom_wall, r.cg_iters_max);
    std::printf("Final mass u:  %.10g\nMax value u:   %.10g\nMass loss u:   %.6g\n", r.final_mass, r.max_value, r.mass_loss);
+   if (c.ps) // remhos.cpp:1429-1435
+   {
+      std::printf("Final mass us: %.10g\nMax value s:   %.10g\nMass loss us:  %.6g\n", r.final_mass_us, r.s_max, r.mass_loss_us);
+   }
    return 0;
 }

@@ -87,6 +87,7 @@ int rmhd_case_get_info(const rmhd_case *c, rmhd_case_info *info)
 const double *rmhd_case_x0(const rmhd_case *c) { return c->d.x0.data(); }
 const double *rmhd_case_vel(const rmhd_case *c) { return c->d.vel.data(); }
 const double *rmhd_case_u0(const rmhd_case *c) { return c->d.u0.data(); }
+const double *rmhd_case_s0(const rmhd_case *c) { return c->d.s0.data(); }
 const double *rmhd_case_subcell_vel(const rmhd_case *c)
 {
    return c->d.subcell_vel.empty() ? nullptr : c->d.subcell_vel.data();

@@ -220,15 +220,34 @@ void DofInfo::ComputeBounds(const Vector &el_min, const Vector &el_max, Vector &
 
 // ---- AdvectionOperator (remhos.cpp:1596-1739, 1798-1916) -----------------------------------------
 AdvectionOperator::AdvectionOperator(ParFiniteElementSpace &space, DofInfo &dofs_, HOSolver *hos, LOSolver *los,
-                                     FCTSolver *fct, bool fused_limiter)
-   : LimitedTimeDependentOperator(space.GetVSize()), pfes(space), dofs(dofs_), ho_solver(hos), lo_solver(los),
-     fct_solver(fct), lumpedM(rmh_lumped_mass(space.Ctx()) ? const_cast<double *>(rmh_lumped_mass(space.Ctx())) : nullptr,
-                              space.GetVSize()),
-     du_HO(space.GetVSize()), du_LO(fused_limiter ? 0 : space.GetVSize()), fused(fused_limiter)
+                                     FCTSolver *fct, bool fused_limiter, bool product_sync)
+   : LimitedTimeDependentOperator((product_sync ? 2 : 1) * space.GetVSize()), pfes(space), dofs(dofs_), ho_solver(hos),
+     lo_solver(los), fct_solver(fct),
+     lumpedM(rmh_lumped_mass(space.Ctx()) ? const_cast<double *>(rmh_lumped_mass(space.Ctx())) : nullptr, space.GetVSize()),
+     du_HO(space.GetVSize()), du_LO(fused_limiter ? 0 : space.GetVSize()), d_us_HO(product_sync ? space.GetVSize() : 0),
+     s_ratio(product_sync ? space.GetVSize() : 0), u_new(product_sync ? space.GetVSize() : 0), fused(fused_limiter),
+     product(product_sync)
 {
    if (ho_solver) { ho_solver->timer = &timer; }
    if (lo_solver) { lo_solver->timer = &timer; }
    if (fct_solver) { fct_solver->timer = &timer; }
+   if (product)
+   {
+      // flag arrays of product remap (mfem::Array<bool> on the device)
+      static_assert(sizeof(bool) == 1, "Array<bool> is handed to the kernels as a byte array");
+      const int ne = space.GetNE(), n = space.GetVSize();
+      bool *p = nullptr;
+      HIP_CALL(hipMalloc((void **)&p, (size_t)2 * (ne + n)));
+      s_bool_el.MakeRef(p, ne);
+      s_bool_dofs.MakeRef(p + ne, n);
+      s_bool_el_new.MakeRef(p + ne + n, ne);
+      s_bool_dofs_new.MakeRef(p + 2 * ne + n, n);
+   }
+}
+
+AdvectionOperator::~AdvectionOperator()
+{
+   if (product) { (void)hipFree(s_bool_el.Write()); }
 }
 
 void AdvectionOperator::MultUnlimited(const Vector &X, Vector &Y) const
@@ -237,30 +256,61 @@ void AdvectionOperator::MultUnlimited(const Vector &X, Vector &Y) const
    // (remhos.cpp:1598-1637) -- matrix-free here: the kernels evaluate x0 + t*v themselves
    RMH_CALL(rmh_setup(pfes.Ctx(), GetTime()));
    RMH_VERIFY(ho_solver && lo_solver && fct_solver, "FCT requires HO and LO solvers."); // remhos.cpp:1690
-   ho_solver->CalcHOSolution(X, Y);
+   const int n = pfes.GetVSize();
+   if (product)
+   {
+      // Remap the product field (remhos.cpp:1709-1738).  Its HO rate is formed FIRST: the context keeps the element
+      // extrema of the last vector rmh_ho_apply saw, and the fused limiter of u relies on them.
+      const Vector us(const_cast<double *>(X.Read()) + n, n);
+      Vector d_us(Y.Write() + n, n);
+      ho_solver->CalcHOSolution(us, d_us);
+   }
+   const Vector u(const_cast<double *>(X.Read()), n);
+   Vector d_u(Y.Write(), n);
+   ho_solver->CalcHOSolution(u, d_u);
    // Limiting is deferred to LimitMult()
 }
 
 void AdvectionOperator::LimitMult(const Vector &X, Vector &Y) const
 {
-   const Vector &u = X;
-   Vector &d_u = Y;
+   const int n = pfes.GetVSize();
+   const Vector u(const_cast<double *>(X.Read()), n);
+   Vector d_u(Y.Write(), n);
    if (fused)
    {
       // d_u holds du_HO on entry; the fused kernel reads du_HO and writes d_u element by element
       RMH_CALL(rmh_limit_fused(pfes.Ctx(), u.Read(), d_u.Read(), dt, d_u.Write(), nullptr, 0.0, 1.0, 0.0, nullptr));
-      return;
    }
-   // the reference's sequence, remhos.cpp:1812-1831 (the x_gf face-neighbour exchange at
-   // :1812-1813 is dead weight for ClipScale and is skipped)
-   du_HO = d_u; // Vector du_HO(d_u)
-   auto mba = dynamic_cast<MassBasedAvg *>(lo_solver);
-   if (mba) { mba->SetHOSolution(du_HO); }
-   lo_solver->CalcLOSolution(u, du_LO);
-   dofs.ComputeElementsMinMax(u, dofs.xe_min, dofs.xe_max);
-   dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
-   fct_solver->CalcFCTSolution(u, lumpedM, du_HO, du_LO, dofs.xi_min, dofs.xi_max, d_u);
-   UpdateTimeStepEstimate(u, du_LO, dofs.xi_min, dofs.xi_max); // remhos.cpp:1839-1842 (no-op with a fixed dt)
+   else
+   {
+      // the reference's sequence, remhos.cpp:1812-1831 (the x_gf face-neighbour exchange at
+      // :1812-1813 is dead weight for ClipScale and is skipped)
+      du_HO = d_u; // Vector du_HO(d_u)
+      auto mba = dynamic_cast<MassBasedAvg *>(lo_solver);
+      if (mba) { mba->SetHOSolution(du_HO); }
+      lo_solver->CalcLOSolution(u, du_LO);
+      dofs.ComputeElementsMinMax(u, dofs.xe_min, dofs.xe_max);
+      dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
+      fct_solver->CalcFCTSolution(u, lumpedM, du_HO, du_LO, dofs.xi_min, dofs.xi_max, d_u);
+      UpdateTimeStepEstimate(u, du_LO, dofs.xi_min, dofs.xi_max); // remhos.cpp:1839-1842 (no-op with a fixed dt)
+   }
+   if (!product) { return; }
+   // Remap the product field (remhos.cpp:1848-1915)
+   const Vector us(const_cast<double *>(X.Read()) + n, n);
+   Vector d_us(Y.Write() + n, n);
+   d_us_HO = d_us; // Vector d_us_HO(d_us)
+   Vector d_us_LO;
+   RMH_VERIFY(!fct_solver->NeedsLOProductInput(), "no FCT solver on this path needs the LO product rate"); // :1866-1870
+   // Compute the ratio s = us_old / u_old, and old active dofs.
+   ComputeRatio(pfes, us, u, s_ratio, s_bool_el, s_bool_dofs);
+   // Bounds for s, based on the old values (and old active dofs).
+   dofs.ComputeElementsMinMax(s_ratio, dofs.xe_min, dofs.xe_max, &s_bool_el, &s_bool_dofs);
+   dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max); // (+inf, -inf) of inactive elements = "&s_bool_el"
+   // Evolve u and get the new active dofs.
+   add(u, dt, d_u, u_new);
+   ComputeBoolIndicators(pfes, u_new, s_bool_el_new, s_bool_dofs_new);
+   fct_solver->CalcFCTProduct(us, lumpedM, d_us_HO, d_us_LO, dofs.xi_min, dofs.xi_max, u_new, s_bool_el_new, s_bool_dofs_new,
+                              d_us);
 }
 
 void AdvectionOperator::UpdateTimeStepEstimate(const Vector &x, const Vector &dx, const Vector &x_min,
@@ -275,6 +325,127 @@ real_t AdvectionOperator::GetTimeStepRatio() const
    RMH_CALL(rmh_dt_estimate_get(pfes.Ctx(), &est));
    return (dt != 0.) ? est / dt : 0.; // remhos.cpp:1997
 }
+
+// ---- IDP solvers (remhos_solvers.cpp) ---------------------------------------------------------------------------------
+void ForwardEulerIDPSolver::Init(LimitedTimeDependentOperator &f_)
+{
+   IDPODESolver::Init(f_);
+   dx.SetSize(f_.Height());
+}
+void ForwardEulerIDPSolver::Step(Vector &x, real_t &t, real_t &dt)
+{
+   // remhos_solvers.cpp:30-40
+   f->SetTime(t);
+   f->SetDt(dt);
+   f->MultUnlimited(x, dx);
+   f->LimitMult(x, dx);
+   add(x, dt, dx, x);
+   t += dt;
+}
+
+void RKIDPSolver::ConstructD()
+{
+   // Convert high-order to Forward Euler factors (remhos_solvers.cpp:42-96)
+   d = new real_t[s * (s + 1) / 2]();
+   const real_t *a_n = a; // new coeff line
+   const real_t *a_o = a; // old coeff line
+   int i_o = -1;          // old stage
+   real_t c_o = 0.;       // old time fraction
+   for (int i = 0; i < s; i++)
+   {
+      const real_t c_n = (i < s - 1) ? c[i] : 1.; // new time fraction
+      const real_t dc = c_n - c_o;                // time fraction diff
+      real_t *di = d + i * (i + 1) / 2;
+      for (int j = 0; j < i; j++)
+      {
+         const real_t a_oj = (j <= i_o) ? a_o[j] : 0.; // old coeff
+         const real_t m = (a_n[j] - a_oj) / dc;        // old HO update coeff
+         if (m == 0.) { di[j] = 0.; continue; }
+         // Express j-th HO update by Forward Euler updates
+         const real_t *dj = d + j * (j + 1) / 2;
+         const real_t dij = m / dj[j];
+         for (int k = 0; k < j; k++) { di[k] -= dj[k] * dij; }
+         di[j] = dij;
+      }
+      di[i] = a_n[i] / dc;
+      // Update stage
+      const double c_next = (i < s - 2) ? c[i + 1] : 1.;
+      if (c_next > c_n) { i_o = i; c_o = c_n; a_o = a_n; }
+      if (i < s - 2) { a_n += i + 1; }
+      else { a_n = b; }
+   }
+}
+
+RKIDPSolver::RKIDPSolver(int s_, const real_t a_[], const real_t b_[], const real_t c_[]) : s(s_), a(a_), b(b_), c(c_)
+{
+   dxs = new Vector[s];
+   ConstructD();
+}
+RKIDPSolver::~RKIDPSolver()
+{
+   delete[] dxs;
+   delete[] d;
+}
+void RKIDPSolver::Init(LimitedTimeDependentOperator &f_)
+{
+   IDPODESolver::Init(f_);
+   for (int i = 0; i < s; i++) { dxs[i].SetSize(f->Height()); }
+}
+void RKIDPSolver::Step(Vector &x, real_t &t, real_t &dt)
+{
+   // remhos_solvers.cpp:171-250 with use_masks = false (remhos.cpp:502-507)
+   real_t c_o = 0.;
+   // Perform the first step
+   f->SetTime(t);
+   f->SetDt(c[0] * dt);
+   f->MultUnlimited(x, dxs[0]);
+   f->LimitMult(x, dxs[0]);
+   // Update state
+   {
+      const double c_next = (s > 2) ? c[1] : 1.;
+      if (c_next > c[0]) // only when advancing after
+      {
+         add(x, c[0] * dt, dxs[0], x);
+         f->SetTime(t + c[0] * dt);
+         c_o = c[0];
+      }
+   }
+   // Step through higher stages
+   const real_t *d_i = d + 1;
+   for (int i = 1; i < s; i++)
+   {
+      const real_t c_n = (i < s - 1) ? c[i] : 1.;
+      const real_t dc = c_n - c_o;
+      const real_t dct = dc * dt;
+      // Explicit HO step
+      f->SetDt(dct);
+      f->MultUnlimited(x, dxs[i]);
+      // Form the unlimited update for the stage: it converts eq. (2.16) in JLG's paper into an update using the
+      // previous limited updates.
+      add(d_i[i], dxs[i], d_i[0], dxs[0], dxs[i]);
+      for (int j = 1; j < i; j++) { add(dxs[i], d_i[j], dxs[j], dxs[i]); }
+      // Limit the step (always a Forward Euler step).
+      f->LimitMult(x, dxs[i]);
+      // Update the state
+      const double c_next = (i < s - 2) ? c[i + 1] : 1.;
+      if (i == s - 1 || c_next > c_n) // only when advancing after
+      {
+         f->SetTime(t + c_n * dt);
+         add(x, dct, dxs[i], x);
+         c_o = c_n;
+      }
+      d_i += i + 1;
+   }
+   t += dt;
+}
+
+// 2-stage, 2nd order / 3-stage, 3rd order (remhos_solvers.cpp:252-260)
+const real_t RK2IDPSolver::a[] = {.5};
+const real_t RK2IDPSolver::b[] = {0., 1.};
+const real_t RK2IDPSolver::c[] = {.5};
+const real_t RK3IDPSolver::a[] = {1. / 3., 0., 2. / 3.};
+const real_t RK3IDPSolver::b[] = {.25, 0., .75};
+const real_t RK3IDPSolver::c[] = {1. / 3., 2. / 3.};
 
 // ---- RK3 SSP [MFEM RK3SSPSolver::Step] -------------------------------------------------------------
 void RK3SSPSolver::Init(LimitedTimeDependentOperator &op)
@@ -307,9 +478,12 @@ void RK3SSPSolver::Step(Vector &x, real_t &t, real_t &dt)
 
 using namespace remhos;
 
-extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
+extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res) { return rmhd_run_state(cfg, res, nullptr, nullptr); }
+
+extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *u_final, double *us_final)
 {
    if (!cfg || !res) { g_driver_error = "null argument"; return -1; }
+   std::memset(res, 0, sizeof(*res));
    CaseConfig cc = to_config(*cfg);
    if (cc.px * cc.py * cc.pz != 1)
    {
@@ -359,18 +533,47 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       else { lo_solver = new PAResidualDistributionSubcell(pfes); }
       double dt = cd.dt;
       FCTSolver *fct_solver = new ClipScaleSolver(pfes, nullptr, dt);
+      // -ps / -s 11|12|13 (remhos.cpp:484-507, 875-904): block vector [u | us], IDP solvers.  They limit a COMBINATION of
+      // the stage's HO rate and the earlier limited updates, so the stage cannot be the one-kernel rmh_stage_fused:
+      // HO kernel + fused limiter kernel (fused = 1) or the reference's call sequence (fused = 0).
+      const bool ps = cfg->ps != 0;
+      const int ode_type = cfg->ode_solver ? cfg->ode_solver : 3;
+      const bool idp = ode_type > 10;
+      RMH_VERIFY(ode_type == 3 || ode_type == 11 || ode_type == 12 || ode_type == 13, "-s must be 3, 11, 12 or 13");
+      RMH_VERIFY(!ps || cd.exec_mode == 1, "Products are processed only in remap mode.");                         // remhos.cpp:1713
+      RMH_VERIFY(!ps || !cfg->dt_control, "Automatic time step is not implemented for product remap.");           // remhos.cpp:1714
+      RMH_VERIFY(!ps || cc.lo_type == 5, "product remap is built for -lo 5 (what the fused limiter kernel takes)");
       // fused = 1: one kernel per RK stage (rmh_stage_fused with the LO solver and the mass tolerance of the options)
-      const bool fused = cfg->fused != 0;
+      const bool fused = cfg->fused != 0 && !ps && !idp;
       if (fused)
       {
          RMH_CALL(rmh_set_lo_type(ctx, cc.lo_type));
          if (cfg->ho_type == 2) { RMH_CALL(rmh_set_mass_tol(ctx, 1e-12, 0.0, 500)); }
       }
-      AdvectionOperator adv(pfes, dofs, ho_solver, lo_solver, fct_solver, false);
+      AdvectionOperator adv(pfes, dofs, ho_solver, lo_solver, fct_solver, (ps || idp) && cfg->fused != 0 && cc.lo_type == 5, ps);
 
-      Vector u(vsize);
+      // Primary scalar field is u; for product remap we also evolve us (remhos.cpp:875-904): S = [u | us]
+      Vector S((ps ? 2 : 1) * vsize);
+      Vector u(S.ReadWrite(), vsize);
       u.CopyFromHost(cd.u0.data());
-      std::vector<double> h_u(vsize), h_m(vsize);
+      std::vector<double> h_u(vsize), h_m(vsize), h_us(ps ? vsize : 0);
+      if (ps)
+      {
+         // s = s0 where the element is active (BoolFunctionCoefficient on ComputeBoolIndicators(u), remhos.cpp:890-894),
+         // us = u * s node by node ("we don't target conservation at initialization", :899-900)
+         for (int e = 0; e < cd.ne_owned; e++)
+         {
+            bool active = false;
+            for (int i = 0; i < cd.ndof; i++) { active = active || cd.u0[(size_t)e * cd.ndof + i] > 1e-12; } // EMPTY_ZONE_TOL
+            for (int i = 0; i < cd.ndof; i++)
+            {
+               const size_t k = (size_t)e * cd.ndof + i;
+               h_us[k] = cd.u0[k] * (active ? cd.s0[k] : 0.0);
+            }
+         }
+         Vector us(S.ReadWrite() + vsize, vsize);
+         us.CopyFromHost(h_us.data());
+      }
       // initial mass (remhos.cpp:1073-1076)
       Vector masses(vsize);
       RMH_CALL(rmh_compute_lumped_mass(ctx, 0.0, masses.Write()));
@@ -380,6 +583,8 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       long double mass0_acc = 0.0L;
       for (int i = 0; i < vsize; i++) { mass0_acc += (long double)h_m[i] * cd.u0[i]; }
       const double mass0 = (double)mass0_acc;
+      long double mass0_us_acc = 0.0L;
+      for (int i = 0; i < (ps ? vsize : 0); i++) { mass0_us_acc += (long double)h_m[i] * h_us[i]; } // remhos.cpp:1077-1081
 
       // Print the starting mesh and initial condition (remhos.cpp:1015-1030)
       if (cfg->save)
@@ -387,7 +592,16 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
          const std::string e = save_mfem(cd, 0.0, cd.u0.data(), "meshHO_init.mesh", "sltn_init.gf");
          RMH_VERIFY(e.empty(), e.c_str());
       }
-      RK3SSPSolver ode_solver;
+      ODESolver *ode_solver_p = nullptr; // remhos.cpp:486-500
+      switch (ode_type)
+      {
+         case 11: ode_solver_p = new ForwardEulerIDPSolver(); break;
+         case 12: ode_solver_p = new RK2IDPSolver(); break;
+         case 13: ode_solver_p = new RK3IDPSolver(); break;
+         default: ode_solver_p = new RK3SSPSolver(); break;
+      }
+      ODESolver &ode_solver = *ode_solver_p;
+      const int stages_per_step = ode_type == 11 ? 1 : (ode_type == 12 ? 2 : 3);
       double t = 0.0;
       adv.SetTime(t);
       ode_solver.Init(adv);
@@ -422,7 +636,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
             RMH_CALL(rmh_stage_fused(ctx, y2.Read(), dt_real, u.Read(), 1. / 3, 2. / 3, dt_real, u.Write(), nullptr));
             t += dt_real;
          }
-         else { ode_solver.Step(u, t, dt_real); }
+         else { ode_solver.Step(S, t, dt_real); }
          ti++;
          ti_total++;
          if (dtc)
@@ -470,6 +684,29 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
          umax = std::fmax(umax, h_u[i]);
       }
       const double mass = (double)mass_acc;
+      if (u_final) { std::copy(h_u.begin(), h_u.end(), u_final); }
+      if (ps)
+      {
+         // remhos.cpp:1404, 1416-1434: mass of us with the same lumped masses; max of the ratio s = us / u
+         Vector us(S.ReadWrite() + vsize, vsize), s_fin(vsize);
+         us.CopyToHost(h_us.data());
+         if (us_final) { std::copy(h_us.begin(), h_us.end(), us_final); }
+         long double acc = 0.0L;
+         for (int i = 0; i < vsize; i++) { acc += (long double)h_m[i] * h_us[i]; }
+         bool *flags = nullptr;
+         HIP_CALL(hipMalloc((void **)&flags, (size_t)cd.ne_owned + vsize));
+         Array<bool> el(flags, cd.ne_owned), dfl(flags + cd.ne_owned, vsize);
+         ComputeRatio(pfes, us, u, s_fin, el, dfl);
+         std::vector<double> h_s(vsize);
+         s_fin.CopyToHost(h_s.data());
+         (void)hipFree(flags);
+         double smax = -INFINITY;
+         for (int i = 0; i < vsize; i++) { smax = std::fmax(smax, h_s[i]); }
+         res->final_mass_us = (double)acc;
+         res->mass0_us = (double)mass0_us_acc;
+         res->mass_loss_us = std::fabs(res->mass0_us - res->final_mass_us);
+         res->s_max = smax;
+      }
       adv.Timer().Update(ctx);
       const TimingData &T = adv.Timer();
       res->final_mass = mass;
@@ -479,7 +716,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       res->dt = dt;
       res->t_end = t;
       res->steps = ti;
-      res->stages = 3 * ti_total; // the FOMs count repeated steps too (remhos.cpp:1340-1348)
+      res->stages = stages_per_step * ti_total; // the FOMs count repeated steps too (remhos.cpp:1340-1348)
       res->global_dofs = pfes.GlobalVSize();
       res->t_rhs = T.sw_rhs;
       res->t_inv = T.sw_L2inv;
@@ -498,6 +735,7 @@ extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res)
       rmh_last_cg_iters(ctx, &it);
       res->cg_iters_max = it;
       res->repeats = repeats;
+      delete ode_solver_p;
       delete fct_solver;
       delete lo_solver;
       delete ho_solver;

@@ -188,6 +188,9 @@ double u0_function(int problem, const double *bb_min, const double *bb_max, cons
    }
 }
 
+// Simple nonlinear function (remhos.cpp:2357-2361): physical coordinates, no bounding-box map
+double s0_function(const double x[3]) { return 2.0 + std::sin(2 * M_PI * x[0]) * std::sin(2 * M_PI * x[1]); }
+
 std::string build_case(const CaseConfig &cfg, CaseData &out)
 {
    MeshDef md;
@@ -323,6 +326,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    out.x0.resize((size_t)ne * 81);
    out.vel.resize((size_t)ne * 81);
    out.u0.resize((size_t)ne * out.ndof);
+   out.s0.resize((size_t)ne * out.ndof);
    const bool lo4 = cfg.lo_type == 4;
    if (lo4) { out.subcell_vel.assign((size_t)ne * 3 * out.ndof, 0.0); }
    out.owned_gid.resize(ne);
@@ -373,6 +377,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
                   }
                   const int i = ix + D * (iy + D * iz);
                   out.u0[(size_t)e * out.ndof + i] = u0_function(problem, bmin, bmax, x);
+                  out.s0[(size_t)e * out.ndof + i] = s0_function(x);
                   if (lo4)
                   {
                      // remap: v_sub_gf, the instantaneous velocity at the sub-mesh nodes, zero on the
@@ -546,6 +551,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
       permute_rows(out.x0, 81);
       permute_rows(out.vel, 81);
       permute_rows(out.u0, (size_t)out.ndof);
+      permute_rows(out.s0, (size_t)out.ndof);
       permute_rows(out.subcell_vel, (size_t)3 * out.ndof);
       permute_rows(out.owned_gid, 1);
       permute_rows(out.stencil27, 27);

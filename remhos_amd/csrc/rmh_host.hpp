@@ -52,6 +52,7 @@ struct CaseData
    std::vector<double> x0;          // [ne_owned][3][27]
    std::vector<double> vel;         // [ne_owned][3][27]
    std::vector<double> u0;          // [ne_owned][ndof]
+   std::vector<double> s0;          // [ne_owned][ndof] s0_function at the same nodes (product remap, remhos.cpp:892-894)
    std::vector<double> subcell_vel; // [ne_owned][3][ndof] (lo 4 only)
    std::vector<int> face_nbr;       // [ne_owned][6]
    std::vector<int> stencil27;      // [ne_owned][27]
@@ -62,6 +63,7 @@ struct CaseData
 // problem definitions (remhos.cpp:2001-2120, 2201-2355)
 void velocity_function(int problem, const double *bb_min, const double *bb_max, const double x[3], double v[3]);
 double u0_function(int problem, const double *bb_min, const double *bb_max, const double x[3]);
+double s0_function(const double x[3]); // remhos.cpp:2357-2361
 
 // returns an empty string on success, an error message otherwise
 std::string build_case(const CaseConfig &cfg, CaseData &out);

@@ -93,3 +93,24 @@ def test_survey_cross_checks(name, kw, e):
     else:
         assert _r10(out["mass"]) == e["mass"]
     assert _r10(out["max"]) == e["max"]
+
+
+def test_product_remap_idp3():
+    """Product-field remap, the reference's "Product remap 2D IDP3 (FCTProject)" run (autotest/out_baseline.dat:197-200:
+    -ho 3 -lo 5 -fct 4 -ps -s 13 on inline-quad): 200 RK3-IDP steps of (u, us) through Remhos.limit_mult / step_idp,
+    i.e. through compute_ratio, elem_minmax_masked, the bounds of s over the old active dofs, the compatible LO product,
+    the scaled bounds, the FCT solve and ZeroOutEmptyDofs (remhos.cpp:1848-1915, remhos_fct.cpp:26-153, 733-758,
+    remhos_sync.cpp, remhos_solvers.cpp:42-250).  Both printed masses, 10 digits.  This is what pins the checker of the
+    HIP product kernels (tests/test_gpu_product.py, tests/test_gpu_product_run.py)."""
+    import json
+    import os
+
+    from oracle.remhos_oracle import Config, Remhos
+
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat.json")))["product_remap"][0]
+    r = Remhos(Config(mesh=kat["mesh"], rs=kat["rs"], order=kat["order"], problem=kat["problem"], dt=kat["dt"],
+                      t_final=kat["t_final"], ho=kat["ho"], lo=kat["lo"], fct=kat["fct"], ps=True, ode=kat["ode"]))
+    out = r.run()
+    assert out["steps"] == kat["steps"]
+    assert float(f"{out['mass']:.10g}") == kat["mass"]
+    assert float(f"{out['mass_us']:.10g}") == kat["mass_us"]
