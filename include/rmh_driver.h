@@ -102,6 +102,11 @@ typedef struct {
    long long send_bytes_per_stage, recv_bytes_per_stage; /* this rank's halo records per RK stage                     */
    /* -ps (remhos.cpp:1404, 1416-1434): */
    double final_mass_us, mass0_us, mass_loss_us, s_max;
+   /* error norms against the exact field where one exists (remhos.cpp:1438-1470, ComputeLpError: quadrature of order
+    * 2 p + 3, L-infinity over the quadrature points): problem 4 (rotation) against the initial condition like the
+    * reference, problem 0 on the periodic meshes against u0(x - v t) wrapped into the box; has_errors = 0 otherwise */
+   int has_errors, pad2_;
+   double err_l1, err_l2, err_linf;
 } rmhd_result;
 
 /* remhos() on one GPU (px = py = pz = 1): setup, time loop (RK3 SSP, or the IDP solvers -s 11 / 12 / 13; with -ps

@@ -1126,6 +1126,33 @@ class Remhos:
         self.steps = ti
         return self.report()
 
+    def lp_errors(self):
+        """L1, L2, Linf of u_h - u_ex the way remhos() computes them (remhos.cpp:1438-1470, ParGridFunction::ComputeLpError
+        [MFEM]: Gauss-Legendre rule of order 2 p + 3 per element, Linf over the quadrature points): problem 4 against the
+        initial condition (what the reference prints), problem 0 on a periodic mesh against u0(x - v t) wrapped into the
+        box.  None where no exact field is defined."""
+        prob = self.cfg.problem % 10
+        if self.exec_mode != 0 or prob not in (0, 4) or (prob == 0 and not self.lat.periodic):
+            return None
+        T, dim = self.T, self.dim
+        xq, wq = gauss_legendre_01(T.p + 2)
+        B, _ = bernstein(T.p, xq)
+        L, dL = lagrange(gll_nodes(T.mo), xq)
+        Phi = kron_list([B] * dim)
+        Psi = kron_list([L] * dim)
+        dPsi = [kron_list([dL if d == c else L for d in range(dim)]) for c in range(dim)]
+        w = kron_list([wq.reshape(-1, 1)] * dim).ravel()
+        X = self.X0
+        x = np.einsum("qn,enc->eqc", Psi, X)
+        J = np.stack([np.einsum("qn,enc->eqc", dPsi[c], X) for c in range(dim)], axis=-1)
+        wd = w[None, :] * np.abs(det(J))
+        if prob == 0:
+            v = self.vel(np.zeros((1, dim)))[0]
+            length = self.bb_max - self.bb_min
+            x = self.bb_min + np.mod(x - v * self.t - self.bb_min, length)
+        e = np.abs(self.u @ Phi.T - u0_function(self.cfg.problem, x, self.bb_min, self.bb_max))
+        return float((wd * e).sum()), float(np.sqrt((wd * e * e).sum())), float(e.max())
+
     def report(self):
         if self.exec_mode == 1:
             self.update_geometry(self.t)
@@ -1139,6 +1166,9 @@ class Remhos:
             s, _, _ = compute_ratio(self.us, self.u)
             mass_us = float((masses * self.us).sum())
             extra = {"mass_us": mass_us, "s_max": float(s.max()), "mass_loss_us": abs(self.mass0_us - mass_us)}
+        errs = self.lp_errors()
+        if errs is not None:
+            extra.update(err_l1=errs[0], err_l2=errs[1], err_linf=errs[2])
         return {
             **extra,
             "mass": mass,

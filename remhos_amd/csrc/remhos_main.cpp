@@ -82,6 +82,7 @@ int main(int argc, char **argv)
                "(megadofs x time steps / second)\n---\n", r.fom_rhs, r.fom_inv, r.fom_lo, r.fom_fct, r.fom);
    std::printf("FOM wall (everything included): %.8g\nmax local PCG iterations: %d\n", r.fom_wall, r.cg_iters_max);
    std::printf("Final mass u:  %.10g\nMax value u:   %.10g\nMass loss u:   %.6g\n", r.final_mass, r.max_value, r.mass_loss);
+   if (r.has_errors) { std::printf("L1-error: %.10g. (L2 %.10g, Linf %.10g)\n", r.err_l1, r.err_l2, r.err_linf); } // remhos.cpp:1441-1442
    if (c.ps) // remhos.cpp:1429-1435
    {
       std::printf("Final mass us: %.10g\nMax value s:   %.10g\nMass loss us:  %.6g\n", r.final_mass_us, r.s_max, r.mass_loss_us);

@@ -685,6 +685,17 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
       }
       const double mass = (double)mass_acc;
       if (u_final) { std::copy(h_u.begin(), h_u.end(), u_final); }
+      {
+         // Compute errors, if the exact solution is known (remhos.cpp:1438-1470)
+         double es[3];
+         if (lp_error_sums(cd, cc.problem, t, h_u.data(), es).empty())
+         {
+            res->has_errors = 1;
+            res->err_l1 = es[0];
+            res->err_l2 = std::sqrt(es[1]);
+            res->err_linf = es[2];
+         }
+      }
       if (ps)
       {
          // remhos.cpp:1404, 1416-1434: mass of us with the same lumped masses; max of the ratio s = us / u
@@ -924,6 +935,8 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       if (rccl) { if (rmh_allreduce(blocks[0].ctx, &v, 1, op) != 0) { reduce_failed = true; } }
       return v;
    };
+   bool want_errors = false, have_errors = false;
+   double err_sums[3] = {0, 0, 0};
    auto mass_and_max = [&](double t, double &mass, double &umax) -> bool
    {
       mass = 0.0; umax = -INFINITY;
@@ -937,6 +950,12 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
          long double acc = 0.0L; // (extended precision: see rmhd_run)
          for (int i = 0; i < b.vsize; i++) { acc += (long double)hm[i] * hu[i]; umax = std::fmax(umax, hu[i]); }
          mass += (double)acc;
+         double es[3];
+         if (want_errors && lp_error_sums(b.cd, cc0.problem, t, hu.data(), es).empty())
+         {
+            have_errors = true;
+            err_sums[0] += es[0]; err_sums[1] += es[1]; err_sums[2] = std::fmax(err_sums[2], es[2]);
+         }
       }
       mass = reduce(mass, 0);  // MPI_Allreduce SUM, remhos.cpp:1412
       umax = reduce(umax, 2);  // MPI_Allreduce MAX, remhos.cpp:1415
@@ -1034,7 +1053,14 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    (void)reduce(0.0, 0); // (every rank has finished its last stage)
    const auto w1 = std::chrono::steady_clock::now();
    double mass = 0, umax = 0;
+   want_errors = true; // (remhos.cpp:1438-1470; MPI-reduced like ComputeLpError)
    if (!mass_and_max(t, mass, umax)) { g_driver_error = "final mass"; cleanup(); return -1; }
+   if (have_errors)
+   {
+      err_sums[0] = reduce(err_sums[0], 0);
+      err_sums[1] = reduce(err_sums[1], 0);
+      err_sums[2] = reduce(err_sums[2], 2);
+   }
    double tk = 0.0;
    int itmax = 0;
    for (Block &b : blocks)
@@ -1053,6 +1079,13 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    res->max_value = umax;
    res->mass0 = mass0;
    res->mass_loss = std::fabs(mass0 - mass);
+   if (have_errors)
+   {
+      res->has_errors = 1;
+      res->err_l1 = err_sums[0];
+      res->err_l2 = std::sqrt(err_sums[1]);
+      res->err_linf = err_sums[2];
+   }
    res->dt = dt;
    res->t_end = t;
    res->steps = ti;

