@@ -249,7 +249,7 @@ int rmh_limit_fused_lo(rmh_ctx *ctx, const double *u, const double *du_ho, const
  * LimitMult (remhos_solvers.hpp:46-50, remhos.cpp:1596-1916) and the RK vector update
  *   y_out = a * x_base + b * (u + dt_rk * du)          (x_base may be NULL: a is ignored)
  * du_HO, du_LO, the lumped mass and the per-dof bounds never leave the compute unit; the element extrema
- * of y_out are kept for the next stage (normally its input).  du (may be NULL) receives the limited rate.
+ * of y_out are kept for the next stage (rmh_stage_fused_chain).  du (may be NULL) receives the limited rate.
  * y_out must not alias u (other workgroups still read neighbour traces of u); it may alias x_base.
  * Ghost values of u and ghost extrema must be set for multi-rank runs. */
 int rmh_stage_fused(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
@@ -259,13 +259,21 @@ int rmh_stage_fused(rmh_ctx *ctx, const double *u, double dt, const double *x_ba
  * the elements that touch no ghost while the halo exchange (ParGridFunction::ExchangeFaceNbrData,
  * remhos_ho.cpp:122, and the min/max GroupCommunicator of remhos_tools.cpp:461-466) is in flight, and
  * the halo-dependent ones after it.  All ranges of one stage take the same arguments; finish != 0 on
- * the last one (the element extrema of y_out then become the next stage's input extrema). */
+ * the last one (the element extrema of y_out then become the context's, see rmh_stage_fused_chain). */
 int rmh_stage_fused_range(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b,
                           double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish);
 
-/* rmh_stage_fused keeps the element extrema of y_out and reuses them when the next call's input IS that vector
- * (same pointer).  A caller that changes the contents of that vector in between (e.g. restores a saved state
- * when a step is repeated, remhos.cpp:1181-1193) must announce it here; the next stage then recomputes them. */
+/* Chained stages.  A finished stage leaves the element extrema of y_out in the context and names them with a token
+ * (never 0).  The next stage needs the extrema of ITS input for the bounds: presenting that token (in_token) is the
+ * caller's statement "u is the untouched y_out of the stage that returned this token" and saves the streaming pass that
+ * recomputes them; in_token = 0, a stale token, or any other entry point called in between costs that pass and nothing
+ * else -- there is no way to get bounds from extrema that do not belong to u.  All range calls of one stage pass the same
+ * in_token; *out_token (may be NULL) is set by the finishing call (0 before).  rmh_stage_fused / rmh_stage_fused_range
+ * are this call with in_token = 0.  rmh_invalidate_extrema drops the context's token (kept for callers of the earlier,
+ * pointer-keyed interface; not needed with tokens: a caller that modified the vector simply does not present one). */
+int rmh_stage_fused_chain(rmh_ctx *ctx, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,
+                          double *y_out, double *du, int e_begin, int e_end, int finish, unsigned long long in_token,
+                          unsigned long long *out_token);
 int rmh_invalidate_extrema(rmh_ctx *ctx);
 
 /* Which LOSolver rmh_stage_fused runs inside the stage kernel: 5 = MassBasedAvg (default), 4 =

@@ -16,7 +16,7 @@ SYMBOLS = [
     "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_lo_rd", "rmh_elem_minmax", "rmh_bounds",
-    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range",
+    "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range", "rmh_stage_fused_chain",
     "rmh_halo_pack_records", "rmh_set_ghost_records", "rmh_timers", "rmh_reset_timers", "rmh_enable_timers",
     "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_mass_completion", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
@@ -100,6 +100,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_halo_pack_records.argtypes = [p, p, p, C.c_int, p]
     lib.rmh_set_ghost_records.argtypes = [p, p]
     lib.rmh_stage_fused_range.argtypes = [p, p, d, p, d, d, d, p, p, C.c_int, C.c_int, C.c_int]
+    lib.rmh_stage_fused_chain.argtypes = [p, p, d, p, d, d, d, p, p, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     lib.rmh_timers.argtypes = [p, C.POINTER(d * 4)]
     lib.rmh_reset_timers.argtypes = [p]
     lib.rmh_enable_timers.argtypes = [p, i]
@@ -254,14 +255,16 @@ class Context:
         self._check(self.lib.rmh_limit_fused_lo(self.h, _ptr(u), _ptr(du_ho), _ptr(du_lo), float(dt), _ptr(du),
                                                 _ptr(x_base), float(a), float(b), float(dt_rk), _ptr(y_out)))
 
-    def stage_fused(self, u, dt, y_out, x_base=None, a=0.0, b=1.0, dt_rk=0.0, du=None):
-        self._check(self.lib.rmh_stage_fused(self.h, _ptr(u), float(dt), _ptr(x_base), float(a), float(b), float(dt_rk),
-                                             _ptr(y_out), _ptr(du)))
+    def stage_fused(self, u, dt, y_out, x_base=None, a=0.0, b=1.0, dt_rk=0.0, du=None, token=0):
+        """token: what the stage that wrote u returned (0: the extrema of u are recomputed); returns the token of y_out"""
+        return self.stage_fused_range(u, dt, y_out, 0, self.ne, True, x_base=x_base, a=a, b=b, dt_rk=dt_rk, du=du, token=token)
 
-    def stage_fused_range(self, u, dt, y_out, e_begin, e_end, finish, x_base=None, a=0.0, b=1.0, dt_rk=0.0, du=None):
-        self._check(self.lib.rmh_stage_fused_range(self.h, _ptr(u), float(dt), _ptr(x_base), float(a), float(b),
+    def stage_fused_range(self, u, dt, y_out, e_begin, e_end, finish, x_base=None, a=0.0, b=1.0, dt_rk=0.0, du=None, token=0):
+        out = C.c_ulonglong(0)
+        self._check(self.lib.rmh_stage_fused_chain(self.h, _ptr(u), float(dt), _ptr(x_base), float(a), float(b),
                                                    float(dt_rk), _ptr(y_out), _ptr(du), int(e_begin), int(e_end),
-                                                   1 if finish else 0))
+                                                   1 if finish else 0, int(token), C.byref(out)))
+        return out.value
 
     def enable_timers(self, on=True):
         self._check(self.lib.rmh_enable_timers(self.h, 1 if on else 0))

@@ -28,6 +28,14 @@ int fail(int code, const std::string &msg)
 namespace
 {
 
+// the context's element extrema no longer belong to the output of a finished fused stage: no token is valid, and a
+// stage that was left unfinished is forgotten
+inline void extrema_dropped(rmh_ctx *c)
+{
+   c->xe_token = 0;
+   c->stage_open = false;
+}
+
 int timers_resolve(rmh_ctx *c);
 
 int timer_begin(rmh_ctx *c, int bucket, EventPair &ep)
@@ -460,7 +468,7 @@ int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
    if (rc) { return rc; }
    rc = timer_end(c, 0, ep);
    c->ho_done = true;
-   c->xe_of = nullptr; // see rmh_stage_fused_range: only the fused stage chain sets it
+   extrema_dropped(c);
    return rc;
 }
 
@@ -482,7 +490,7 @@ int rmh_lo_massavg(rmh_ctx *c, const double *u, const double *du_ho, double dt, 
 {
    if (!c || !u || !du_ho || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
-   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
+   extrema_dropped(c);
    if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_lo_massavg needs the lumped mass of rmh_ho_apply"); }
    EventPair ep;
    int rc = timer_begin(c, 2, ep);
@@ -498,7 +506,7 @@ namespace
 int lo_rd(rmh_ctx *c, const double *u, double *du_lo, int lo_type)
 {
    RMH_ENTER(c);
-   c->xe_of = nullptr; // (d_xe_min/max now hold the extrema of u, but only the fused stage chain may rely on xe_of)
+   extrema_dropped(c);
    EventPair ep;
    int rc = timer_begin(c, 2, ep);
    if (rc) { return rc; }
@@ -543,7 +551,7 @@ int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u
 {
    if (!c || !xe_min || !xe_max || !u_min || !u_max) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
-   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
+   extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
                                       c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
@@ -560,7 +568,7 @@ int rmh_fct_clipscale(rmh_ctx *c, const double *u, const double *m, const double
       return fail(RMH_ERR_INVALID, "null argument");
    }
    RMH_ENTER(c);
-   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
+   extrema_dropped(c);
    EventPair ep;
    int rc = timer_begin(c, 3, ep);
    if (rc) { return rc; }
@@ -575,7 +583,7 @@ int rmh_product_ratio(rmh_ctx *c, const double *us, const double *u, double *s, 
 {
    if (!c || !u || !active_el || !active_dofs || ((us != nullptr) != (s != nullptr))) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
-   c->xe_of = nullptr;
+   extrema_dropped(c);
    RMH_DISPATCH(c, hipLaunchKernelGGL((product_ratio_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, us, u, s,
                                       active_el, active_dofs));
    RMH_HIP(hipGetLastError());
@@ -604,7 +612,7 @@ int rmh_fct_product(rmh_ctx *c, const double *us, const double *m, const double 
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    if (c->ng > 0) { return fail(RMH_ERR_STATE, "product remap is single-rank (the ghost extrema of s are not exchanged)"); }
    RMH_ENTER(c);
-   c->xe_of = nullptr;
+   extrema_dropped(c);
    EventPair ep;
    int rc = timer_begin(c, 3, ep);
    if (rc) { return rc; }
@@ -620,7 +628,7 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    if (!c || !u || !du_ho || (!du && !y_out)) { return fail(RMH_ERR_INVALID, "null argument"); }
    if (!c->ho_done) { return fail(RMH_ERR_STATE, "rmh_limit_fused must follow rmh_ho_apply on the same u"); }
    RMH_ENTER(c);
-   c->xe_of = nullptr; // writes caller vectors: the cached extrema may no longer describe what xe_of points to
+   extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    LimitArgs la;
    la.u = u;
@@ -664,9 +672,11 @@ int rmh_limit_fused_lo(rmh_ctx *c, const double *u, const double *du_ho, const d
    return limit_fused_impl(c, u, du_ho, du_lo, dt, du, x_base, a, b, dt_rk, y_out);
 }
 
-int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b,
-                          double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish)
+int rmh_stage_fused_chain(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,
+                          double *y_out, double *du, int e_begin, int e_end, int finish, unsigned long long in_token,
+                          unsigned long long *out_token)
 {
+   if (out_token) { *out_token = 0; }
    if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
@@ -679,16 +689,19 @@ int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *
    if (c->lo_type == 3 && c->p < 2) { return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 3 needs order >= 2"); }
    if (c->ng > 0 && (!c->u_ghost || !c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost data not set"); }
    int rc = 0;
-   if (c->xe_of != u)
+   // Element extrema of the stage input.  They are at hand only if the caller PRESENTS the token the stage that wrote u
+   // returned -- its statement that u is that stage's untouched output.  Anything else (no token, a stale one, a vector
+   // that was modified since) costs one streaming pass.  The ranges of one stage share the extrema of its first call.
+   if (!c->stage_open)
    {
-      // element extrema of the stage input are not at hand: one streaming pass (normally they are
-      // left behind by the previous fused stage, whose output is this stage's input).  xe_of is set ONLY by a
-      // finished fused stage (to its y_out) and cleared by every other entry point that writes caller vectors; a
-      // caller that modifies y_out by other means before feeding it back calls rmh_invalidate_extrema
-      rc = rmh_elem_minmax(c, u, c->d_xe_min, c->d_xe_max);
-      if (rc) { return rc; }
-      c->xe_of = u;
+      if (in_token == 0 || in_token != c->xe_token)
+      {
+         rc = rmh_elem_minmax(c, u, c->d_xe_min, c->d_xe_max);
+         if (rc) { return rc; }
+      }
+      c->stage_open = true;
    }
+   c->xe_token = 0; // (until this stage is finished, no token is valid)
    if (e_end > e_begin)
    {
       EventPair ep;
@@ -700,19 +713,28 @@ int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *
    }
    if (finish)
    {
+      // the stage wrote the extrema of y_out beside it: they become the context's, named by a fresh token
       std::swap(c->d_xe_min, c->d_xe_min2);
       std::swap(c->d_xe_max, c->d_xe_max2);
-      c->xe_of = y_out;
+      c->xe_token = ++c->xe_counter;
+      c->stage_open = false;
+      if (out_token) { *out_token = c->xe_token; }
    }
    c->ho_done = false; // the lumped mass vector is not refreshed by the fused stage
    return rc;
+}
+
+int rmh_stage_fused_range(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b,
+                          double dt_rk, double *y_out, double *du, int e_begin, int e_end, int finish)
+{
+   return rmh_stage_fused_chain(c, u, dt, x_base, a, b, dt_rk, y_out, du, e_begin, e_end, finish, 0, nullptr);
 }
 
 int rmh_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_base, double a, double b, double dt_rk,
                     double *y_out, double *du)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null argument"); }
-   return rmh_stage_fused_range(c, u, dt, x_base, a, b, dt_rk, y_out, du, 0, c->ne, 1);
+   return rmh_stage_fused_chain(c, u, dt, x_base, a, b, dt_rk, y_out, du, 0, c->ne, 1, 0, nullptr);
 }
 
 int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend, double *rows, double *out_min,
@@ -786,7 +808,7 @@ int rmh_set_lo_type(rmh_ctx *c, int lo_type)
 int rmh_invalidate_extrema(rmh_ctx *c)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
-   c->xe_of = nullptr;
+   extrema_dropped(c);
    return RMH_OK;
 }
 

@@ -47,7 +47,10 @@ struct rmh_ctx
    double *d_fgeo = nullptr;                        // face speed coefficients (face_geom_kernel)
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
    double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
-   const double *xe_of = nullptr;                     // vector whose element extrema d_xe_min/max hold
+   // d_xe_min / d_xe_max hold the element extrema of the output of the last FINISHED fused stage iff xe_token != 0; the
+   // stage returned that token, and only a caller that presents it gets them reused (rmh_stage_fused_chain)
+   unsigned long long xe_token = 0, xe_counter = 0;
+   bool stage_open = false; // between the first range call of a stage and its finishing call
    int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
    const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
    int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)

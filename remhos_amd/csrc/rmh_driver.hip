@@ -612,6 +612,7 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
       HIP_CALL(hipDeviceSynchronize());
       const auto w0 = std::chrono::steady_clock::now();
       Vector y1(fused ? vsize : 0), y2(fused ? vsize : 0);
+      unsigned long long tok_u = 0;
       Vector Sold(dtc ? vsize : 0);
       int repeats = 0;
       while (!done)
@@ -628,12 +629,15 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
          {
             // one kernel per RK stage (rmh_stage_fused): same stage times and combinations as
             // RK3SSPSolver::Step; input and output vectors of a stage differ
+            // (tok_u names the element extrema of u left by the stage that wrote it: rmh_stage_fused_chain)
+            unsigned long long tok = 0;
+            const int ne = cd.ne_owned;
             RMH_CALL(rmh_setup(ctx, t));
-            RMH_CALL(rmh_stage_fused(ctx, u.Read(), dt_real, nullptr, 0.0, 1.0, dt_real, y1.Write(), nullptr));
+            RMH_CALL(rmh_stage_fused_chain(ctx, u.Read(), dt_real, nullptr, 0.0, 1.0, dt_real, y1.Write(), nullptr, 0, ne, 1, tok_u, &tok));
             RMH_CALL(rmh_setup(ctx, t + dt_real));
-            RMH_CALL(rmh_stage_fused(ctx, y1.Read(), dt_real, u.Read(), 3. / 4, 1. / 4, dt_real, y2.Write(), nullptr));
+            RMH_CALL(rmh_stage_fused_chain(ctx, y1.Read(), dt_real, u.Read(), 3. / 4, 1. / 4, dt_real, y2.Write(), nullptr, 0, ne, 1, tok, &tok));
             RMH_CALL(rmh_setup(ctx, t + dt_real / 2));
-            RMH_CALL(rmh_stage_fused(ctx, y2.Read(), dt_real, u.Read(), 1. / 3, 2. / 3, dt_real, u.Write(), nullptr));
+            RMH_CALL(rmh_stage_fused_chain(ctx, y2.Read(), dt_real, u.Read(), 1. / 3, 2. / 3, dt_real, u.Write(), nullptr, 0, ne, 1, tok, &tok_u));
             t += dt_real;
          }
          else { ode_solver.Step(S, t, dt_real); }
@@ -649,7 +653,7 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
                ti--;
                t -= dt_real;
                u = Sold;
-               RMH_CALL(rmh_invalidate_extrema(ctx)); // the fused stage cached the extrema of the rejected state
+               tok_u = 0; // (u is no longer the output of the last stage)
                dt = 0.85 * dt;
                repeats++;
                RMH_VERIFY(dt >= 1e-12, "The time step crashed!");
@@ -766,6 +770,7 @@ struct Block
    rmh_ctx *ctx = nullptr;
    double *x = nullptr, *y1 = nullptr, *y2 = nullptr, *xold = nullptr, *m = nullptr;
    int vsize = 0;
+   unsigned long long tok = 0; // token of the extrema of the vector the next stage reads (rmh_stage_fused_chain)
    hipStream_t stream = nullptr; // the context's stream: a non-blocking one, so that the exchange stream overlaps it
 };
 
@@ -982,14 +987,14 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       for (Block &b : blocks)
       {
          if (rmh_setup(b.ctx, ts) != 0) { return false; }
-         if (rmh_stage_fused_range(b.ctx, in(b), dt_real, which == 0 ? nullptr : b.x, ra, rb, dt_real, out(b), nullptr,
-                                   b.cd.ne_halo, b.cd.ne_owned, 0) != 0) { return false; }
+         if (rmh_stage_fused_chain(b.ctx, in(b), dt_real, which == 0 ? nullptr : b.x, ra, rb, dt_real, out(b), nullptr,
+                                   b.cd.ne_halo, b.cd.ne_owned, 0, b.tok, nullptr) != 0) { return false; }
       }
       for (Block &b : blocks) { if (rmh_exchange_end(b.ctx) != 0) { return false; } }
       for (Block &b : blocks)
       {
-         if (rmh_stage_fused_range(b.ctx, in(b), dt_real, which == 0 ? nullptr : b.x, ra, rb, dt_real, out(b), nullptr, 0,
-                                   b.cd.ne_halo, 1) != 0) { return false; }
+         if (rmh_stage_fused_chain(b.ctx, in(b), dt_real, which == 0 ? nullptr : b.x, ra, rb, dt_real, out(b), nullptr, 0,
+                                   b.cd.ne_halo, 1, b.tok, &b.tok) != 0) { return false; }
       }
       return true;
    };
@@ -1036,7 +1041,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
             for (Block &b : blocks)
             {
                RMHD_HIP(hipMemcpyAsync(b.x, b.xold, sizeof(double) * b.vsize, hipMemcpyDeviceToDevice, b.stream));
-               RMHD_TRY(rmh_invalidate_extrema(b.ctx));
+               b.tok = 0; // (x is no longer the output of the last stage)
             }
             RMHD_HIP(hipDeviceSynchronize());
             dt = 0.85 * dt;

@@ -69,6 +69,7 @@ class Stepper:
             self.m = torch.empty_like(self.x)
         self.t = 0.0
         self.dt = case.dt
+        self.tok_x = 0  # token of the element extrema of self.x (rmh_stage_fused_chain); 0: none
         # Neighbour exchange: plan, pack kernels, ghost records and (with RCCL) the transport live in the library
         # (rmh_exchange_*, include/rmh.h).  Transports: "rccl" = grouped ncclSend/ncclRecv inside the library on a
         # communicator made from a unique id broadcast over the process group; "external" = this class moves the
@@ -181,7 +182,9 @@ class Stepper:
             self.ctx.exchange_end()
 
     # -- one RK stage: out = a*x + b*(u + dt*F(u, t)) ----------------------------------------------
-    def stage(self, u, t, dt, x_base, a, b, out):
+    def stage(self, u, t, dt, x_base, a, b, out, token=0):
+        """token: what the stage that wrote u returned, if u is still that output (one-kernel stage: saves the pass that
+        recomputes the element extrema of u, rmh_stage_fused_chain); returns the token of `out` (0 for the other paths)"""
         c = self.ctx
         if self.defer_exchange:
             works = []  # (lockstep driver of several same-process blocks: it has begun and will end the exchange itself)
@@ -192,23 +195,21 @@ class Stepper:
             # elements that reach no ghost run while the exchange is in flight (the RCCL send/recv
             # kernels live on the library's exchange stream), the halo-dependent shell after it
             nh, ne = self.case.ne_halo, self.case.ne_owned
-            c.stage_fused_range(u, dt, out, nh, ne, False, x_base=x_base, a=a, b=b, dt_rk=dt)
+            c.stage_fused_range(u, dt, out, nh, ne, False, x_base=x_base, a=a, b=b, dt_rk=dt, token=token)
             self.exchange_end(works)
-            c.stage_fused_range(u, dt, out, 0, nh, True, x_base=x_base, a=a, b=b, dt_rk=dt)
-            return
+            return c.stage_fused_range(u, dt, out, 0, nh, True, x_base=x_base, a=a, b=b, dt_rk=dt, token=token)
         if not self.defer_exchange:
             self.exchange_end(works)
         if self.one_kernel:
-            c.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt)
-            return
+            return c.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt, token=token)
         c.ho_apply(u, self.k)
         if self.fused_lo4:
             (c.lo_rd if self.lo == 3 else c.lo_rdsubcell)(u, self.du_lo)
             c.limit_fused_lo(u, self.k, self.du_lo, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
-            return
+            return 0
         if self.fused:
             c.limit_fused(u, self.k, dt, du=None, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
-            return
+            return 0
         # the reference's call sequence (remhos.cpp:1815-1831)
         m = c.lumped_mass_ptr()  # refreshed by rmh_ho_apply at this stage's mesh position (remhos.cpp:1632)
         if self.lo == 4:
@@ -227,6 +228,7 @@ class Stepper:
             out.copy_(b * y)
         else:
             out.copy_(a * x_base + b * y)
+        return 0
 
     def step(self, dt):
         """RK3SSPSolver::Step: stage times t, t+dt, t+dt/2 (SURVEY A.6)."""
@@ -234,9 +236,11 @@ class Stepper:
         if self.one_kernel:
             # the one-kernel stage reads neighbour traces of its input while other workgroups already
             # write the output: input and output must be different vectors (x_base may be the output)
-            self.stage(x, t, dt, None, 0.0, 1.0, y)
-            self.stage(y, t + dt, dt, x, 0.75, 0.25, self.y2)
-            self.stage(self.y2, t + dt / 2, dt, x, 1.0 / 3.0, 2.0 / 3.0, x)
+            # (tok_x: the token of self.x, valid as long as nothing but this chain writes it -- run() drops it when it
+            # restores a saved state)
+            tok = self.stage(x, t, dt, None, 0.0, 1.0, y, token=self.tok_x)
+            tok = self.stage(y, t + dt, dt, x, 0.75, 0.25, self.y2, token=tok)
+            self.tok_x = self.stage(self.y2, t + dt / 2, dt, x, 1.0 / 3.0, 2.0 / 3.0, x, token=tok)
             self.t = t + dt
             return
         self.stage(x, t, dt, None, 0.0, 1.0, y)
@@ -273,7 +277,7 @@ class Stepper:
                     ti -= 1
                     self.t = t_old
                     self.x.copy_(self.x_old)
-                    self.ctx.invalidate_extrema()
+                    self.tok_x = 0  # (x is no longer the output of the last stage: its extrema are recomputed)
                     self.dt = 0.85 * self.dt
                     self.repeats += 1
                     if self.dt < 1e-12:
@@ -308,7 +312,7 @@ def lockstep_step(steppers, dt):
         for s in steppers:
             s.defer_exchange = True
             try:
-                s.stage(get_u(s), s.t + t_off, dt, get_base(s), a, b, get_out(s))
+                s.tok_x = s.stage(get_u(s), s.t + t_off, dt, get_base(s), a, b, get_out(s), token=s.tok_x)
             finally:
                 s.defer_exchange = False
 

@@ -242,3 +242,43 @@ def test_mass_completion_emulated(lib, p):
     assert np.abs(res["cap1"][1] - ref[1]).max() > 1e-4 * sc
     assert np.abs(res["cap1all"][0] - ref[0]).max() < 0.5 * np.abs(res["cap1fix"][0] - ref[0]).max()
     ctx.close()
+
+
+def test_extrema_tokens(lib):
+    """rmh_stage_fused_chain: the element extrema of a stage's output are reused only for a caller that presents the
+    token that stage returned; no token or a stale one costs a recomputation and never gives wrong bounds (the
+    pointer-keyed cache this replaces could: a vector modified in place kept its stale extrema)."""
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh="cube01_hex", rs=0, order=2, problem=10, dt=0.02, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=2, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    u = perturbed(r.u)
+    ctx.setup(0.3)
+    y1, y2, z2 = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+    t1 = ctx.stage_fused(u, cfg.dt, y1)
+    assert t1 != 0
+    t2 = ctx.stage_fused(y1, cfg.dt, y2, token=t1)          # extrema reused
+    assert t2 not in (0, t1)
+    ctx.stage_fused(y1, cfg.dt, z2)                         # recomputed
+    assert np.array_equal(y2, z2)
+    ctx.stage_fused(y1, cfg.dt, z2, token=t1)               # a stale token (two stages old) is not honoured
+    assert np.array_equal(y2, z2)
+    # a vector modified in place: its owner presents no token -- the new extrema are used
+    y1b = y1.copy()
+    y1b[0, :] += 0.25
+    ref = np.zeros_like(u)
+    ctx.stage_fused(y1b, cfg.dt, ref)
+    t1 = ctx.stage_fused(u, cfg.dt, y1)
+    y1[0, :] += 0.25
+    ctx.stage_fused(y1, cfg.dt, z2, token=0)
+    assert np.array_equal(ref, z2)
+    # any other entry point in between drops the token
+    t1 = ctx.stage_fused(u, cfg.dt, y1)
+    dh = np.zeros_like(u)
+    ctx.ho_apply(u, dh)
+    ctx.stage_fused(y1, cfg.dt, z2, token=t1)
+    ctx.stage_fused(y1, cfg.dt, ref)
+    assert np.array_equal(ref, z2)
+    ctx.close()
