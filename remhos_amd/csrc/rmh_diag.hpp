@@ -25,6 +25,10 @@ __device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
       __syncthreads();                                                                 \
       if (threadIdx.x < 32 && blockIdx.x < RMH_STAMP_MAXWG) { g_stamps[blockIdx.x][threadIdx.x] += s_stamp[threadIdx.x]; } \
    } while (0)
+#elif defined(RMH_PHASE_MARKS)
+// diagnostic compile to assembly only (tools/isa_phases.py): a comment per phase boundary in the .s file
+#define RMH_STAMP(k) asm volatile("; RMH_PHASE " #k)
+#define RMH_STAMP_FLUSH()
 #else
 #define RMH_STAMP(k)
 #define RMH_STAMP_FLUSH()

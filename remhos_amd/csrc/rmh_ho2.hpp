@@ -41,13 +41,14 @@ namespace rmh
 // Table rows of the qz loops of the column phase / of the three legs of the PCG's mass apply from the LDS copy
 // (uniform-address reads, in order with the other LDS traffic) instead of scalar loads.  Measured at two wavefronts
 // per SIMD: p = 6 7.43 k -> 7.63 k (column) -> 7.66 k (PCG); p = 5 -0.8 % / -8 %, p = 4 0, p = 3 -3.7 %.  At three
-// wavefronts per SIMD (p = 6 now) the column phase is better off with scalar loads again (11.1 k -> 11.9 k, 100 -> 32
-// B/lane of scratch, 17 % fewer LDS instructions); the PCG legs keep the LDS copy (scalar: -0.5 %).
+// wavefronts per SIMD (p = 6 now) both are better off with scalar loads again: column phase 11.1 k -> 11.9 k (100 -> 32
+// B/lane of scratch, 17 % fewer LDS instructions); PCG legs, with the one or two iterations of the -pa rule, p = 6
+// 16.24 k -> 16.58 k, p = 3 18.29 k -> 18.04 k with the LDS copy, p = 4 -1.7 % with it: scalar loads everywhere.
 #ifndef RMH_COLTAB_LDS
 #define RMH_COLTAB_LDS 0
 #endif
 #ifndef RMH_PCGTAB_LDS
-#define RMH_PCGTAB_LDS (P >= 6)
+#define RMH_PCGTAB_LDS 0
 #endif
 // wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
 // other workgroups on the CU (0: off)
