@@ -9,7 +9,8 @@
 // reference's ctest #3 / #7 final masses (remhos_tests.cpp:63-68, 81-86).
 //
 // Restated from the reference (same algorithm as its CPU partial-assembly path: sum-factorised like MFEM's PA kernels,
-// every contraction specialised on (p + 1, p + 3) at compile time, OpenMP over elements):
+// every contraction specialised on (p + 1, p + 3) at compile time, OpenMP over elements; the HO loop -- geometry, K u,
+// local mass solve -- is vectorised ACROSS elements, batches of 8 (AVX-512) or 4 (AVX2) elements, one per SIMD lane):
 //   HO   : K_vol (ConvectionIntegrator PA apply, remhos.cpp:646-657; qdata remhos_lo.cpp:1155-1190,
 //          apply remhos_lo.cpp:1473-1612) + upwind DG trace (remhos.cpp:659-678) + element-local
 //          Jacobi-PCG mass solve in the Gauss-Legendre basis (DGMassInverse, remhos_ho.cpp:79-80,126)
@@ -143,29 +144,30 @@ struct Tables
 
 // ---- contractions, all extents known at compile time ------------------------------------------------------------
 // out[(k2*N1 + k1)*NQ + q] = sum_i M[q*NI + i] in[(k2*N1 + k1)*NI + i]
-template <int NQ, int NI, int N12>
-inline void cx(const double *M, const double *in, double *out)
+// (T = double: one element; T = vd: a batch of VL elements, one per SIMD lane -- the tables stay scalar)
+template <int NQ, int NI, int N12, class T>
+inline void cx(const double *M, const T *in, T *out)
 {
    for (int k = 0; k < N12; k++)
    {
       for (int q = 0; q < NQ; q++)
       {
-         double acc = 0.0;
+         T acc = T() * 0.0;
          for (int i = 0; i < NI; i++) { acc += M[q * NI + i] * in[k * NI + i]; }
          out[k * NQ + q] = acc;
       }
    }
 }
 // out[(k2*NQ + q)*N0 + k0] = sum_i M[q*NI + i] in[(k2*NI + i)*N0 + k0]
-template <int NQ, int NI, int N0, int N2>
-inline void cy(const double *M, const double *in, double *out)
+template <int NQ, int NI, int N0, int N2, class T>
+inline void cy(const double *M, const T *in, T *out)
 {
    for (int k2 = 0; k2 < N2; k2++)
    {
       for (int q = 0; q < NQ; q++)
       {
-         double acc[N0];
-         for (int k0 = 0; k0 < N0; k0++) { acc[k0] = 0.0; }
+         T acc[N0];
+         for (int k0 = 0; k0 < N0; k0++) { acc[k0] = T() * 0.0; }
          for (int i = 0; i < NI; i++)
          {
             const double m = M[q * NI + i];
@@ -176,12 +178,12 @@ inline void cy(const double *M, const double *in, double *out)
    }
 }
 // out[q*N01 + k] = sum_i M[q*NI + i] in[i*N01 + k]
-template <int NQ, int NI, int N01>
-inline void cz(const double *M, const double *in, double *out)
+template <int NQ, int NI, int N01, class T>
+inline void cz(const double *M, const T *in, T *out)
 {
    for (int q = 0; q < NQ; q++)
    {
-      for (int k = 0; k < N01; k++) { out[q * N01 + k] = 0.0; }
+      for (int k = 0; k < N01; k++) { out[q * N01 + k] = T() * 0.0; }
       for (int i = 0; i < NI; i++)
       {
          const double m = M[q * NI + i];
@@ -190,19 +192,38 @@ inline void cz(const double *M, const double *in, double *out)
    }
 }
 // NI^3 -> NQ^3 with one matrix per direction ([q][i] layout); and the transposed use NQ^3 -> NI^3 with [i][q] matrices
-template <int NQ, int NI>
-inline void interp3(const double *Mx, const double *My, const double *Mz, const double *in, double *out, double *wa, double *wb)
+template <int NQ, int NI, class T>
+inline void interp3(const double *Mx, const double *My, const double *Mz, const T *in, T *out, T *wa, T *wb)
 {
    cx<NQ, NI, NI * NI>(Mx, in, wa);        // [NI][NI][NQ]
    cy<NQ, NI, NQ, NI>(My, wa, wb);         // [NI][NQ][NQ]
    cz<NQ, NI, NQ * NQ>(Mz, wb, out);       // [NQ][NQ][NQ]
 }
-template <int NI, int NQ>
-inline void test3(const double *Mxt, const double *Myt, const double *Mzt, const double *in, double *out, double *wa, double *wb)
+template <int NI, int NQ, class T>
+inline void test3(const double *Mxt, const double *Myt, const double *Mzt, const T *in, T *out, T *wa, T *wb)
 {
    cz<NI, NQ, NQ * NQ>(Mzt, in, wa);       // [NI][NQ][NQ]
    cy<NI, NQ, NQ, NI>(Myt, wa, wb);        // [NI][NI][NQ]
    cx<NI, NQ, NI * NI>(Mxt, wb, out);      // [NI][NI][NI]
+}
+
+// A batch of VL elements, one per SIMD lane (GCC vector extension: lowered to AVX-512 or to pairs of AVX2 operations,
+// whatever the build targets): the element loop of the HO part is vectorised ACROSS elements -- inside one element the
+// contraction extents (3 ... 9) are too short to fill a vector.
+#ifdef __AVX512F__
+constexpr int VL = 8;
+#else
+constexpr int VL = 4;
+#endif
+typedef double vd __attribute__((vector_size(VL * sizeof(double))));
+typedef long long vm __attribute__((vector_size(VL * sizeof(long long))));
+inline vd vsel(vm mask, vd a, vd b) { return mask ? a : b; }
+inline vd vmax0(vd x) { return vsel(x > 0.0, x, x * 0.0); }
+inline bool vany(vm m)
+{
+   bool any = false;
+   for (int l = 0; l < VL; l++) { any = any || m[l] != 0; }
+   return any;
 }
 
 double g_bucket[4] = {0, 0, 0, 0}; // RHS, INV, LO, FCT: max over threads, accumulated over calls
@@ -218,29 +239,40 @@ inline double now()
 
 template <int P>
 int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr, const int *stencil27, double t,
-            double dt, const double *u, double *du, double *ws_m, double *ws_duho, double *ws_xe, double rel_tol)
+            double dt, const double *u, double *du, double *ws_m, double *ws_duho, double *ws_xe, double rel_tol, double abs_tol,
+            int completion)
 {
    static const Tables<P> T;
    constexpr int D = P + 1, Q = P + 3, D2 = D * D, D3 = D2 * D, Q2 = Q * Q, Q3 = Q2 * Q;
    const double alpha = exec_mode == 1 ? 1.0 : -1.0, upw = exec_mode == 1 ? 1.0 : -1.0;
    int itmax = 0;
    double b_rhs = 0.0, b_inv = 0.0, b_lo = 0.0, b_fct = 0.0;
+   const int nbatch = (ne + VL - 1) / VL;
 
+   // HO part: batches of VL elements, lane l = element min(e0 + l, ne - 1) (lanes past the end repeat the last element
+   // and are not stored)
 #pragma omp parallel reduction(max : itmax, b_rhs, b_inv)
    {
-   alignas(64) double X[81], V[81], Jc[9 * Q3], vq[3 * Q3], tmp[Q3], Dq[3 * Q3], wd[Q3], g[Q3], gr[3 * Q3], wa[Q3], wb[Q3];
-   alignas(64) double rhs[D3], rg[D3], xg[D3], dd[D3], Ad[D3], dg[D3], t1[D3], t2[D3], val[Q2], row[Q * D];
+   std::vector<vd> buf((size_t)81 * 2 + 9 * Q3 + 3 * Q3 + Q3 + 3 * Q3 + Q3 + Q3 + 3 * Q3 + Q3 + Q3 + 9 * D3 + Q2 + Q * D + D3);
+   vd *X = buf.data(), *V = X + 81, *Jc = V + 81, *vq = Jc + 9 * Q3, *tmp = vq + 3 * Q3, *Dq = tmp + Q3, *wd = Dq + 3 * Q3,
+      *g = wd + Q3, *gr = g + Q3, *wa = gr + 3 * Q3, *wb = wa + Q3, *rhs = wb + Q3, *rg = rhs + D3, *xg = rg + D3, *dd = xg + D3,
+      *Ad = dd + D3, *dg = Ad + D3, *t1 = dg + D3, *t2 = t1 + D3, *mm = t2 + D3, *val = mm + D3, *row = val + Q2, *uev = row + Q * D;
    double my_rhs = 0.0, my_inv = 0.0;
 #pragma omp for schedule(static)
-   for (int e = 0; e < ne; e++)
+   for (int b = 0; b < nbatch; b++)
    {
       const double c0 = now();
-      const double *ue = u + (size_t)e * D3;
+      int el[VL];
+      for (int l = 0; l < VL; l++) { el[l] = std::min(b * VL + l, ne - 1); }
       for (int i = 0; i < 81; i++)
       {
-         V[i] = vel[(size_t)e * 81 + i];
-         X[i] = x0[(size_t)e * 81 + i] + (exec_mode == 1 ? t * V[i] : 0.0);
+         for (int l = 0; l < VL; l++)
+         {
+            V[i][l] = vel[(size_t)el[l] * 81 + i];
+            X[i][l] = x0[(size_t)el[l] * 81 + i] + (exec_mode == 1 ? t * V[i][l] : 0.0);
+         }
       }
+      for (int i = 0; i < D3; i++) { for (int l = 0; l < VL; l++) { uev[i][l] = u[(size_t)el[l] * D3 + i]; } }
       // geometry at the quadrature points (remap: moved mesh, remhos.cpp:1598-1608)
       for (int c = 0; c < 3; c++)
       {
@@ -257,26 +289,26 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
             for (int qx = 0; qx < Q; qx++)
             {
                const int q = qx + Q * (qy + Q * qz);
-               const double J00 = Jc[0 * Q3 + q], J01 = Jc[1 * Q3 + q], J02 = Jc[2 * Q3 + q];
-               const double J10 = Jc[3 * Q3 + q], J11 = Jc[4 * Q3 + q], J12 = Jc[5 * Q3 + q];
-               const double J20 = Jc[6 * Q3 + q], J21 = Jc[7 * Q3 + q], J22 = Jc[8 * Q3 + q];
-               const double A11 = J11 * J22 - J12 * J21, A12 = J21 * J02 - J01 * J22, A13 = J01 * J12 - J11 * J02;
-               const double A21 = J20 * J12 - J10 * J22, A22 = J00 * J22 - J02 * J20, A23 = J10 * J02 - J00 * J12;
-               const double A31 = J10 * J21 - J20 * J11, A32 = J20 * J01 - J00 * J21, A33 = J00 * J11 - J01 * J10;
-               const double detJ = J00 * A11 + J01 * A21 + J02 * A31;
+               const vd J00 = Jc[0 * Q3 + q], J01 = Jc[1 * Q3 + q], J02 = Jc[2 * Q3 + q];
+               const vd J10 = Jc[3 * Q3 + q], J11 = Jc[4 * Q3 + q], J12 = Jc[5 * Q3 + q];
+               const vd J20 = Jc[6 * Q3 + q], J21 = Jc[7 * Q3 + q], J22 = Jc[8 * Q3 + q];
+               const vd A11 = J11 * J22 - J12 * J21, A12 = J21 * J02 - J01 * J22, A13 = J01 * J12 - J11 * J02;
+               const vd A21 = J20 * J12 - J10 * J22, A22 = J00 * J22 - J02 * J20, A23 = J10 * J02 - J00 * J12;
+               const vd A31 = J10 * J21 - J20 * J11, A32 = J20 * J01 - J00 * J21, A33 = J00 * J11 - J01 * J10;
+               const vd detJ = J00 * A11 + J01 * A21 + J02 * A31;
                const double w3 = T.W[qx] * wyz;
-               const double v0 = vq[q], v1 = vq[Q3 + q], v2 = vq[2 * Q3 + q];
-               Dq[q] = alpha * w3 * (A11 * v0 + A12 * v1 + A13 * v2);
-               Dq[Q3 + q] = alpha * w3 * (A21 * v0 + A22 * v1 + A23 * v2);
-               Dq[2 * Q3 + q] = alpha * w3 * (A31 * v0 + A32 * v1 + A33 * v2);
+               const vd v0 = vq[q], v1 = vq[Q3 + q], v2 = vq[2 * Q3 + q];
+               Dq[q] = (alpha * w3) * (A11 * v0 + A12 * v1 + A13 * v2);
+               Dq[Q3 + q] = (alpha * w3) * (A21 * v0 + A22 * v1 + A23 * v2);
+               Dq[2 * Q3 + q] = (alpha * w3) * (A31 * v0 + A32 * v1 + A33 * v2);
                wd[q] = w3 * detJ;
             }
          }
       }
       // K_vol u
-      interp3<Q, D>(T.G, T.B, T.B, ue, &gr[0], wa, wb);
-      interp3<Q, D>(T.B, T.G, T.B, ue, &gr[Q3], wa, wb);
-      interp3<Q, D>(T.B, T.B, T.G, ue, &gr[2 * Q3], wa, wb);
+      interp3<Q, D>(T.G, T.B, T.B, uev, &gr[0], wa, wb);
+      interp3<Q, D>(T.B, T.G, T.B, uev, &gr[Q3], wa, wb);
+      interp3<Q, D>(T.B, T.B, T.G, uev, &gr[2 * Q3], wa, wb);
       for (int q = 0; q < Q3; q++) { g[q] = Dq[q] * gr[q] + Dq[Q3 + q] * gr[Q3 + q] + Dq[2 * Q3 + q] * gr[2 * Q3 + q]; }
       test3<D, Q>(T.Bt, T.Bt, T.Bt, g, rhs, wa, wb);
       // faces (own outward normal), sum-factorised per face
@@ -284,20 +316,28 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
       {
          const int c = f >> 1, side = f & 1, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
          const int pw3[3] = {1, 3, 9}, pwD[3] = {1, D, D2};
-         const int nb = face_nbr[(size_t)e * 6 + f];
-         const double *un = nb >= 0 ? u + (size_t)nb * D3 : nullptr;
-         // jump of the traces, contracted along i1: row[q1][i2]
-         for (int q1 = 0; q1 < Q; q1++)
+         const double *un[VL];
+         for (int l = 0; l < VL; l++)
          {
-            for (int i2 = 0; i2 < D; i2++)
+            const int nb = face_nbr[(size_t)el[l] * 6 + f];
+            un[l] = nb >= 0 ? u + (size_t)nb * D3 : nullptr;
+         }
+         // jump of the traces, contracted along i1: row[q1][i2]
+         for (int i2 = 0; i2 < D; i2++)
+         {
+            vd jmp[D];
+            for (int i1 = 0; i1 < D; i1++)
             {
-               double acc = 0.0;
-               for (int i1 = 0; i1 < D; i1++)
-               {
-                  const double own = ue[(side ? (D - 1) : 0) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]];
-                  const double nbv = un ? un[(side ? 0 : (D - 1)) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]] : 0.0;
-                  acc += T.B[q1 * D + i1] * (nbv - own);
-               }
+               const int io = (side ? (D - 1) : 0) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2];
+               const int in = (side ? 0 : (D - 1)) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2];
+               vd nbv;
+               for (int l = 0; l < VL; l++) { nbv[l] = un[l] ? un[l][in] : 0.0; }
+               jmp[i1] = nbv - uev[io];
+            }
+            for (int q1 = 0; q1 < Q; q1++)
+            {
+               vd acc = jmp[0] * 0.0;
+               for (int i1 = 0; i1 < D; i1++) { acc += T.B[q1 * D + i1] * jmp[i1]; }
                row[q1 * D + i2] = acc;
             }
          }
@@ -305,7 +345,8 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
          {
             for (int q1 = 0; q1 < Q; q1++)
             {
-               double t1v[3] = {0, 0, 0}, t2v[3] = {0, 0, 0}, vf[3] = {0, 0, 0};
+               vd z = X[0] * 0.0;
+               vd t1v[3] = {z, z, z}, t2v[3] = {z, z, z}, vf[3] = {z, z, z};
                for (int a2 = 0; a2 < 3; a2++)
                {
                   for (int a1 = 0; a1 < 3; a1++)
@@ -321,14 +362,14 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
                      }
                   }
                }
-               const double nx = t1v[1] * t2v[2] - t1v[2] * t2v[1], ny = t1v[2] * t2v[0] - t1v[0] * t2v[2];
-               const double nz = t1v[0] * t2v[1] - t1v[1] * t2v[0];
-               double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
+               const vd nx = t1v[1] * t2v[2] - t1v[2] * t2v[1], ny = t1v[2] * t2v[0] - t1v[0] * t2v[2];
+               const vd nz = t1v[0] * t2v[1] - t1v[1] * t2v[0];
+               vd vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
                if (!side) { vn = -vn; }
-               const double s = std::fmax(0.0, upw * vn) * T.W[q1] * T.W[q2];
-               double jump = 0.0;
+               const vd sp = vmax0(upw * vn) * (T.W[q1] * T.W[q2]);
+               vd jump = z;
                for (int i2 = 0; i2 < D; i2++) { jump += T.B[q2 * D + i2] * row[q1 * D + i2]; }
-               val[q1 + Q * q2] = s * jump;
+               val[q1 + Q * q2] = sp * jump;
             }
          }
          // test with the face's Bernstein functions: along q1 first
@@ -336,7 +377,7 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
          {
             for (int i1 = 0; i1 < D; i1++)
             {
-               double acc = 0.0;
+               vd acc = X[0] * 0.0;
                for (int q1 = 0; q1 < Q; q1++) { acc += T.B[q1 * D + i1] * val[q1 + Q * q2]; }
                row[q2 * D + i1] = acc;
             }
@@ -345,7 +386,7 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
          {
             for (int i1 = 0; i1 < D; i1++)
             {
-               double acc = 0.0;
+               vd acc = X[0] * 0.0;
                for (int q2 = 0; q2 < Q; q2++) { acc += T.B[q2 * D + i2] * row[q2 * D + i1]; }
                rhs[(side ? (D - 1) : 0) * pwD[c] + i1 * pwD[c1] + i2 * pwD[c2]] += acc;
             }
@@ -354,55 +395,84 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
       const double c1 = now();
       my_rhs += c1 - c0;
       // lumped mass M 1 (remhos.cpp:1632) and the local mass solve: Jacobi-PCG in the GL nodal basis
-      test3<D, Q>(T.Bt, T.Bt, T.Bt, wd, &ws_m[(size_t)e * D3], wa, wb);
+      test3<D, Q>(T.Bt, T.Bt, T.Bt, wd, mm, wa, wb);
       // b_g = Ci^T (x)3 b : out[k] = sum_i Ci[i*D+k] in[i]
       cx<D, D, D2>(T.Cit, rhs, t1);
       cy<D, D, D, D>(T.Cit, t1, t2);
       cz<D, D, D2>(T.Cit, t2, rg);
       test3<D, Q>(T.Bg2t, T.Bg2t, T.Bg2t, wd, dg, wa, wb);
-      double nom = 0.0;
+      vd nom = X[0] * 0.0, sum_b = nom, vol = nom;
       for (int i = 0; i < D3; i++)
       {
-         xg[i] = 0.0;
+         xg[i] = nom * 0.0;
          dd[i] = rg[i] / dg[i];
          nom += rg[i] * dd[i];
+         sum_b += rg[i];
+         vol += mm[i];
       }
-      const double tol = rel_tol * rel_tol * nom;
+      // DGMassInverse's stopping rule (remhos_ho.cpp:79-80): (D^-1 r, r) <= max(rel^2 nom0, abs^2); lanes that are done
+      // are frozen (step length 0) while the others of the batch go on
+      vd tol = rel_tol * rel_tol * nom;
+      tol = vsel(tol > abs_tol * abs_tol, tol, tol * 0.0 + abs_tol * abs_tol);
       int it = 0;
-      while (nom > tol && it < 100)
+      vm act = nom > tol;
+      while (vany(act) && it < 100)
       {
          interp3<Q, D>(T.Bg, T.Bg, T.Bg, dd, tmp, wa, wb);
          for (int q = 0; q < Q3; q++) { tmp[q] *= wd[q]; }
          test3<D, Q>(T.Bgt, T.Bgt, T.Bgt, tmp, Ad, wa, wb);
-         double den = 0.0;
+         vd den = nom * 0.0;
          for (int i = 0; i < D3; i++) { den += dd[i] * Ad[i]; }
-         if (!(den > 0.0)) { break; }
-         const double al = nom / den;
-         double bn = 0.0;
+         act = act & (den > 0.0);
+         const vd al = vsel(act, nom / den, nom * 0.0);
+         vd bn = nom * 0.0;
          for (int i = 0; i < D3; i++)
          {
             xg[i] += al * dd[i];
             rg[i] -= al * Ad[i];
             bn += rg[i] * (rg[i] / dg[i]);
          }
-         const double beta = bn / nom;
-         for (int i = 0; i < D3; i++) { dd[i] = rg[i] / dg[i] + beta * dd[i]; }
-         nom = bn;
+         const vd beta = vsel(act, bn / nom, nom * 0.0);
+         for (int i = 0; i < D3; i++) { dd[i] = vsel(act, rg[i] / dg[i] + beta * dd[i], dd[i]); }
+         nom = vsel(act, bn, nom);
+         act = act & (nom > tol);
          it++;
       }
       itmax = std::max(itmax, it);
+      if (completion)
+      {
+         // the completion of the product path (rmh_set_mass_completion): one Jacobi step on the left-over residual ...
+         for (int i = 0; i < D3; i++) { xg[i] += rg[i] / dg[i]; }
+      }
       // x_b = Ci (x)3 x_g : out[i] = sum_k Ci[i*D+k] in[k]
       cx<D, D, D2>(T.Ci, xg, t1);
       cy<D, D, D, D>(T.Ci, t1, t2);
-      cz<D, D, D2>(T.Ci, t2, &ws_duho[(size_t)e * D3]);
-      double lo = INFINITY, hi = -INFINITY;
-      for (int i = 0; i < D3; i++)
+      cz<D, D, D2>(T.Ci, t2, xg);
+      if (completion)
       {
-         lo = std::fmin(lo, ue[i]);
-         hi = std::fmax(hi, ue[i]);
+         // ... and the constant mode: the element's mass rate becomes exactly 1^T b
+         vd mx = nom * 0.0;
+         for (int i = 0; i < D3; i++) { mx += mm[i] * xg[i]; }
+         const vd cst = (sum_b - mx) / vol;
+         for (int i = 0; i < D3; i++) { xg[i] += cst; }
       }
-      ws_xe[e] = lo;
-      ws_xe[ne + e] = hi;
+      vd lo = uev[0], hi = uev[0];
+      for (int i = 1; i < D3; i++)
+      {
+         lo = vsel(uev[i] < lo, uev[i], lo);
+         hi = vsel(uev[i] > hi, uev[i], hi);
+      }
+      for (int l = 0; l < VL && b * VL + l < ne; l++)
+      {
+         const int e = b * VL + l;
+         for (int i = 0; i < D3; i++)
+         {
+            ws_m[(size_t)e * D3 + i] = mm[i][l];
+            ws_duho[(size_t)e * D3 + i] = xg[i][l];
+         }
+         ws_xe[e] = lo[l];
+         ws_xe[ne + e] = hi[l];
+      }
       my_inv += now() - c1;
    }
    b_rhs = my_rhs;
@@ -436,24 +506,36 @@ int stage_t(int ne, int exec_mode, const double *x0, const double *vel, const in
          smin[s] = nb >= 0 ? ws_xe[nb] : INFINITY;
          smax[s] = nb >= 0 ? ws_xe[ne + nb] : -INFINITY;
       }
+      // per-dof bounds = extrema over the elements that share the dof's CG node: a dof on the low / high layer of a
+      // direction also sees the neighbour on that side.  27 boxes per element (low layer, interior, high layer per
+      // direction), then one look-up per dof.
+      double bmin[27], bmax[27];
+      for (int b3 = 0; b3 < 27; b3++)
+      {
+         const int bx = b3 % 3, by = (b3 / 3) % 3, bz = b3 / 9;
+         double lo = INFINITY, hi = -INFINITY;
+         for (int oz = (bz == 0 ? -1 : 0); oz <= (bz == 2 ? 1 : 0); oz++)
+         {
+            for (int oy = (by == 0 ? -1 : 0); oy <= (by == 2 ? 1 : 0); oy++)
+            {
+               for (int ox = (bx == 0 ? -1 : 0); ox <= (bx == 2 ? 1 : 0); ox++)
+               {
+                  const int s = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
+                  lo = std::fmin(lo, smin[s]);
+                  hi = std::fmax(hi, smax[s]);
+               }
+            }
+         }
+         bmin[b3] = lo;
+         bmax[b3] = hi;
+      }
       double sumPos = 0.0, sumNeg = 0.0;
       const double eps = 1.0e-15;
       for (int i = 0; i < D3; i++)
       {
-         const int idx[3] = {i % D, (i / D) % D, i / D2};
-         double umin = INFINITY, umax = -INFINITY;
-         for (int oz = (idx[2] == 0 ? -1 : 0); oz <= (idx[2] == D - 1 ? 1 : 0); oz++)
-         {
-            for (int oy = (idx[1] == 0 ? -1 : 0); oy <= (idx[1] == D - 1 ? 1 : 0); oy++)
-            {
-               for (int ox = (idx[0] == 0 ? -1 : 0); ox <= (idx[0] == D - 1 ? 1 : 0); ox++)
-               {
-                  const int s = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
-                  umin = std::fmin(umin, smin[s]);
-                  umax = std::fmax(umax, smax[s]);
-               }
-            }
-         }
+         const int ix = i % D, iy = (i / D) % D, iz = i / D2;
+         const int b3 = (ix == 0 ? 0 : (ix == D - 1 ? 2 : 1)) + 3 * (iy == 0 ? 0 : (iy == D - 1 ? 2 : 1)) + 9 * (iz == 0 ? 0 : (iz == D - 1 ? 2 : 1));
+         const double umin = bmin[b3], umax = bmax[b3];
          const double u_new_lo = ue[i] + dt * dl[i];
          const double f_clip_min = m[i] / dt * (umin - u_new_lo);
          const double f_clip_max = m[i] / dt * (umax - u_new_lo);
@@ -531,28 +613,31 @@ extern "C" {
 
 // One stage: du = F(u, t) with dt the full step (LO/FCT).  Arrays as in include/rmh.h (host memory).
 // ws_m receives the lumped mass.  Returns the max PCG iteration count.
+// Local mass solve: PCG stopped at (D^-1 r, r) <= max(rel_tol^2 nom0, abs_tol^2) like DGMassInverse (remhos_ho.cpp:79-80);
+// completion != 0 adds the product path's Jacobi step + constant mode (rmh_set_mass_completion).
 int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr,
               const int *stencil27, double t, double dt, const double *u, double *du, double *ws_m,
-              double *ws_duho, double *ws_xe /* [2*ne] */, double rel_tol)
+              double *ws_duho, double *ws_xe /* [2*ne] */, double rel_tol, double abs_tol, int completion)
 {
    int it = 0;
-   CPU_DISPATCH(p, it = stage_t<P>(ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, du, ws_m, ws_duho, ws_xe, rel_tol));
+   CPU_DISPATCH(p, it = stage_t<P>(ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, du, ws_m, ws_duho, ws_xe, rel_tol, abs_tol,
+                                   completion));
    return it;
 }
 
 // RK3-SSP step in place on u (size ne*ndof); work arrays are allocated by the caller (4 * ne*ndof + 2*ne).
 int cpu_rk3_step(int p, int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr,
-                 const int *stencil27, double t, double dt, double *u, double *work, double rel_tol)
+                 const int *stencil27, double t, double dt, double *u, double *work, double rel_tol, double abs_tol, int completion)
 {
    const size_t n = (size_t)ne * (p + 1) * (p + 1) * (p + 1);
    double *y = work, *k = work + n, *m = work + 2 * n, *dh = work + 3 * n, *xe = work + 4 * n;
-   int it = cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, k, m, dh, xe, rel_tol);
+   int it = cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, k, m, dh, xe, rel_tol, abs_tol, completion);
 #pragma omp parallel for
    for (long long i = 0; i < (long long)n; i++) { y[i] = u[i] + dt * k[i]; }
-   it = std::max(it, cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t + dt, dt, y, k, m, dh, xe, rel_tol));
+   it = std::max(it, cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t + dt, dt, y, k, m, dh, xe, rel_tol, abs_tol, completion));
 #pragma omp parallel for
    for (long long i = 0; i < (long long)n; i++) { y[i] = 0.75 * u[i] + 0.25 * (y[i] + dt * k[i]); }
-   it = std::max(it, cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t + dt / 2, dt, y, k, m, dh, xe, rel_tol));
+   it = std::max(it, cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t + dt / 2, dt, y, k, m, dh, xe, rel_tol, abs_tol, completion));
 #pragma omp parallel for
    for (long long i = 0; i < (long long)n; i++) { u[i] = (1.0 / 3.0) * u[i] + (2.0 / 3.0) * (y[i] + dt * k[i]); }
    return it;
@@ -573,6 +658,8 @@ void cpu_buckets(double t[4], int reset)
       if (reset) { g_bucket[k] = 0.0; }
    }
 }
+
+int cpu_simd_width(void) { return VL; } // elements per batch of the HO loop
 
 int cpu_num_threads(void)
 {

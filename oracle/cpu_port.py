@@ -11,15 +11,22 @@ def load():
     # one thread per core, pinned (reported with the baseline): set before the OpenMP runtime starts
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
-    path = os.path.join(_HERE, "libcpu_port.so")
+    name = "libcpu_port.so"
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+        if "avx512f" in flags and "avx512dq" in flags and os.environ.get("RMH_CPU_PORT_AVX2", "0") != "1":
+            name = "libcpu_port_v4.so"  # the element batches of the HO loop are 8 doubles wide
+    except (OSError, StopIteration):
+        pass
+    path = os.path.join(_HERE, name)
     if not os.path.exists(path):
         import subprocess
 
         subprocess.check_call(["make", "-C", _HERE])
     lib = C.CDLL(path)
     p, d, i = C.c_void_p, C.c_double, C.c_int
-    lib.cpu_stage.argtypes = [i, i, i, p, p, p, p, d, d, p, p, p, p, p, d]
-    lib.cpu_rk3_step.argtypes = [i, i, i, p, p, p, p, d, d, p, p, d]
+    lib.cpu_stage.argtypes = [i, i, i, p, p, p, p, d, d, p, p, p, p, p, d, d, i]
+    lib.cpu_rk3_step.argtypes = [i, i, i, p, p, p, p, d, d, p, p, d, d, i]
     lib.cpu_lumped_mass.argtypes = [i, i, i, p, p, d, p]
     lib.cpu_lumped_mass.restype = None
     lib.cpu_buckets.argtypes = [C.POINTER(d * 4), i]
@@ -30,7 +37,9 @@ def load():
 class CpuPort:
     """RK3 stepping of a case (arrays in the C-ABI layouts of include/rmh.h) on the host cores."""
 
-    def __init__(self, order, exec_mode, x0, vel, face_nbr, stencil27, u0, rel_tol=1e-14):
+    def __init__(self, order, exec_mode, x0, vel, face_nbr, stencil27, u0, rel_tol=1e-14, abs_tol=0.0, completion=False):
+        """rel_tol 1e-14: converged local solve (default); (0, 1e-8, True) = the product's -pa rule: DGMassInverse's abs 1e-8
+        (remhos_ho.cpp:79-80) + Jacobi step + constant mode"""
         self.lib = load()
         self.p, self.mode = order, exec_mode
         self.x0 = np.ascontiguousarray(x0, dtype=np.float64)
@@ -41,13 +50,14 @@ class CpuPort:
         self.ne = self.nbr.shape[0]
         self.work = np.zeros(4 * self.u.size + 2 * self.ne)
         self.t = 0.0
-        self.rel_tol = rel_tol
+        self.rel_tol, self.abs_tol, self.completion = rel_tol, abs_tol, int(bool(completion))
         self.threads = self.lib.cpu_num_threads()
+        self.simd_width = self.lib.cpu_simd_width()
 
     def step(self, dt):
         it = self.lib.cpu_rk3_step(self.p, self.ne, self.mode, self.x0.ctypes.data, self.vel.ctypes.data,
                                    self.nbr.ctypes.data, self.st.ctypes.data, self.t, dt, self.u.ctypes.data,
-                                   self.work.ctypes.data, self.rel_tol)
+                                   self.work.ctypes.data, self.rel_tol, self.abs_tol, self.completion)
         self.t += dt
         return it
 
@@ -58,7 +68,7 @@ class CpuPort:
         u = np.ascontiguousarray(u)
         self.lib.cpu_stage(self.p, self.ne, self.mode, self.x0.ctypes.data, self.vel.ctypes.data, self.nbr.ctypes.data,
                            self.st.ctypes.data, t, dt, u.ctypes.data, du.ctypes.data, m.ctypes.data, dh.ctypes.data,
-                           xe.ctypes.data, self.rel_tol)
+                           xe.ctypes.data, self.rel_tol, self.abs_tol, self.completion)
         return du, m, dh
 
     def buckets(self, reset=False):
