@@ -88,13 +88,21 @@ struct RMHContext
    RMHContext &operator=(const RMHContext &) = delete;
 };
 
-// replaces LocalInverseHOSolver (remhos_ho.hpp:56-68, PA branch remhos_ho.cpp:119-128)
+// replaces LocalInverseHOSolver (remhos_ho.hpp:56-68, remhos_ho.cpp:72-128).  Like the reference's constructor it looks at
+// the assembly level: partial assembly -> DGMassInverse's stopping rule (abs 1e-8, rel 0: remhos_ho.cpp:79-80), completed by
+// the two steps of rmh_set_mass_completion (Jacobi step on the left-over residual, constant mode: every stage conserves the
+// mass to round-off); otherwise the element-local solve converged to rel. 1e-14, the stand-in for the exact inverse (:104-115).
 class RMHLocalInverseHOSolver : public HOSolver
 {
    RMHContext &rmh;
 
 public:
-   RMHLocalInverseHOSolver(ParFiniteElementSpace &space, RMHContext &c) : HOSolver(space), rmh(c) {}
+   RMHLocalInverseHOSolver(ParFiniteElementSpace &space, RMHContext &c, bool partial_assembly = true) : HOSolver(space), rmh(c)
+   {
+      const int rc = partial_assembly ? (rmh_set_mass_tol(rmh.ctx, 0.0, 1e-8, 100) | rmh_set_mass_completion(rmh.ctx, 1, 1))
+                                      : (rmh_set_mass_tol(rmh.ctx, 1e-14, 0.0, 100) | rmh_set_mass_completion(rmh.ctx, 0, 0));
+      MFEM_VERIFY(rc == 0, rmh_last_error());
+   }
    void CalcHOSolution(const Vector &u, Vector &du) const override
    {
       MFEM_VERIFY(timer, "Timer not set."); // remhos_ho.cpp:86
