@@ -44,8 +44,7 @@ def _run(tmp_path, mesh, rs, p, prob, steps, part, opts=""):
     return u[order], float(parts[0]["mass"][0]), float(parts[0]["umax"][0])
 
 
-@pytest.mark.parametrize("mesh,rs,p,prob,part", [("periodic-cube", 0, 2, 10, (1, 2, 1)),
-                                                 ("cube01_hex", 1, 1, 10, (2, 2, 1)),
+@pytest.mark.parametrize("mesh,rs,p,prob,part", [("cube01_hex", 1, 1, 10, (2, 2, 1)),
                                                  # p = 3: the wavefront-aligned DPP reductions of the batched kernel, 3 ranks
                                                  ("periodic-cube", 0, 3, 10, (1, 3, 1)),
                                                  # 6^3 elements, 3x6x6 per rank: a non-empty interior range runs while

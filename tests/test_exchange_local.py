@@ -118,9 +118,9 @@ def test_partitioned_cpp_driver_equals_single_block(lib):
     from remhos_amd.case import RmhdResult, make_config
 
     one, many = RmhdResult(), RmhdResult()
-    cfg = make_config("cube01_hex", 1, 1, 10, -1.0, 0.5, max_steps=2)
+    cfg = make_config("cube01_hex", 1, 1, 10, -1.0, 0.5, max_steps=1)
     assert lib.rmhd_run(C.byref(cfg), C.byref(one)) == 0, lib.rmhd_last_error()
-    cfgp = make_config("cube01_hex", 1, 1, 10, -1.0, 0.5, max_steps=2, part=(2, 1, 2))
+    cfgp = make_config("cube01_hex", 1, 1, 10, -1.0, 0.5, max_steps=1, part=(2, 1, 2))
     assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
     assert (many.steps, many.stages, many.global_dofs) == (one.steps, one.stages, one.global_dofs)
     assert many.max_value == one.max_value

@@ -46,6 +46,6 @@ def emulib():
     return bind_driver(load_library(emu_library_path()))
 
 
-@pytest.mark.parametrize("ode,fused", [(13, 1), (12, 0), (11, 1)])
-def test_product_remap_emulated_vs_oracle(emulib, ode, fused):
-    run_both(emulib, "cube01_hex", 1, 2, 0.02, ode, 2, fused, 1e-11)
+@pytest.mark.parametrize("ode,fused,steps", [(13, 1, 1), (12, 0, 1), (11, 1, 2)])
+def test_product_remap_emulated_vs_oracle(emulib, ode, fused, steps):
+    run_both(emulib, "cube01_hex", 0, 2, 0.02, ode, steps + 1, fused, 1e-11)

@@ -103,7 +103,7 @@ def emulib():
     return bind_driver(load_library(emu_library_path()))
 
 
-@pytest.mark.parametrize("p,wrap,lo,compact", [(2, 1, 5, True), (2, 3, 5, False), (3, 2, 4, True)])
+@pytest.mark.parametrize("p,wrap,lo,compact", [(2, 1, 5, True), (2, 3, 5, False), (2, 2, 4, True)])
 def test_selfloop_emulated_equals_plain_periodic(emulib, p, wrap, lo, compact):
     u0 = plain_run(emulib, "cpu", 0, p, 1, lo=lo)
     u1, tr, _ = selfloop_run(emulib, "cpu", 0, p, wrap, 1, lo=lo, compact=compact)
