@@ -1066,6 +1066,28 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
       }
    }
+   else if (!FUSED && !LO4 && NB == 1)
+   {
+      // one element per workgroup (p = 4, 5, 6): from the loaded values in registers -- thread, wavefront (DPP), and the
+      // wavefront results in the spare doubles behind the flags; thread 0 combines them at the end of the kernel (a
+      // serial loop of one thread over the D^3 values in LDS was 22 k cycles at p = 6)
+#pragma unroll
+      for (int j = 0; j < NLU; j++)
+      {
+         const bool in = tid + j * NT < D3;
+         my_min = fmin(my_min, in ? gu[j] : INFINITY);
+         my_max = fmax(my_max, in ? gu[j] : -INFINITY);
+      }
+      my_min = wave_minmax<true>(my_min);
+      my_max = wave_minmax<false>(my_max);
+      if ((tid & 63) == 63)
+      {
+         double *part = s_acc + 4 * NB + 2; // (8 doubles are reserved for the flags, the first two hold them)
+         static_assert(NB != 1 || NT / 64 <= 3, "spare doubles behind the flags");
+         part[2 * (tid >> 6)] = my_min;
+         part[2 * (tid >> 6) + 1] = my_max;
+      }
+   }
    else if (!FUSED && !LO4 && tid < NB)
    {
       const double *uu = RMH_W(tid) + oU;
@@ -2153,7 +2175,19 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             L.m[(size_t)e0 * D3 + t] = mm[r];
          }
       }
-      if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < L.e_end)
+      if (!C::WAVE_ALIGNED && NB == 1)
+      {
+         if (tid == 0 && e0 < L.e_end)
+         {
+            const double *part = s_acc + 4 * NB + 2; // (written in phase B, many barriers ago)
+            double lo = part[0], hi = part[1];
+#pragma unroll
+            for (int w = 1; w < NT / 64; w++) { lo = fmin(lo, part[2 * w]); hi = fmax(hi, part[2 * w + 1]); }
+            L.xe_min[e0] = lo;
+            L.xe_max[e0] = hi;
+         }
+      }
+      else if (!C::WAVE_ALIGNED && tid < NB && e0 + tid < L.e_end)
       {
          L.xe_min[e0 + tid] = my_min;
          L.xe_max[e0 + tid] = my_max;
@@ -2293,6 +2327,46 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             {
                L.xe_min_out[e0 + t / D3] = lo;
                L.xe_max_out[e0 + t / D3] = hi;
+            }
+         }
+      }
+      else if (NB == 1)
+      {
+         // one element per workgroup (p = 4, 5, 6): every thread reduces its own rounds, every wavefront by DPP, the
+         // wavefront results meet in the partial-sum slots -- one barrier and no round trip of the values through LDS
+         // (min / max do not depend on the order)
+         constexpr int NW = NT / 64;
+         double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const bool in = tid + r * NT < D3;
+            lo = fmin(lo, in ? ynew[r] : INFINITY);
+            hi = fmax(hi, in ? ynew[r] : -INFINITY);
+         }
+         lo = wave_minmax<true>(lo);
+         hi = wave_minmax<false>(hi);
+         if (NW == 1)
+         {
+            if (tid == 63 && e0 < L.e_end)
+            {
+               L.xe_min_out[e0] = lo;
+               L.xe_max_out[e0] = hi;
+            }
+         }
+         else
+         {
+            // (the two ring slots the last element sums did NOT use: slower threads may still be reading those)
+            double *slo_ = s_acc + 4 * NB + 8 + C::N2 + ring * NW, *shi_ = s_acc + 4 * NB + 8 + C::N2 + ((ring + 1) % 4) * NW;
+            if ((tid & 63) == 63) { slo_[tid >> 6] = lo; shi_[tid >> 6] = hi; }
+            __syncthreads();
+            if (tid == 0 && e0 < L.e_end)
+            {
+               double l2 = slo_[0], h2 = shi_[0];
+#pragma unroll
+               for (int w = 1; w < NW; w++) { l2 = fmin(l2, slo_[w]); h2 = fmax(h2, shi_[w]); }
+               L.xe_min_out[e0] = l2;
+               L.xe_max_out[e0] = h2;
             }
          }
       }
