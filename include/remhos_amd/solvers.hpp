@@ -82,10 +82,18 @@ class SpaceLayout
    rmh_ctx *ctx;
    int ne, ndof;
    long long global_vsize;
+   bool exchange; // the context has neighbour ranks (rmh_exchange_setup): the solvers exchange what MFEM's would
 
 public:
-   SpaceLayout(rmh_ctx *c, int ne_, int ndof_, long long gvs) : ctx(c), ne(ne_), ndof(ndof_), global_vsize(gvs) {}
+   SpaceLayout(rmh_ctx *c, int ne_, int ndof_, long long gvs, bool has_neighbours = false)
+      : ctx(c), ne(ne_), ndof(ndof_), global_vsize(gvs), exchange(has_neighbours)
+   {
+   }
    rmh_ctx *Ctx() const { return ctx; }
+   // ParGridFunction::ExchangeFaceNbrData (remhos_ho.cpp:122): the neighbours' face layers and element extrema of u
+   void ExchangeFaceNbrData(const double *u) const;
+   // the GroupCommunicator min / max of DofInfo::ComputeOverlapBounds (remhos_tools.cpp:461-466) for given extrema
+   void ExchangeElementExtrema(const double *el_min, const double *el_max) const;
    int GetNE() const { return ne; }
    int GetNDofs() const { return ndof; }
    int GetVSize() const { return ne * ndof; }

@@ -169,6 +169,14 @@ int rmh_comm_attach(rmh_ctx *ctx, void *nccl_comm);
 int rmh_comm_connect_local(rmh_ctx *ctx, int peer_index, rmh_ctx *peer_ctx, int peer_ctx_index);
 int rmh_exchange_begin(rmh_ctx *ctx, const double *u);
 int rmh_exchange_end(rmh_ctx *ctx);
+/* The same neighbours exchange CALLER-GIVEN element extrema (device arrays [ne_owned]): the ghost extrema -- what rmh_bounds
+ * reads beside its arguments -- become the neighbours' values of xe_min / xe_max for the elements of the send lists.  This is
+ * the GroupCommunicator min / max reduction of DofInfo::ComputeOverlapBounds (remhos_tools.cpp:461-466) for a field other
+ * than the u whose extrema travel with rmh_exchange_begin: the masked extrema of s = us / u in product remap
+ * (remhos.cpp:1883-1886; (+inf, -inf) of inactive elements are carried as they are).  RCCL or same-process neighbours; no
+ * exchange of u may be open; with same-process neighbours every context calls begin before any calls end. */
+int rmh_exchange_minmax_begin(rmh_ctx *ctx, const double *xe_min, const double *xe_max);
+int rmh_exchange_minmax_end(rmh_ctx *ctx);
 /* segments of the library-owned buffers (device pointers; counts in doubles) for a caller-side transport */
 int rmh_exchange_buffers(rmh_ctx *ctx, double **send_buf, long long *send_doubles, double **ghost_buf, long long *ghost_doubles);
 int rmh_exchange_peer(rmh_ctx *ctx, int peer_index, int *rank, long long *send_offset, long long *send_doubles,
@@ -223,7 +231,9 @@ int rmh_fct_clipscale(rmh_ctx *ctx, const double *u, const double *m,
  * rmh_fct_product: ClipScaleSolver::CalcFCTProduct (remhos_fct.cpp:543-566) = CalcCompatibleLOProduct (:26-115; s_min /
  *   s_max are updated in place like the reference's) + ScaleProductBounds (:117-153) + ClipScale (:449-541) +
  *   ZeroOutEmptyDofs (remhos_sync.cpp:98-116) in one kernel.  d_us_HO comes from rmh_ho_apply on us.
- * Single-rank only: the ghost extrema of s would need their own exchange. */
+ * All three work element by element; across ranks the bounds of s need the neighbours' masked extrema:
+ * rmh_exchange_minmax_begin / _end on the output of rmh_elem_minmax_masked, then rmh_bounds (what DofInfo::ComputeBounds of
+ * include/remhos_amd/solvers.hpp does). */
 int rmh_product_ratio(rmh_ctx *ctx, const double *us, const double *u, double *s, unsigned char *active_el,
                       unsigned char *active_dofs);
 int rmh_elem_minmax_masked(rmh_ctx *ctx, const double *u, const unsigned char *active_el, const unsigned char *active_dofs,

@@ -21,7 +21,7 @@ SYMBOLS = [
     "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_mass_completion", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
     "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
-    "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce",
+    "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_minmax_begin", "rmh_exchange_minmax_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce",
     "rmh_build_tables", "rmh_product_ratio", "rmh_elem_minmax_masked", "rmh_fct_product",
 ]
 
@@ -123,6 +123,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_comm_connect_local.argtypes = [p, i, p, i]
     lib.rmh_exchange_begin.argtypes = [p, p]
     lib.rmh_exchange_end.argtypes = [p]
+    lib.rmh_exchange_minmax_begin.argtypes = [p, p, p]
+    lib.rmh_exchange_minmax_end.argtypes = [p]
     lib.rmh_exchange_buffers.argtypes = [p, C.POINTER(p), C.POINTER(ll), C.POINTER(p), C.POINTER(ll)]
     lib.rmh_exchange_peer.argtypes = [p, i, C.POINTER(i), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll)]
     lib.rmh_allreduce.argtypes = [p, C.POINTER(d), i, i]
@@ -339,6 +341,11 @@ class Context:
 
     def exchange_end(self):
         self._check(self.lib.rmh_exchange_end(self.h))
+
+    def exchange_minmax(self, xe_min, xe_max):
+        """ghost extrema := the neighbours' values of the given element extrema (RCCL or self / same-process peers)"""
+        self._check(self.lib.rmh_exchange_minmax_begin(self.h, _ptr(xe_min), _ptr(xe_max)))
+        self._check(self.lib.rmh_exchange_minmax_end(self.h))
 
     def exchange_buffers(self):
         """(send_ptr, send_doubles, ghost_ptr, ghost_doubles) of the library-owned buffers"""

@@ -610,7 +610,6 @@ int rmh_fct_product(rmh_ctx *c, const double *us, const double *m, const double 
       return fail(RMH_ERR_INVALID, "null argument");
    }
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
-   if (c->ng > 0) { return fail(RMH_ERR_STATE, "product remap is single-rank (the ghost extrema of s are not exchanged)"); }
    RMH_ENTER(c);
    extrema_dropped(c);
    EventPair ep;

@@ -84,6 +84,8 @@ struct PeerPlan
    long long recv_off = 0, recv_n = 0; // segment of the ghost buffer (doubles)
    rmh_ctx *local = nullptr;           // same-process peer (rmh_comm_connect_local)
    int local_index = -1;               // this context's peer index on the other side
+   int send_first_el = 0, send_count_el = 0; // its records in the send list / its ghost slots (rmh_exchange_minmax_*)
+   int recv_first_el = 0, recv_count_el = 0;
 };
 
 struct Exchange
@@ -105,7 +107,30 @@ struct Exchange
    hipEvent_t ev_done = nullptr;           // ghosts received (exchange stream)
    unsigned long long gen_begin = 0, gen_end = 0;
    double *d_red = nullptr;                // scratch of rmh_allreduce
+   // exchange of caller-given element extrema (rmh_exchange_minmax_*): [nsend][2] out, [ne_ghost][2] in, and where ghost
+   // g's (min, max) pair sits in the ghost buffer (doubles)
+   double *d_send2 = nullptr, *d_recv2 = nullptr;
+   long long *d_ghost_pos = nullptr;
+   int ng = 0;
+   unsigned long long mm_begin = 0, mm_end = 0;
 };
+
+__global__ void minmax_pack_kernel(const double *xe_min, const double *xe_max, const int *send_elem, int n, double *out)
+{
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+   {
+      out[2 * k] = xe_min[send_elem[k]];
+      out[2 * k + 1] = xe_max[send_elem[k]];
+   }
+}
+__global__ void minmax_unpack_kernel(const double *in, const long long *ghost_pos, int ng, double *ghost)
+{
+   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += gridDim.x * blockDim.x)
+   {
+      ghost[ghost_pos[g]] = in[2 * g];
+      ghost[ghost_pos[g] + 1] = in[2 * g + 1];
+   }
+}
 
 // one workgroup per send record
 template <int P>
@@ -167,6 +192,9 @@ void exchange_free(rmh_ctx *c)
    (void)hipFree(x->d_send);
    (void)hipFree(x->d_ghost);
    (void)hipFree(x->d_red);
+   (void)hipFree(x->d_send2);
+   (void)hipFree(x->d_recv2);
+   (void)hipFree(x->d_ghost_pos);
    if (x->ev_packed) { (void)hipEventDestroy(x->ev_packed); }
    if (x->ev_done) { (void)hipEventDestroy(x->ev_done); }
    if (x->xs) { (void)hipStreamDestroy(x->xs); }
@@ -351,7 +379,23 @@ static int exchange_setup_impl(rmh_ctx *c, const rmh_exchange_desc *d, int compa
       x->send_doubles = off;
       x->ghost_doubles = (long long)ng * full_rec;
    }
-   for (int k = 0; k < d->n_peers; k++) { x->peers[k].rank = d->peer_rank[k]; }
+   {
+      int first = 0;
+      for (int k = 0; k < d->n_peers; k++)
+      {
+         x->peers[k].rank = d->peer_rank[k];
+         x->peers[k].send_first_el = first;
+         x->peers[k].send_count_el = d->send_count[k];
+         x->peers[k].recv_first_el = d->recv_first[k];
+         x->peers[k].recv_count_el = d->recv_count[k];
+         first += d->send_count[k];
+      }
+   }
+   // where the (min, max) pair of ghost g lives: cells 2 c, 2 c + 1 of its compact record, or behind the values of its
+   // whole-element record
+   x->ng = ng;
+   std::vector<long long> ghost_pos(ng);
+   for (int g = 0; g < ng; g++) { ghost_pos[g] = x->compact ? 2 * ghost_cell[g] : (long long)g * full_rec + nd; }
    // ---- device side --------------------------------------------------------------------------------------------
    if (nsend > 0)
    {
@@ -365,6 +409,10 @@ static int exchange_setup_impl(rmh_ctx *c, const rmh_exchange_desc *d, int compa
          RMH_HIP(hipMemcpy(x->d_send_off, send_off.data(), nsend * sizeof(long long), hipMemcpyHostToDevice));
       }
    }
+   RMH_HIP(hipMalloc((void **)&x->d_send2, std::max<long long>(1, 2 * nsend) * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&x->d_recv2, std::max<long long>(1, 2 * (long long)ng) * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&x->d_ghost_pos, std::max<long long>(1, (long long)ng) * sizeof(long long)));
+   if (ng > 0) { RMH_HIP(hipMemcpy(x->d_ghost_pos, ghost_pos.data(), ng * sizeof(long long), hipMemcpyHostToDevice)); }
    RMH_HIP(hipMalloc((void **)&x->d_send, std::max<long long>(1, x->send_doubles) * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&x->d_ghost, std::max<long long>(1, x->ghost_doubles) * sizeof(double)));
    RMH_HIP(hipMemset(x->d_ghost, 0, std::max<long long>(1, x->ghost_doubles) * sizeof(double)));
@@ -558,6 +606,93 @@ int rmh_exchange_end(rmh_ctx *c)
       RMH_HIP(hipStreamWaitEvent(c->stream, x->ev_done, 0));
    }
    x->gen_end++;
+   return RMH_OK;
+}
+
+int rmh_exchange_minmax_begin(rmh_ctx *c, const double *xe_min, const double *xe_max)
+{
+   if (!c || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   Exchange *x = c->xch;
+   if (!x) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax_begin: no exchange plan"); }
+   if (x->gen_begin != x->gen_end) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax_begin: an exchange of u is still open"); }
+   if (x->mm_begin != x->mm_end) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax_begin: the previous one was not ended"); }
+   RMH_ENTER(c);
+   x->mm_begin++;
+   if (x->peers.empty()) { return RMH_OK; }
+   for (PeerPlan &p : x->peers)
+   {
+      if (p.local && p.local->xch->mm_end > 0) { RMH_HIP(hipStreamWaitEvent(c->stream, p.local->xch->ev_done, 0)); }
+   }
+   if (x->nsend > 0)
+   {
+      hipLaunchKernelGGL(minmax_pack_kernel, dim3(std::max(1, std::min(1024, (x->nsend + 255) / 256))), dim3(256), 0, c->stream, xe_min,
+                         xe_max, (const int *)x->d_send_elem, x->nsend, x->d_send2);
+      RMH_HIP(hipGetLastError());
+   }
+   RMH_HIP(hipEventRecord(x->ev_packed, c->stream));
+   if (x->comm)
+   {
+      RMH_HIP(hipStreamWaitEvent(x->xs, x->ev_packed, 0));
+      int rc = rccl().GroupStart();
+      const char *what = "ncclGroupStart";
+      if (rc == 0)
+      {
+         for (PeerPlan &p : x->peers)
+         {
+            if (p.local) { continue; }
+            if (rc == 0 && p.send_count_el > 0) { rc = rccl().Send(x->d_send2 + 2 * (size_t)p.send_first_el, 2 * (size_t)p.send_count_el, Rccl::kDouble, p.rank, x->comm, x->xs); what = "ncclSend"; }
+            if (rc == 0 && p.recv_count_el > 0) { rc = rccl().Recv(x->d_recv2 + 2 * (size_t)p.recv_first_el, 2 * (size_t)p.recv_count_el, Rccl::kDouble, p.rank, x->comm, x->xs); what = "ncclRecv"; }
+         }
+         const int rc_end = rccl().GroupEnd();
+         if (rc == 0 && rc_end != 0) { rc = rc_end; what = "ncclGroupEnd"; }
+      }
+      if (rc != 0)
+      {
+         x->mm_begin--;
+         return fail(RMH_ERR_HIP, std::string(what) + ": " + rccl().GetErrorString(rc));
+      }
+   }
+   return RMH_OK;
+}
+
+int rmh_exchange_minmax_end(rmh_ctx *c)
+{
+   if (!c) { return fail(RMH_ERR_INVALID, "null argument"); }
+   Exchange *x = c->xch;
+   if (!x) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax_end: no exchange plan"); }
+   if (x->mm_begin != x->mm_end + 1) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax_end without rmh_exchange_minmax_begin"); }
+   RMH_ENTER(c);
+   if (x->peers.empty()) { x->mm_end++; return RMH_OK; }
+   bool any_local = false, any_remote = false;
+   for (PeerPlan &p : x->peers)
+   {
+      if (!p.local) { any_remote = true; continue; }
+      Exchange *o = p.local->xch;
+      if (o->mm_begin != x->mm_begin)
+      {
+         return fail(RMH_ERR_STATE, "rmh_exchange_minmax_end: a same-process neighbour has not begun this exchange");
+      }
+      const PeerPlan &q = o->peers[p.local_index];
+      if (q.send_count_el != p.recv_count_el) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax_end: the two sides' lists differ"); }
+      if (!any_local) { RMH_HIP(hipStreamWaitEvent(x->xs, x->ev_packed, 0)); }
+      any_local = true;
+      RMH_HIP(hipStreamWaitEvent(x->xs, o->ev_packed, 0));
+      if (p.recv_count_el > 0)
+      {
+         RMH_HIP(hipMemcpyAsync(x->d_recv2 + 2 * (size_t)p.recv_first_el, o->d_send2 + 2 * (size_t)q.send_first_el,
+                                2 * (size_t)p.recv_count_el * sizeof(double), hipMemcpyDeviceToDevice, x->xs));
+      }
+   }
+   if (any_remote && !x->comm) { return fail(RMH_ERR_STATE, "rmh_exchange_minmax needs RCCL or same-process neighbours (no caller-side transport)"); }
+   if (x->ng > 0)
+   {
+      hipLaunchKernelGGL(minmax_unpack_kernel, dim3(std::max(1, std::min(1024, (x->ng + 255) / 256))), dim3(256), 0, x->xs,
+                         (const double *)x->d_recv2, (const long long *)x->d_ghost_pos, x->ng, x->d_ghost);
+      RMH_HIP(hipGetLastError());
+   }
+   RMH_HIP(hipEventRecord(x->ev_done, x->xs));
+   RMH_HIP(hipStreamWaitEvent(c->stream, x->ev_done, 0));
+   x->mm_end++;
    return RMH_OK;
 }
 

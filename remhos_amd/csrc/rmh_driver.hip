@@ -109,6 +109,19 @@ void TimingData::Update(rmh_ctx *ctx)
 }
 
 // ---- solvers: forward to the C ABI ------------------------------------------------------------
+void SpaceLayout::ExchangeFaceNbrData(const double *u) const
+{
+   if (!exchange) { return; }
+   RMH_CALL(rmh_exchange_begin(ctx, u));
+   RMH_CALL(rmh_exchange_end(ctx));
+}
+void SpaceLayout::ExchangeElementExtrema(const double *el_min, const double *el_max) const
+{
+   if (!exchange) { return; }
+   RMH_CALL(rmh_exchange_minmax_begin(ctx, el_min, el_max));
+   RMH_CALL(rmh_exchange_minmax_end(ctx));
+}
+
 LocalInverseHOSolver::LocalInverseHOSolver(ParFiniteElementSpace &space, bool partial_assembly) : HOSolver(space)
 {
    // remhos_ho.cpp:77-81 (M_inv->SetAbsTol(1e-8), M_inv->SetRelTol(0.0)) / :104-115 (exact element inverse)
@@ -127,6 +140,7 @@ LocalInverseHOSolver::LocalInverseHOSolver(ParFiniteElementSpace &space, bool pa
 void LocalInverseHOSolver::CalcHOSolution(const Vector &u, Vector &du) const
 {
    RMH_VERIFY(timer, "Timer not set."); // remhos_ho.cpp:86
+   pfes.ExchangeFaceNbrData(u.Read());  // remhos_ho.cpp:122 (inside K.Mult for the PA branch)
    RMH_CALL(rmh_ho_apply(pfes.Ctx(), u.Read(), du.Write()));
 }
 
@@ -137,6 +151,7 @@ void CGHOSolver::CalcHOSolution(const Vector &u, Vector &du) const
    int maxit;
    RMH_CALL(rmh_get_mass_tol(pfes.Ctx(), &rel, &abs, &maxit));
    RMH_CALL(rmh_set_mass_tol(pfes.Ctx(), 1e-12, 0.0, 500)); // remhos_ho.cpp:60-63
+   pfes.ExchangeFaceNbrData(u.Read());
    RMH_CALL(rmh_ho_apply(pfes.Ctx(), u.Read(), du.Write()));
    RMH_CALL(rmh_set_mass_tol(pfes.Ctx(), rel, abs, maxit));
 }
@@ -215,6 +230,7 @@ void DofInfo::ComputeElementsMinMax(const Vector &u, Vector &u_min, Vector &u_ma
 }
 void DofInfo::ComputeBounds(const Vector &el_min, const Vector &el_max, Vector &dof_min, Vector &dof_max) const
 {
+   pfes.ExchangeElementExtrema(el_min.Read(), el_max.Read()); // remhos_tools.cpp:461-466
    RMH_CALL(rmh_bounds(pfes.Ctx(), el_min.Read(), el_max.Read(), dof_min.Write(), dof_max.Write()));
 }
 
@@ -500,7 +516,7 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
    L.mesh_order = 2;
    L.exec_mode = cd.exec_mode;
    L.ne_owned = cd.ne_owned;
-   L.ne_ghost = 0;
+   L.ne_ghost = cd.ne_ghost; // (> 0 only for a self-wrapped block: rmhd_config.self_wrap)
    L.x0 = cd.x0.data();
    L.vel = cd.vel.data();
    L.face_nbr = cd.face_nbr.data();
@@ -510,6 +526,34 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
    rmh_ctx *ctx = nullptr;
    if (rmh_create(&L, &ctx) != 0) { g_driver_error = rmh_last_error(); return -1; }
    rmh_enable_timers(ctx, 1);
+   if (cd.ne_ghost > 0)
+   {
+      // A self-wrapped block: its only neighbour is this rank itself.  The solver classes then run the exchanges the
+      // reference's would (SpaceLayout::ExchangeFaceNbrData / ExchangeElementExtrema) through the library's plan -- over a
+      // one-rank RCCL communicator, or device copies (RMH_EXCHANGE=local; always under the host emulation).
+      const Peer &pr = cd.peers[0];
+      const int prank = pr.rank, scount = (int)pr.send_elems.size(), rfirst = pr.recv_slots.empty() ? 0 : pr.recv_slots.front(),
+                rcount = (int)pr.recv_slots.size();
+      const int *selems = pr.send_elems.data();
+      rmh_exchange_desc d = {1, &prank, &scount, &selems, &rfirst, &rcount};
+      const char *tr = std::getenv("RMH_EXCHANGE");
+      char id[128];
+      bool ok = cd.peers.size() == 1 && rmh_exchange_setup(ctx, &d, 1) == 0;
+      if (ok && !(tr && std::string(tr) == "local") && rmh_comm_unique_id(id) == 0) { ok = rmh_comm_init(ctx, id, 1, 0) == 0; }
+      else if (ok) { ok = rmh_comm_connect_local(ctx, 0, ctx, 0) == 0; }
+      if (!ok)
+      {
+         g_driver_error = std::string("self-wrapped block: ") + rmh_last_error();
+         rmh_destroy(ctx);
+         return -1;
+      }
+      if (cfg->fused && !cfg->ps && (cfg->ode_solver == 0 || cfg->ode_solver == 3))
+      {
+         g_driver_error = "a self-wrapped block with the one-kernel stage runs through rmhd_run_partitioned";
+         rmh_destroy(ctx);
+         return -1;
+      }
+   }
    if (rmh_set_bounds_type(ctx, cfg->bounds_type) != 0 || (cfg->dt_control && rmh_set_dt_control(ctx, 1) != 0))
    {
       g_driver_error = rmh_last_error();
@@ -521,7 +565,7 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
    const int vsize = cd.ne_owned * cd.ndof;
    int rc = 0;
    {
-      ParFiniteElementSpace pfes(ctx, cd.ne_owned, cd.ndof, (long long)cd.ne_global * cd.ndof);
+      ParFiniteElementSpace pfes(ctx, cd.ne_owned, cd.ndof, (long long)cd.ne_global * cd.ndof, cd.ne_ghost > 0);
       DofInfo dofs(pfes);
       // solver factory of remhos.cpp:912-925, 927-995 for the options on the path
       HOSolver *ho_solver = nullptr;

@@ -76,3 +76,25 @@ def test_ghost_setters_refused_after_exchange_setup(lib):
         with pytest.raises(RmhError):
             call()
     st.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(mesh="periodic-cube", rs=1, order=3, problem=0, dt=0.01, t_final=0.5, max_steps=4, fused=0),
+    dict(mesh="periodic-cube", rs=1, order=3, problem=10, dt=0.02, t_final=0.5, max_steps=3, fused=1, ps=1, ode_solver=13),
+    dict(mesh="periodic-cube", rs=1, order=2, problem=10, dt=0.02, t_final=0.5, max_steps=3, fused=0, ps=1, ode_solver=12, lo_type=5),
+    dict(mesh="periodic-cube", rs=1, order=4, problem=10, dt=0.02, t_final=0.5, max_steps=2, fused=0, lo_type=4),
+], ids=["sequence-transport", "product-idp3-fused", "product-idp2-sequence", "sequence-lo4"])
+def test_rccl_selfloop_solver_classes(lib, kw):
+    """The solver classes over the neighbour exchange (one-rank RCCL communicator): ExchangeFaceNbrData of u and of us in
+    the HO solver (remhos_ho.cpp:122), the min / max reduction of ComputeBounds for u and for the MASKED extrema of
+    s = us / u (rmh_exchange_minmax_*; remhos_tools.cpp:461-466, remhos.cpp:1883-1886) -- product remap across rank
+    boundaries.  Bit-identical to the plain periodic run."""
+    from tests.test_selfloop import driver_fields
+
+    u0, us0, r0 = driver_fields(lib, 0, **kw)
+    for wrap in (1, 3):
+        u1, us1, r1 = driver_fields(lib, wrap, **kw)
+        assert np.array_equal(u0, u1) and np.array_equal(us0, us1)
+        assert r0.max_value == r1.max_value
+        if kw.get("ps"):
+            assert r0.s_max == r1.s_max and abs(r0.final_mass_us - r1.final_mass_us) <= 1e-14 * abs(r0.final_mass_us)

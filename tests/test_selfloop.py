@@ -109,3 +109,37 @@ def test_selfloop_emulated_equals_plain_periodic(emulib, p, wrap, lo, compact):
     u1, tr, _ = selfloop_run(emulib, "cpu", 0, p, wrap, 1, lo=lo, compact=compact)
     assert tr == "local"
     assert np.array_equal(u0, u1)
+
+
+def driver_fields(lib, self_wrap, **kw):
+    """final u (and us) of rmhd_run_state in GLOBAL element order"""
+    import ctypes as C
+
+    from remhos_amd.case import Case, RmhdResult, make_config
+
+    cfg = make_config(self_wrap=self_wrap, **kw)
+    case = Case(lib, cfg)
+    n = case.u0.size
+    u, us = np.zeros(n), np.zeros(n)
+    res = RmhdResult()
+    assert lib.rmhd_run_state(C.byref(cfg), C.byref(res), u.ctypes.data, us.ctypes.data) == 0, lib.rmhd_last_error()
+    order = np.argsort(case.owned_gid)
+    return u.reshape(case.u0.shape)[order], us.reshape(case.u0.shape)[order], res
+
+
+SOLVER_CLASS_RUNS = [
+    # the reference's call sequence (HOSolver / LOSolver / DofInfo / FCTSolver one by one): every exchange the reference's
+    # classes make -- ExchangeFaceNbrData in the HO solver, the min / max reduction in ComputeBounds -- goes through the plan
+    dict(mesh="periodic-cube", rs=0, order=2, problem=0, dt=0.02, t_final=0.5, max_steps=1, fused=0),
+    # product remap with the IDP solver: exchanges of u, of us, and of the masked extrema of s = us / u
+    dict(mesh="periodic-cube", rs=0, order=2, problem=10, dt=0.02, t_final=0.5, max_steps=1, fused=1, ps=1, ode_solver=13),
+]
+
+
+@pytest.mark.parametrize("kw", SOLVER_CLASS_RUNS, ids=["sequence-transport", "product-idp3"])
+def test_selfloop_solver_classes_emulated(emulib, kw, monkeypatch):
+    monkeypatch.setenv("RMH_EXCHANGE", "local")
+    u0, us0, r0 = driver_fields(emulib, 0, **kw)
+    u1, us1, r1 = driver_fields(emulib, 2, **kw)
+    assert np.array_equal(u0, u1) and np.array_equal(us0, us1)
+    assert r0.max_value == r1.max_value and abs(r0.final_mass - r1.final_mass) <= 1e-14 * abs(r0.final_mass)
