@@ -51,6 +51,8 @@ int main(int argc, char **argv)
       else if (a == "-rank") { c.rank = std::atoi(next()); }
       else if (a == "-dev") { device = std::atoi(next()); }
       else if (a == "-comm-file") { comm_file = next(); }
+      else if (a == "-self-wrap") { c.self_wrap = std::atoi(next()); } // validation: 1 + d, see rmh_driver.h
+      else if (a == "-warmup") { c.warmup_steps = std::atoi(next()); }
       else if (a == "-pa") { c.pa = 1; }
       else if (a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { c.ode_solver = std::atoi(next()); }
@@ -66,7 +68,7 @@ int main(int argc, char **argv)
    rmhd_result r;
    // box-partitioned runs: all blocks in this process (no -comm-file), or one block per process over RCCL
    //   for r in 0 1; do remhos_amd_run ... -px 2 -rank $r -dev $r -comm-file /tmp/rmh.id & done
-   const bool partitioned = c.px * c.py * c.pz > 1;
+   const bool partitioned = c.px * c.py * c.pz > 1 || (c.self_wrap && !comm_file.empty());
    if (partitioned ? rmhd_run_partitioned(&c, comm_file.empty() ? nullptr : comm_file.c_str(), device, &r) != 0 : rmhd_run(&c, &r) != 0)
    {
       std::fprintf(stderr, "remhos_amd: %s\n", rmhd_last_error());
