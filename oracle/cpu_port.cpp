@@ -22,6 +22,7 @@
 // re-assembly of K to it, remhos.cpp:1634-1637), INV = mass-solve set-up + PCG (:1620-1623), LO, FCT (incl. bounds).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #ifdef _OPENMP
@@ -607,6 +608,33 @@ void lumped_mass_t(int ne, int exec_mode, const double *x0, const double *vel, d
       default: { constexpr int P = 6; expr; break; } \
    }
 
+// NUMA placement: the caller's arrays (numpy) were touched first by one thread, i.e. they live on one memory node, and the
+// 128 threads of a two-socket host would all read the mesh from there.  cpu_place() copies an input array once into a
+// buffer whose pages are first touched by the threads that will read them (the same static partition of the elements
+// as the stage loops); the copy is reused as long as the caller passes the same pointer and size.
+struct Placed
+{
+   const void *src = nullptr;
+   size_t bytes = 0;
+   void *buf = nullptr;
+};
+template <class T>
+const T *cpu_place(Placed &pl, const T *src, size_t per_elem, int ne)
+{
+   const size_t bytes = sizeof(T) * per_elem * (size_t)ne;
+   if (pl.src == src && pl.bytes == bytes) { return (const T *)pl.buf; }
+   std::free(pl.buf);
+   pl.buf = std::malloc(bytes);
+   pl.src = src;
+   pl.bytes = bytes;
+   T *dst = (T *)pl.buf;
+#pragma omp parallel for schedule(static)
+   for (int e = 0; e < ne; e++) { std::memcpy(dst + per_elem * (size_t)e, src + per_elem * (size_t)e, sizeof(T) * per_elem); }
+   return dst;
+}
+Placed g_px0, g_pvel, g_pnbr, g_pst;
+Placed g_pu;
+
 } // namespace
 
 extern "C" {
@@ -627,9 +655,16 @@ int cpu_stage(int p, int ne, int exec_mode, const double *x0, const double *vel,
 
 // RK3-SSP step in place on u (size ne*ndof); work arrays are allocated by the caller (4 * ne*ndof + 2*ne).
 int cpu_rk3_step(int p, int ne, int exec_mode, const double *x0, const double *vel, const int *face_nbr,
-                 const int *stencil27, double t, double dt, double *u, double *work, double rel_tol, double abs_tol, int completion)
+                 const int *stencil27, double t, double dt, double *u_caller, double *work, double rel_tol, double abs_tol, int completion)
 {
    const size_t n = (size_t)ne * (p + 1) * (p + 1) * (p + 1);
+   x0 = cpu_place(g_px0, x0, 81, ne);
+   vel = cpu_place(g_pvel, vel, 81, ne);
+   face_nbr = cpu_place(g_pnbr, face_nbr, 6, ne);
+   stencil27 = cpu_place(g_pst, stencil27, 27, ne);
+   // the state: a placed working copy, written back at the end of the step (the caller reads it between steps)
+   g_pu.src = nullptr;
+   double *u = const_cast<double *>(cpu_place(g_pu, (const double *)u_caller, n / ne, ne));
    double *y = work, *k = work + n, *m = work + 2 * n, *dh = work + 3 * n, *xe = work + 4 * n;
    int it = cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, k, m, dh, xe, rel_tol, abs_tol, completion);
 #pragma omp parallel for
@@ -639,7 +674,7 @@ int cpu_rk3_step(int p, int ne, int exec_mode, const double *x0, const double *v
    for (long long i = 0; i < (long long)n; i++) { y[i] = 0.75 * u[i] + 0.25 * (y[i] + dt * k[i]); }
    it = std::max(it, cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t + dt / 2, dt, y, k, m, dh, xe, rel_tol, abs_tol, completion));
 #pragma omp parallel for
-   for (long long i = 0; i < (long long)n; i++) { u[i] = (1.0 / 3.0) * u[i] + (2.0 / 3.0) * (y[i] + dt * k[i]); }
+   for (long long i = 0; i < (long long)n; i++) { u_caller[i] = (1.0 / 3.0) * u[i] + (2.0 / 3.0) * (y[i] + dt * k[i]); }
    return it;
 }
 
