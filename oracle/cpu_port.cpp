@@ -633,7 +633,6 @@ const T *cpu_place(Placed &pl, const T *src, size_t per_elem, int ne)
    return dst;
 }
 Placed g_px0, g_pvel, g_pnbr, g_pst;
-Placed g_pu;
 
 } // namespace
 
@@ -662,9 +661,7 @@ int cpu_rk3_step(int p, int ne, int exec_mode, const double *x0, const double *v
    vel = cpu_place(g_pvel, vel, 81, ne);
    face_nbr = cpu_place(g_pnbr, face_nbr, 6, ne);
    stencil27 = cpu_place(g_pst, stencil27, 27, ne);
-   // the state: a placed working copy, written back at the end of the step (the caller reads it between steps)
-   g_pu.src = nullptr;
-   double *u = const_cast<double *>(cpu_place(g_pu, (const double *)u_caller, n / ne, ne));
+   double *u = u_caller; // (the state stays where the caller has it: a placed copy per step cost more than it gained)
    double *y = work, *k = work + n, *m = work + 2 * n, *dh = work + 3 * n, *xe = work + 4 * n;
    int it = cpu_stage(p, ne, exec_mode, x0, vel, face_nbr, stencil27, t, dt, u, k, m, dh, xe, rel_tol, abs_tol, completion);
 #pragma omp parallel for
