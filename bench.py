@@ -142,7 +142,8 @@ def cpu_baseline(lib, order, rs, mass_solve="pa", budget_s=15.0):
         "unit": "MDOFs*RK-stage/s",
         "cores": cp.threads,
         "kind": "port",
-        "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads, element batches of {cp.simd_width} per SIMD vector, "
+        "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads = the CPUs the container may use (affinity mask capped by the "
+                  f"cgroup quota), element batches of {cp.simd_width} per SIMD vector, "
                   f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}): periodic-cube -rs {rs_cpu} "
                   f"-o {order} -p 10 -lo 5 -fct 2, mass solve {MASS_SOLVE[mass_solve][1]}, {ndofs} dofs, {stages} RK stages in {el:.2f} s",
         "buckets_s": {"rhs": tb[0], "inv": tb[1], "lo": tb[2], "fct": tb[3]},

@@ -7,8 +7,27 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (the GPU boxes show 256
+    logical CPUs but run their containers with cpu.max = 16 CPUs: 128 OpenMP threads there time-share 16 CPUs' worth and
+    are four times SLOWER than 16 threads -- what rounds 1 and 2 reported as the 128-thread baseline)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            quota = float(txt[0]) if txt[0] != "max" else -1.0
+            period = float(txt[1]) if len(txt) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = max(1, min(n, int(quota / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def load():
-    # one thread per core, pinned (reported with the baseline): set before the OpenMP runtime starts
+    # one thread per usable core, pinned (reported with the baseline): set before the OpenMP runtime starts
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
     name = "libcpu_port.so"
