@@ -121,3 +121,42 @@ def test_single_workgroup_and_ragged_tail(env):
         torch.cuda.synchronize()
         assert np.abs(st.x.cpu().numpy() - r.u).max() < 1e-10
         st.close()
+
+
+@pytest.mark.parametrize("mesh,rs,p", [("periodic-cube", 5, 3), ("periodic-cube", 4, 6), ("cube01_hex", 5, 4)])
+def test_full_size_pa_rule_element_mass_rates(env, mesh, rs, p):
+    """The -pa rule of the local mass solve (DGMassInverse's abs 1e-8, remhos_ho.cpp:79-80, + Jacobi step + constant mode) at the
+    sizes of BASELINE configs[1], [2], [4]: the mass rate of EVERY element, sum_i m_i du_HO,i, equals the converged solve's to
+    round-off -- with one or two PCG iterations instead of three -- for the stand-alone HO kernel and inside the one-kernel
+    stage; without the completion the literal rule is off by orders of magnitude (so the check can fail)."""
+    torch, lib = env
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(lib, make_config(mesh, rs, p, 10, -1.0, 0.5))
+    st = Stepper(lib, case, device="cuda:0")
+    st.step(st.dt)
+    c, u, dt, nd = st.ctx, st.x, st.dt, case.ndof
+    c.setup(st.t)
+    m = torch.empty_like(u)
+    c.compute_lumped_mass(st.t, m)
+    rates, iters = {}, {}
+    for name, (rel, ab, jac, fix) in {"converged": (1e-14, 0.0, 0, 0), "pa": (0.0, 1e-8, 1, 1), "literal": (0.0, 1e-8, 0, 0)}.items():
+        c.set_mass_tol(rel, ab, 100)
+        c.set_mass_completion(jac, fix)
+        c.last_cg_iters()
+        du_ho, y, du = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+        c.ho_apply(u, du_ho)
+        c.stage_fused(u, dt, y, du=du)
+        torch.cuda.synchronize()
+        iters[name] = c.last_cg_iters()
+        rates[name] = ((m * du_ho).view(-1, nd).sum(1), (m * du).view(-1, nd).sum(1))
+    scale = float(rates["converged"][0].abs().max())
+    dev = {k: (float((v[0] - rates["converged"][0]).abs().max()) / scale, float((v[1] - rates["converged"][1]).abs().max()) / scale)
+           for k, v in rates.items()}
+    print(mesh, rs, p, "PCG iterations", iters, "element mass-rate deviation (HO kernel, stage)", dev)
+    assert iters["pa"] < iters["converged"]
+    floor = 1e-12 * max(1.0, nd / 64.0)
+    assert dev["pa"][0] <= floor and dev["pa"][1] <= 10 * floor  # (stage: the limiter's own round-off floor, see above)
+    assert dev["literal"][0] > 1e3 * max(dev["pa"][0], 1e-16)
+    st.close()
