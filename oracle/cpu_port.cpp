@@ -693,6 +693,16 @@ void cpu_buckets(double t[4], int reset)
 
 int cpu_simd_width(void) { return VL; } // elements per batch of the HO loop
 
+// (the OpenMP runtime may have been started by another library of the process before OMP_NUM_THREADS could be set)
+void cpu_set_threads(int n)
+{
+#ifdef _OPENMP
+   if (n > 0) { omp_set_num_threads(n); }
+#else
+   (void)n;
+#endif
+}
+
 int cpu_num_threads(void)
 {
 #ifdef _OPENMP

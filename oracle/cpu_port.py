@@ -50,6 +50,10 @@ def load():
     lib.cpu_lumped_mass.restype = None
     lib.cpu_buckets.argtypes = [C.POINTER(d * 4), i]
     lib.cpu_buckets.restype = None
+    lib.cpu_set_threads.argtypes = [i]
+    lib.cpu_set_threads.restype = None
+    # (torch's import has usually started the OpenMP runtime already: the environment above is then too late)
+    lib.cpu_set_threads(int(os.environ.get("OMP_NUM_THREADS", usable_cpus())))
     return lib
 
 
