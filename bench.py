@@ -103,7 +103,7 @@ def stored_counters(key, mass_tol, lo):
     return ent.get("hbm_bytes_per_launch"), ent.get("fp64_wave_insts_per_launch"), ent.get("source", "profiles/")
 
 
-def cpu_baseline(lib, order, rs, mass_solve="pa", budget_s=15.0):
+def cpu_baseline(lib, order, rs, mass_solve="pa", budget_s=12.0):
     """Time the CPU port (oracle/cpu_port.cpp: C++/OpenMP restatement of the reference's CPU partial-assembly stage,
     contractions specialised on the order, the HO loop vectorised across batches of 8 (AVX-512) or 4 (AVX2) elements,
     validated against the reference's known answers) on the host cores, one pinned thread per core, on a bounded sample
@@ -132,7 +132,7 @@ def cpu_baseline(lib, order, rs, mass_solve="pa", budget_s=15.0):
     case, cp, stages, el, warm = run(rs_cpu, 30)
     rate = case.u0.size * stages / el
     if rs_cpu < rs and 8.0 * case.u0.size * 6 / rate < budget_s:  # (8 x the dofs; warm-up step + one timed step = 6 stages)
-        case, cp, stages, el, warm = run(rs_cpu + 1, 6)  # ... and the GPU's own mesh when a warm-up + one step of it fit too
+        case, cp, stages, el, warm = run(rs_cpu + 1, 45)  # ... and the GPU's own mesh when a warm-up + one step of it fit too (then up to the budget)
         rs_cpu += 1
     ndofs = case.u0.size
     tb = cp.buckets()
