@@ -60,7 +60,6 @@ def test_element_mass_rate_is_exact_for_any_rule(lib, p):
         ctx.set_mass_completion(jac, fix)
         du_ho, y, du = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
         ctx.ho_apply(u, du_ho)
-        ctx.invalidate_extrema()
         ctx.stage_fused(u, case.dt, y, du=du)
         torch.cuda.synchronize()
         out[name] = (du_ho.cpu().numpy(), (m * du_ho).sum(dim=1).cpu().numpy(), (m * du).sum(dim=1).cpu().numpy())
