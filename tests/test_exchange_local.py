@@ -125,3 +125,63 @@ def test_partitioned_cpp_driver_equals_single_block(lib):
     assert (many.steps, many.stages, many.global_dofs) == (one.steps, one.stages, one.global_dofs)
     assert many.max_value == one.max_value
     assert abs(many.final_mass - one.final_mass) < 1e-14 and abs(many.mass0 - one.mass0) < 1e-14
+
+
+def minmax_exchange_blocks(lib, device, mesh, rs, p, part, compact):
+    """rmh_exchange_minmax_* between the blocks of a partition held by this process: given element extrema (a function of
+    the global element id, with some (+inf, -inf) pairs like the masked extrema of product remap) travel to the neighbours'
+    ghost slots; rmh_bounds on every block must then equal rmh_bounds on the undivided mesh, element for element."""
+    import torch
+
+    from remhos_amd.capi import Context
+    from remhos_amd.case import Case, make_config
+
+    dev = torch.device(device)
+
+    def extrema(gid):
+        lo = np.sin(0.37 * gid) - 1.5
+        hi = lo + 1.0 + np.cos(0.11 * gid) ** 2
+        empty = gid % 7 == 3  # inactive elements: the identities of the reduction
+        return np.where(empty, np.inf, lo), np.where(empty, -np.inf, hi)
+
+    def mk(c):
+        return Context(lib, order=p, exec_mode=c.exec_mode, x0=c.x0, vel=c.vel, face_nbr=c.face_nbr, stencil27=c.stencil27,
+                       ne_ghost=c.ne_ghost, device=dev.index or 0)
+
+    def to(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    g = Case(lib, make_config(mesh, rs, p, 10, -1.0, 0.5))
+    cg = mk(g)
+    lo, hi = extrema(g.owned_gid.astype(np.float64))
+    umin_g, umax_g = to(np.zeros((g.ne_owned, g.ndof))), to(np.zeros((g.ne_owned, g.ndof)))
+    cg.bounds(to(lo), to(hi), umin_g, umax_g)
+    ref = {int(gid): (umin_g[k].cpu().numpy(), umax_g[k].cpu().numpy()) for k, gid in enumerate(g.owned_gid)}
+    cg.close()
+    n = part[0] * part[1] * part[2]
+    cases = [Case(lib, make_config(mesh, rs, p, 10, -1.0, 0.5, part=part, rank=r)) for r in range(n)]
+    ctxs = [mk(c) for c in cases]
+    for c, ctx in zip(cases, ctxs):
+        ctx.exchange_setup(c.peers, compact=compact)
+    for r, (c, ctx) in enumerate(zip(cases, ctxs)):
+        for k, (rank, _, _) in enumerate(c.peers):
+            if rank > r:
+                kk = [j for j, (r2, _, _) in enumerate(cases[rank].peers) if r2 == r][0]
+                ctx.comm_connect_local(k, ctxs[rank], kk)
+    xs = [tuple(to(a) for a in extrema(c.owned_gid.astype(np.float64))) for c in cases]
+    for ctx, (a, b) in zip(ctxs, xs):
+        ctx._check(ctx.lib.rmh_exchange_minmax_begin(ctx.h, a.data_ptr(), b.data_ptr()))
+    for ctx in ctxs:
+        ctx._check(ctx.lib.rmh_exchange_minmax_end(ctx.h))
+    for c, ctx, (a, b) in zip(cases, ctxs, xs):
+        umin, umax = to(np.zeros((c.ne_owned, c.ndof))), to(np.zeros((c.ne_owned, c.ndof)))
+        ctx.bounds(a, b, umin, umax)
+        umin, umax = umin.cpu().numpy(), umax.cpu().numpy()
+        for k, gid in enumerate(c.owned_gid):
+            assert np.array_equal(umin[k], ref[int(gid)][0]) and np.array_equal(umax[k], ref[int(gid)][1])
+        ctx.close()
+
+
+@pytest.mark.parametrize("mesh,rs,p,part,compact", [("cube01_hex", 1, 1, (2, 2, 1), True), ("periodic-cube", 0, 2, (1, 1, 3), False)])
+def test_minmax_exchange_between_blocks(lib, mesh, rs, p, part, compact):
+    minmax_exchange_blocks(lib, "cpu", mesh, rs, p, part, compact)

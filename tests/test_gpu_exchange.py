@@ -62,3 +62,12 @@ def test_partitioned_cpp_driver_on_gpu(lib):
     assert lib.rmhd_run_partitioned(C.byref(cfgp), None, 0, C.byref(many)) == 0, lib.rmhd_last_error()
     assert one.repeats > 0 and (many.steps, many.repeats, many.dt) == (one.steps, one.repeats, one.dt)
     assert many.max_value == one.max_value and abs(many.final_mass - one.final_mass) < 1e-14
+
+
+@pytest.mark.parametrize("mesh,rs,p,part,compact", [("periodic-cube", 2, 3, (2, 2, 2), True), ("periodic-cube", 1, 4, (1, 2, 1), False),
+                                                    ("cube01_hex", 2, 2, (2, 1, 2), True)])
+def test_minmax_exchange_between_blocks_gpu(lib, mesh, rs, p, part, compact):
+    """rmh_exchange_minmax_* (the masked extrema of product remap across ranks) with all blocks on one GPU"""
+    from tests.test_exchange_local import minmax_exchange_blocks
+
+    minmax_exchange_blocks(lib, "cuda:0", mesh, rs, p, part, compact)
