@@ -7,8 +7,9 @@ from remhos_amd.case import Case, bind_driver, make_config
 from remhos_amd.stepper import Stepper
 lib = bind_driver(load_library())
 # (order, refinement, LO solver): the whole remap, bounds and positivity checked at the end
+pa = 0 if "--exact" in sys.argv else 1  # the -pa rule of the local mass solve (default) or the converged solve
 for order, rs, lo in ((3, 4, 5), (3, 4, 4), (4, 3, 5), (5, 3, 5), (6, 3, 5), (6, 2, 4)):
-    case = Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5, lo_type=lo))
+    case = Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5, lo_type=lo, pa=pa))
     st = Stepper(lib, case, device="cuda:0")
     m0, _ = st.local_mass_and_max(0.0)
     t0 = time.time()
