@@ -515,7 +515,7 @@ class Config:
     fct: int = 2  # 2: clip+scale, 4: element FCT projection (only to pin -bt 1 -dtc 1 with the reference's KATs)
     bounds_type: int = 0  # -bt: 0 overlap of the CG-node patches, 1 face-neighbour elements (remhos_tools.hpp:168-182)
     dt_control: int = 0  # -dtc: 0 fixed step, 1 LOBoundsError (remhos.cpp:1968-1998, 1178-1197)
-    ho_solve: str = "exact"  # 'exact' (remhos_ho.cpp:90-118) or 'cg' (DGMassInverse semantics)
+    ho_solve: str = "exact"  # 'exact' (remhos_ho.cpp:90-118), 'cg' (DGMassInverse semantics), 'pa' ('cg' + the product's completion)
     ps: bool = False  # -ps: product-field remap, evolve (u, us) with s = us / u (remhos.cpp:888-904, 1709-1738, 1848-1915)
     ode: int = 3  # -s: 3 RK3 SSP (remhos.cpp:490); 11 / 12 / 13 forward Euler / RK2 / RK3 IDP solvers (remhos_solvers.cpp)
 
@@ -696,6 +696,8 @@ class Remhos:
             return self.mass_solve_exact(rhs)
         if self.cfg.ho_solve == "bernstein_lu":
             return np.linalg.solve(self.mass_matrices(), rhs[..., None])[..., 0]
+        if self.cfg.ho_solve == "pa":  # DGMassInverse's rule + the product's completion (rmh_set_mass_completion)
+            return self.mass_cg(rhs, completion=True)
         return self.mass_cg(rhs)
 
     def _gl_basis(self):
@@ -739,9 +741,11 @@ class Remhos:
             x = x_l.astype(np.float64)
         return x
 
-    def mass_cg(self, rhs, abs_tol=1e-8, rel_tol=0.0, max_iter=100):
+    def mass_cg(self, rhs, abs_tol=1e-8, rel_tol=0.0, max_iter=100, completion=False):
         """DGMassInverse semantics [MFEM]: Jacobi-PCG per element in the Gauss-Legendre nodal
-        basis, stop when (D^-1 r, r) <= max(rel^2 nom0, abs^2)."""
+        basis, stop when (D^-1 r, r) <= max(rel^2 nom0, abs^2) (remhos_ho.cpp:79-80: abs 1e-8, rel 0).
+        completion: the two steps the product adds behind the loop (rmh_set_mass_completion, no counterpart in the
+        reference): x += D^-1 r, then the constant that makes the element's mass rate sum m x_B equal to 1^T b."""
         T = self.T
         xg, _ = gauss_legendre_01(T.D)
         Bg, _ = bernstein(T.p, xg)  # GL nodal value from Bernstein coeffs: u_gl = Bg u_b
@@ -775,8 +779,13 @@ class Remhos:
             active = active & (nom > tol)
             it += 1
         self.cg_iters = it
+        if completion:
+            x = x + r / diag
         # u_gl = C u_b  =>  u_b = Cinv u_gl; in row-vector form x_b = x_gl @ Cinv.T
-        return x @ Cinv.T
+        xb = x @ Cinv.T
+        if completion:
+            xb = xb + ((b.sum(-1) - (self.m * xb).sum(-1)) / self.m.sum(-1))[:, None]
+        return xb
 
     def calc_lo_massavg(self, u, du_ho, dt):
         """MassBasedAvg::CalcLOSolution (remhos_lo.cpp:247-324)."""

@@ -99,3 +99,38 @@ def test_pa_rule_run_against_converged_run(lib, mesh, rs, p, steps):
     assert it1 < it0
     assert abs(m1[0] - m0[0]) <= 1e-12 * abs(m0[0])
     assert float((x1 - x0).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize("mesh,rs,p,t", [("cube01_hex", 1, 2, 0.4), ("cube01_hex", 2, 3, 0.6), ("periodic-cube", 1, 3, 0.3),
+                                         ("cube01_hex", 1, 4, 0.5), ("periodic-cube", 0, 6, 0.5)])
+def test_pa_rule_is_dgmassinverse_rule(lib, mesh, rs, p, t):
+    """The -pa rule against the oracle's restatement of the SAME algorithm (Remhos.mass_cg: Jacobi-PCG in the GL basis stopped
+    at (D^-1 r, r) <= (1e-8)^2 like DGMassInverse, remhos_ho.cpp:79-80, + the two completion steps): the same number of
+    iterations and the same du_HO -- the kernel's stopping rule is the reference's, not just its converged limit."""
+    import torch
+
+    from oracle.remhos_oracle import Config, Remhos
+    from remhos_amd.capi import Context
+    from tests.helpers import layout_from_oracle, perturbed
+
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=10, dt=0.01, t_final=0.7, lo=5, ho_solve="pa")
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    ctx.set_mass_tol(0.0, 1e-8, 100)
+    ctx.set_mass_completion(True, True)
+    u_h = perturbed(r.u)
+    r.update_geometry(t)
+    ref = r.calc_ho(u_h)
+    u = torch.from_numpy(u_h).to("cuda:0")
+    du = torch.empty_like(u)
+    ctx.setup(t)
+    ctx.last_cg_iters()
+    ctx.ho_apply(u, du)
+    torch.cuda.synchronize()
+    it = ctx.last_cg_iters()
+    err = float(np.abs(du.cpu().numpy() - ref).max() / np.abs(ref).max())
+    print(mesh, rs, p, "iterations GPU / oracle", it, r.cg_iters, "rel err", err)
+    assert it == r.cg_iters and 0 < it < 20
+    assert err < {2: 1e-12, 3: 2e-10, 4: 5e-10, 6: 1e-7}[p]
+    ctx.close()
