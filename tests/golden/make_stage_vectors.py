@@ -28,13 +28,17 @@ CASES = [
     ("remap_p2_lo4_bt1", "cube01_hex", 1, 2, 10, 4, 1, 0.4),
     ("remap_p3_lo3", "periodic-cube", 0, 3, 10, 3, 0, 0.6),
     ("remap_p4_lo5", "cube01_hex", 0, 4, 10, 5, 0, 0.3),
+    # the -pa rule of the local mass solve: DGMassInverse's abs 1e-8 (remhos_ho.cpp:79-80) + the product's completion steps
+    # (oracle: ho_solve = "pa"); the fixture carries mass_solve = "pa" and the oracle's PCG iteration count
+    ("remap_p3_lo5_pa", "cube01_hex", 1, 3, 10, 5, 0, 0.5),
 ]
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     for name, mesh, rs, p, prob, lo, bt, t in CASES:
-        cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=lo, bounds_type=bt)
+        pa = name.endswith("_pa")
+        cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=lo, bounds_type=bt, ho_solve="pa" if pa else "exact")
         r = Remhos(cfg)
         r.refine_steps = 2
         x0, vel, nbr, st = layout_from_oracle(r)
@@ -48,7 +52,8 @@ def main():
         np.savez_compressed(
             os.path.join(here, f"stage_{name}.npz"), order=p, exec_mode=r.exec_mode, lo=lo, bounds_type=bt, t=t, dt=cfg.dt,
             x0=x0, vel=vel, face_nbr=nbr, stencil27=st, subcell_vel=sub, u=u, du_ho=keep["du_ho"], du_lo=keep["du_lo"],
-            umin=keep["umin"], umax=keep["umax"], du=du, m=keep["m"])
+            umin=keep["umin"], umax=keep["umax"], du=du, m=keep["m"], mass_solve="pa" if pa else "exact",
+            cg_iters=getattr(r, "cg_iters", 0) if pa else 0)
         print(name, u.shape, float(np.abs(du).max()))
 
 
