@@ -115,6 +115,12 @@ typedef struct {
  * NULL; us_final only with -ps) -- what -save writes, for parity checks of whole runs. */
 int rmhd_run(const rmhd_config *cfg, rmhd_result *res);
 int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *u_final, double *us_final);
+/* The same loop for ONE BLOCK of a px x py x pz partition, one process per block (mpirun -np N ./remhos in the reference): the
+ * solver classes exchange through the library's plan over RCCL (unique id through comm_id_file like rmhd_run_partitioned),
+ * the report is reduced over the ranks (rmh_allreduce).  Everything rmhd_run takes, incl. -ps with the IDP solvers and the
+ * granular solver sequence; the one-kernel stage of a partitioned run is rmhd_run_partitioned's.  comm_id_file = NULL:
+ * rmhd_run_state.  The fields handed back are this rank's elements. */
+int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, int device, rmhd_result *res, double *u_final, double *us_final);
 
 /* The same run on a px x py x pz box partition (ParMesh(comm, mesh, partitioning), remhos.cpp:459-463), one fused
  * kernel per RK stage and block, one neighbour exchange per stage inside the library (rmh_exchange_begin / _end):

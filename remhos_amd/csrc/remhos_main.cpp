@@ -69,7 +69,14 @@ int main(int argc, char **argv)
    // box-partitioned runs: all blocks in this process (no -comm-file), or one block per process over RCCL
    //   for r in 0 1; do remhos_amd_run ... -px 2 -rank $r -dev $r -comm-file /tmp/rmh.id & done
    const bool partitioned = c.px * c.py * c.pz > 1 || (c.self_wrap && !comm_file.empty());
-   if (partitioned ? rmhd_run_partitioned(&c, comm_file.empty() ? nullptr : comm_file.c_str(), device, &r) != 0 : rmhd_run(&c, &r) != 0)
+   // the one-kernel stage of a partitioned run: rmhd_run_partitioned; the solver classes (-ps, -s 11|12|13, -unfused) of one
+   // block per process: rmhd_run_rank
+   const bool classes = c.ps || c.ode_solver > 10 || !c.fused;
+   int rc;
+   if (partitioned && classes && !comm_file.empty()) { rc = rmhd_run_rank(&c, comm_file.c_str(), device, &r, nullptr, nullptr); }
+   else if (partitioned) { rc = rmhd_run_partitioned(&c, comm_file.empty() ? nullptr : comm_file.c_str(), device, &r); }
+   else { rc = rmhd_run(&c, &r); }
+   if (rc != 0)
    {
       std::fprintf(stderr, "remhos_amd: %s\n", rmhd_last_error());
       return 2;

@@ -494,16 +494,30 @@ void RK3SSPSolver::Step(Vector &x, real_t &t, real_t &dt)
 
 using namespace remhos;
 
-extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res) { return rmhd_run_state(cfg, res, nullptr, nullptr); }
+namespace
+{
+bool read_or_write_id(const char *path, bool writer, char id[128]); // (below, with rmhd_run_partitioned)
+}
+
+extern "C" int rmhd_run(const rmhd_config *cfg, rmhd_result *res) { return rmhd_run_rank(cfg, nullptr, 0, res, nullptr, nullptr); }
 
 extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *u_final, double *us_final)
+{
+   return rmhd_run_rank(cfg, nullptr, 0, res, u_final, us_final);
+}
+
+extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, int device, rmhd_result *res, double *u_final,
+                             double *us_final)
 {
    if (!cfg || !res) { g_driver_error = "null argument"; return -1; }
    std::memset(res, 0, sizeof(*res));
    CaseConfig cc = to_config(*cfg);
-   if (cc.px * cc.py * cc.pz != 1)
+   const int nranks = cc.px * cc.py * cc.pz;
+   const bool rccl_ranks = comm_id_file && comm_id_file[0];
+   if (nranks != 1 && !rccl_ranks)
    {
-      g_driver_error = "rmhd_run drives one block; box-partitioned runs go through rmhd_run_partitioned";
+      g_driver_error = "rmhd_run drives one block; box-partitioned runs go through rmhd_run_partitioned, or through "
+                       "rmhd_run_rank with one process per block";
       return -1;
    }
    CaseData cd;
@@ -522,34 +536,67 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
    L.face_nbr = cd.face_nbr.data();
    L.stencil27 = cd.stencil27.data();
    L.subcell_vel = cd.subcell_vel.empty() ? nullptr : cd.subcell_vel.data();
-   L.device = 0;
+   L.device = device;
    rmh_ctx *ctx = nullptr;
    if (rmh_create(&L, &ctx) != 0) { g_driver_error = rmh_last_error(); return -1; }
    rmh_enable_timers(ctx, 1);
+   bool reduce_over_ranks = false;
    if (cd.ne_ghost > 0)
    {
-      // A self-wrapped block: its only neighbour is this rank itself.  The solver classes then run the exchanges the
-      // reference's would (SpaceLayout::ExchangeFaceNbrData / ExchangeElementExtrema) through the library's plan -- over a
-      // one-rank RCCL communicator, or device copies (RMH_EXCHANGE=local; always under the host emulation).
-      const Peer &pr = cd.peers[0];
-      const int prank = pr.rank, scount = (int)pr.send_elems.size(), rfirst = pr.recv_slots.empty() ? 0 : pr.recv_slots.front(),
-                rcount = (int)pr.recv_slots.size();
-      const int *selems = pr.send_elems.data();
-      rmh_exchange_desc d = {1, &prank, &scount, &selems, &rfirst, &rcount};
+      // The block has neighbours: the other blocks of the partition, one process each, over RCCL (comm_id_file) -- or,
+      // for a self-wrapped block, this rank itself.  The solver classes then run the exchanges the reference's would
+      // (SpaceLayout::ExchangeFaceNbrData / ExchangeElementExtrema) through the library's plan; a self-wrapped block
+      // without an id file uses a one-rank RCCL communicator, or device copies (RMH_EXCHANGE=local; always under the
+      // host emulation).
+      const int np = (int)cd.peers.size();
+      std::vector<int> prank(np), scount(np), rfirst(np), rcount(np);
+      std::vector<const int *> selems(np);
+      for (int j = 0; j < np; j++)
+      {
+         const Peer &pr = cd.peers[j];
+         prank[j] = pr.rank;
+         scount[j] = (int)pr.send_elems.size();
+         selems[j] = pr.send_elems.data();
+         rfirst[j] = pr.recv_slots.empty() ? 0 : pr.recv_slots.front();
+         rcount[j] = (int)pr.recv_slots.size();
+      }
+      rmh_exchange_desc d = {np, prank.data(), scount.data(), selems.data(), rfirst.data(), rcount.data()};
+      bool thin = false;
+      const int P3[3] = {cc.px, cc.py, cc.pz};
+      for (int dd = 0; dd < 3; dd++) { thin = thin || (P3[dd] > 1 && cd.n[dd] / P3[dd] < 2); }
       const char *tr = std::getenv("RMH_EXCHANGE");
       char id[128];
-      bool ok = cd.peers.size() == 1 && rmh_exchange_setup(ctx, &d, 1) == 0;
-      if (ok && !(tr && std::string(tr) == "local") && rmh_comm_unique_id(id) == 0) { ok = rmh_comm_init(ctx, id, 1, 0) == 0; }
-      else if (ok) { ok = rmh_comm_connect_local(ctx, 0, ctx, 0) == 0; }
+      bool ok = rmh_exchange_setup(ctx, &d, thin ? 0 : 1) == 0;
+      if (ok && rccl_ranks)
+      {
+         if (cc.rank == 0) { std::remove(comm_id_file); ok = rmh_comm_unique_id(id) == 0; }
+         std::string why;
+         if (ok && !read_or_write_id(comm_id_file, cc.rank == 0, id)) { ok = false; why = "cannot exchange the RCCL unique id through the file"; }
+         if (!why.empty()) { g_driver_error = "neighbour exchange: " + why; rmh_destroy(ctx); return -1; }
+         ok = ok && rmh_comm_init(ctx, id, nranks, cc.rank) == 0;
+         if (ok && cc.rank == 0) { std::remove(comm_id_file); }
+         reduce_over_ranks = ok;
+      }
+      else if (ok && np == 1 && prank[0] == cc.rank && !(tr && std::string(tr) == "local") && rmh_comm_unique_id(id) == 0)
+      {
+         ok = rmh_comm_init(ctx, id, 1, 0) == 0;
+      }
+      else if (ok && np == 1 && prank[0] == cc.rank) { ok = rmh_comm_connect_local(ctx, 0, ctx, 0) == 0; }
+      else if (ok)
+      {
+         g_driver_error = "neighbour exchange: a block with neighbour ranks needs the RCCL id file";
+         rmh_destroy(ctx);
+         return -1;
+      }
       if (!ok)
       {
-         g_driver_error = std::string("self-wrapped block: ") + rmh_last_error();
+         g_driver_error = std::string("neighbour exchange: ") + rmh_last_error();
          rmh_destroy(ctx);
          return -1;
       }
       if (cfg->fused && !cfg->ps && (cfg->ode_solver == 0 || cfg->ode_solver == 3))
       {
-         g_driver_error = "a self-wrapped block with the one-kernel stage runs through rmhd_run_partitioned";
+         g_driver_error = "a block with neighbours and the one-kernel stage runs through rmhd_run_partitioned";
          rmh_destroy(ctx);
          return -1;
       }
@@ -626,7 +673,13 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
       // own -- the conservation claims are at the 1e-12 level)
       long double mass0_acc = 0.0L;
       for (int i = 0; i < vsize; i++) { mass0_acc += (long double)h_m[i] * cd.u0[i]; }
-      const double mass0 = (double)mass0_acc;
+      // MPI_Allreduce of the report (remhos.cpp:1074-1081, 1412-1421) over the ranks of a partition: rmh_allreduce
+      auto reduce = [&](double v, int op) -> double
+      {
+         if (reduce_over_ranks) { RMH_CALL(rmh_allreduce(ctx, &v, 1, op)); }
+         return v;
+      };
+      const double mass0 = reduce((double)mass0_acc, 0);
       long double mass0_us_acc = 0.0L;
       for (int i = 0; i < (ps ? vsize : 0); i++) { mass0_us_acc += (long double)h_m[i] * h_us[i]; } // remhos.cpp:1077-1081
 
@@ -731,7 +784,8 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
          mass_acc += (long double)h_m[i] * h_u[i];
          umax = std::fmax(umax, h_u[i]);
       }
-      const double mass = (double)mass_acc;
+      const double mass = reduce((double)mass_acc, 0);
+      umax = reduce(umax, 2);
       if (u_final) { std::copy(h_u.begin(), h_u.end(), u_final); }
       {
          // Compute errors, if the exact solution is known (remhos.cpp:1438-1470)
@@ -739,9 +793,9 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
          if (lp_error_sums(cd, cc.problem, t, h_u.data(), es).empty())
          {
             res->has_errors = 1;
-            res->err_l1 = es[0];
-            res->err_l2 = std::sqrt(es[1]);
-            res->err_linf = es[2];
+            res->err_l1 = reduce(es[0], 0);
+            res->err_l2 = std::sqrt(reduce(es[1], 0));
+            res->err_linf = reduce(es[2], 2);
          }
       }
       if (ps)
@@ -761,10 +815,10 @@ extern "C" int rmhd_run_state(const rmhd_config *cfg, rmhd_result *res, double *
          (void)hipFree(flags);
          double smax = -INFINITY;
          for (int i = 0; i < vsize; i++) { smax = std::fmax(smax, h_s[i]); }
-         res->final_mass_us = (double)acc;
-         res->mass0_us = (double)mass0_us_acc;
+         res->final_mass_us = reduce((double)acc, 0);
+         res->mass0_us = reduce((double)mass0_us_acc, 0);
          res->mass_loss_us = std::fabs(res->mass0_us - res->final_mass_us);
-         res->s_max = smax;
+         res->s_max = reduce(smax, 2);
       }
       adv.Timer().Update(ctx);
       const TimingData &T = adv.Timer();

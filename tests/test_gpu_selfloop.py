@@ -98,3 +98,28 @@ def test_rccl_selfloop_solver_classes(lib, kw):
         assert r0.max_value == r1.max_value
         if kw.get("ps"):
             assert r0.s_max == r1.s_max and abs(r0.final_mass_us - r1.final_mass_us) <= 1e-14 * abs(r0.final_mass_us)
+
+
+def test_rccl_selfloop_rank_driver_product_remap(lib, tmp_path):
+    """rmhd_run_rank: the solver-class loop of ONE BLOCK per process over RCCL (what `mpirun -np N ./remhos -ps -s 13` is in
+    the reference), here the one-rank partition of a self-wrapped block: unique id through the file, exchanges of u, us and
+    the masked extrema of s inside the classes, the report reduced with rmh_allreduce -- equal to the plain periodic run."""
+    from remhos_amd.case import Case, RmhdResult, make_config
+
+    kw = dict(mesh="periodic-cube", rs=1, order=3, problem=10, dt=0.02, t_final=0.5, max_steps=3, fused=1, ps=1, ode_solver=13, pa=1)
+    plain, rank = RmhdResult(), RmhdResult()
+    cfg0 = make_config(**kw)
+    n = Case(lib, cfg0).u0.size
+    u0, us0, u1, us1 = (np.zeros(n) for _ in range(4))
+    assert lib.rmhd_run_state(C.byref(cfg0), C.byref(plain), u0.ctypes.data, us0.ctypes.data) == 0, lib.rmhd_last_error()
+    cfg1 = make_config(self_wrap=2, **kw)
+    case1 = Case(lib, cfg1)
+    idfile = str(tmp_path / "rank.id").encode()
+    assert lib.rmhd_run_rank(C.byref(cfg1), idfile, 0, C.byref(rank), u1.ctypes.data, us1.ctypes.data) == 0, lib.rmhd_last_error()
+    assert not (tmp_path / "rank.id").exists()
+    order = np.argsort(case1.owned_gid)
+    nd = case1.ndof
+    assert np.array_equal(u0.reshape(-1, nd), u1.reshape(-1, nd)[order]) and np.array_equal(us0.reshape(-1, nd), us1.reshape(-1, nd)[order])
+    assert rank.max_value == plain.max_value and rank.s_max == plain.s_max
+    assert abs(rank.final_mass - plain.final_mass) < 1e-14 and abs(rank.final_mass_us - plain.final_mass_us) < 1e-14
+    assert abs(rank.mass0_us - plain.mass0_us) < 1e-14
