@@ -40,7 +40,11 @@ namespace hipemu
 inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 inline std::barrier<> *g_barrier = nullptr;
 inline std::barrier<> *g_wave_barrier[16] = {nullptr}; // one per wavefront: cross-lane operations only meet their own 64 lanes
-inline unsigned long long g_xchg[1024], g_xchg2[1024];
+// cross-lane exchange slots, double-buffered: a lane's call k writes buffer k & 1, meets its wavefront ONCE and reads.  The
+// next write to the same buffer is call k + 2, behind the barrier of call k + 1, which no lane passes before every lane
+// has finished the reads of call k -- so one barrier per call is enough (all lanes of a wavefront make the same calls).
+inline unsigned long long g_xchg_buf[2][1024], g_xchg2_buf[2][1024];
+inline thread_local unsigned t_xchg_call = 0;
 } // namespace hipemu
 
 #define threadIdx (hipemu::t_threadIdx)
@@ -51,14 +55,20 @@ inline unsigned long long g_xchg[1024], g_xchg2[1024];
 inline void __syncthreads() { hipemu::g_barrier->arrive_and_wait(); }
 inline void hipemu_wave_sync() { hipemu::g_wave_barrier[hipemu::t_threadIdx.x >> 6]->arrive_and_wait(); }
 
+#define HIPEMU_XCHG_SLOTS                                              \
+   const unsigned xpar_ = hipemu::t_xchg_call++ & 1u;                  \
+   unsigned long long *const xa = hipemu::g_xchg_buf[xpar_];           \
+   unsigned long long *const xb = hipemu::g_xchg2_buf[xpar_];          \
+   (void)xb
+
 inline double __shfl_xor(double v, int off)
 {
    const unsigned t = threadIdx.x;
-   std::memcpy(&hipemu::g_xchg[t], &v, 8);
+   HIPEMU_XCHG_SLOTS;
+   std::memcpy(&xa[t], &v, 8);
    hipemu_wave_sync();
    double r;
-   std::memcpy(&r, &hipemu::g_xchg[t ^ (unsigned)off], 8);
-   hipemu_wave_sync();
+   std::memcpy(&r, &xa[t ^ (unsigned)off], 8);
    return r;
 }
 
@@ -76,7 +86,8 @@ inline double __hiloint2double(int hi, int lo)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_mask*/, bool /*bc*/)
 {
    const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane;
-   hipemu::g_xchg[t] = (unsigned)src;
+   HIPEMU_XCHG_SLOTS;
+   xa[t] = (unsigned)src;
    hipemu_wave_sync();
    const unsigned row = lane >> 4, inrow = lane & 15u;
    int srclane = -1;
@@ -86,8 +97,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
    else if (ctrl == 0x142) { srclane = (row >= 1) ? (int)(row * 16 - 1) : -1; }                           // row_bcast:15
    else if (ctrl == 0x143) { srclane = (row >= 2) ? 31 : -1; }                                            // row_bcast:31
    int r = old;
-   if (((row_mask >> row) & 1) && srclane >= 0) { r = (int)hipemu::g_xchg[base + srclane]; }
-   hipemu_wave_sync();
+   if (((row_mask >> row) & 1) && srclane >= 0) { r = (int)xa[base + srclane]; }
    return r;
 }
 
@@ -95,13 +105,13 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 inline void hipemu_permlane32_swap(double &a, double &b)
 {
    const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane;
-   std::memcpy(&hipemu::g_xchg[t], &a, 8);
-   std::memcpy(&hipemu::g_xchg2[t], &b, 8);
+   HIPEMU_XCHG_SLOTS;
+   std::memcpy(&xa[t], &a, 8);
+   std::memcpy(&xb[t], &b, 8);
    hipemu_wave_sync();
    double na = a, nb = b;
-   if (lane >= 32) { std::memcpy(&na, &hipemu::g_xchg2[base + lane - 32], 8); }
-   else { std::memcpy(&nb, &hipemu::g_xchg[base + lane + 32], 8); }
-   hipemu_wave_sync();
+   if (lane >= 32) { std::memcpy(&na, &xb[base + lane - 32], 8); }
+   else { std::memcpy(&nb, &xa[base + lane + 32], 8); }
    a = na;
    b = nb;
 }
@@ -110,13 +120,13 @@ inline void hipemu_permlane32_swap(double &a, double &b)
 inline void hipemu_permlane16_swap(double &a, double &b)
 {
    const unsigned t = threadIdx.x, lane = t & 63u, base = t - lane, row = lane >> 4, in = lane & 15u;
-   std::memcpy(&hipemu::g_xchg[t], &a, 8);
-   std::memcpy(&hipemu::g_xchg2[t], &b, 8);
+   HIPEMU_XCHG_SLOTS;
+   std::memcpy(&xa[t], &a, 8);
+   std::memcpy(&xb[t], &b, 8);
    hipemu_wave_sync();
    double na = a, nb = b;
-   if (row & 1u) { std::memcpy(&na, &hipemu::g_xchg2[base + (row - 1) * 16 + in], 8); } // odd rows of a <- even rows of b
-   else { std::memcpy(&nb, &hipemu::g_xchg[base + (row + 1) * 16 + in], 8); }          // even rows of b <- odd rows of a
-   hipemu_wave_sync();
+   if (row & 1u) { std::memcpy(&na, &xb[base + (row - 1) * 16 + in], 8); } // odd rows of a <- even rows of b
+   else { std::memcpy(&nb, &xa[base + (row + 1) * 16 + in], 8); }          // even rows of b <- odd rows of a
    a = na;
    b = nb;
 }
