@@ -29,6 +29,11 @@ namespace rmh
 // Persistent workgroups with register prefetch of the next batch (see ho_kernel2): built and measured in round 2 --
 // the back edge costs the column phase its last registers (60-170 B/lane of scratch at p = 3, 4) and the kernel ran
 // 20-40 % slower; kept as a compile-time option (the launch side sizes the grid accordingly).
+// lo 4 stage: the RD solver's z = K_vol u needs the Bernstein test basis; its x-direction comes out of the x-leg of phase G
+// as a second accumulator (one conversion leg less) -- not at p = 3, where that accumulator is the register that spills
+#ifndef RMH_RD_XLEG
+#define RMH_RD_XLEG (P >= 4)
+#endif
 #ifndef RMH_PERSIST_LOOP
 #define RMH_PERSIST_LOOP 0
 #endif
@@ -114,15 +119,15 @@ struct K2Cfg : TabLayout<P>
    static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
-   // volume rhs by the 1-D change of test basis Cf in each direction (phi^B_i = sum_k C[k][i] l_k), not by a
-   // fourth tensor through phases C-G.
+   // volume rhs by the 1-D change of test basis Cf along y and z (phi^B_i = sum_k C[k][i] l_k; the x-leg of phase G
+   // tests with both bases), not by a fourth tensor through phases C-G.
    static constexpr int NR = 3;
    // INPLACE_Y: the y-leg writes its D outputs over the first D of the Q inputs of its own line (R2 inside R3)
    static constexpr bool INPLACE_Y = RMH_INPLACE_Y;
    static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * Q2 * D, PF = INPLACE_Y ? NR * Q2 * D : oR2 + NR * Q * D2;
    static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
    // lo 4 (subcell residual distribution) extras: sub-mesh node positions behind the phase A-C data,
-   // subcell data [4][NS] and the lumped face flux per dof behind the face buffer
+   // subcell data [3][NS] and the lumped face flux per dof behind the face buffer
    static constexpr int NS = P * P * P;
    static constexpr int oXs = PA;
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
@@ -134,10 +139,10 @@ struct K2Cfg : TabLayout<P>
    static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, oKeep + 2));
    static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
    static constexpr int oF2 = BOTH ? oXs : oF;        // s rows (Bernstein basis) of the RD solver
-   static constexpr int oSub = oF + RF, oDuf = oSub + 4 * NS;
+   static constexpr int oSub = oF + RF, oDuf = oSub + 3 * NS;
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
-   static constexpr int EL0 = W + RF + (LO4 ? 4 * NS + D3 : 0);
+   static constexpr int EL0 = W + RF + (LO4 ? 3 * NS + D3 : 0);
    static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
    // partial sums of the generic reductions: chunks of 64 dofs (one wavefront each), 8 chunks for small elements
    static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
@@ -955,6 +960,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          gsv[j] = a.move ? a.subvel[g] : 0.0;
       }
    }
+   // ... and the sub-mesh velocities at the subcell midpoints of this thread's subcells (read inside the subcell pass they
+   // were a memory round trip in the open)
+   constexpr int NSR = LO4 ? (NB * C::NS + NT - 1) / NT : 1;
+   double gvm[NSR][3];
+   if (LO4)
+   {
+#pragma unroll
+      for (int j = 0; j < NSR; j++)
+      {
+         const int k = min(tid + j * NT, NB * C::NS - 1);
+         const double *vmid = a.subvmid + (size_t)min(e0 + k / C::NS, a.e_end - 1) * 3 * C::NS + k % C::NS;
+#pragma unroll
+         for (int comp = 0; comp < 3; comp++) { gvm[j][comp] = a.rd_subcell ? vmid[comp * C::NS] : 0.0; }
+      }
+   }
    double gn[NLN];
 #pragma unroll
    for (int j = 0; j < NLN; j++)
@@ -1132,13 +1152,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       const double eps = 1.E-15;
       // subcell fluctuations with the 1-point rule on the trilinear subcells and subcell extrema
       // (SetupSubCellPA3D / ApplySubCellWeights remhos_lo.cpp:1137-1192, 1313-1618; :1733-1757)
-      for (int k = tid; k < NB * NS; k += NT)
+#pragma unroll
+      for (int js = 0; js < NSR; js++)
       {
+         const int k = tid + js * NT;
+         if (k >= NB * NS) { break; }
          const int eb = k / NS, m = k % NS;
          const int mx = m % P, my = (m / P) % P, mz = m / (P * P);
          const int base = mx + D * my + D2 * mz;
          const double *su_ = RMH_W(eb) + oU, *xs = RMH_W(eb) + C::oXs;
-         const int e = min(e0 + eb, a.e_end - 1);
          double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, vm[3] = {0, 0, 0};
          double umax = -INFINITY, umin = INFINITY, usum = 0.0;
 #pragma unroll
@@ -1161,7 +1183,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
          }
 #pragma unroll
-         for (int comp = 0; comp < 3; comp++) { vm[comp] = a.rd_subcell ? a.subvmid[((size_t)e * 3 + comp) * NS + m] : 0.0; }
+         for (int comp = 0; comp < 3; comp++) { vm[comp] = gvm[js][comp]; }
          const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
          const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
          const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
@@ -1183,15 +1205,17 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             fluct += w * su_[i];
          }
          double *fl = RMH_W(eb) + C::oSub;
-         // [fluct | umax | umin | ratio]: fluct^+ = max(0, fluct), fluct^- = min(0, fluct) are re-formed by the
-         // readers; eqs. (58)-(59): the ratio fluct^+- / sumWeightsSubcell^+- is formed once per subcell, and
-         // only the one of the two with a non-zero numerator is kept (the other contributes exactly zero)
+         // [fluct | bound | ratio]: fluct^+ = max(0, fluct), fluct^- = min(0, fluct) are re-formed by the readers;
+         // eqs. (58)-(59): the ratio fluct^+- / sumWeightsSubcell^+- is formed once per subcell, and only the one of
+         // the two with a non-zero numerator is kept (the other contributes exactly zero) together with the bound it
+         // multiplies -- the subcell maximum for fluct > 0, else the minimum.  Both ratios are >= 0: the second is
+         // stored negated, its sign tells the dofs which of their two sums it belongs to.
          fl[0 * NS + m] = fluct;
-         fl[1 * NS + m] = umax;
-         fl[2 * NS + m] = umin;
-         fl[3 * NS + m] = (fluct > 0.) ? fluct / (8 * umax - usum + eps) : fmin(0., fluct) / (8 * umin - usum - eps);
+         fl[1 * NS + m] = (fluct > 0.) ? umax : umin;
+         fl[2 * NS + m] = (fluct > 0.) ? fluct / (8 * umax - usum + eps) : -(fmin(0., fluct) / (8 * umin - usum - eps));
       }
    }
+   RMH_STAMP(24);
 #if RMH_EARLY_PENCILS
    // The neighbour traces are the only loads that depend on another load (the neighbour index): they are not waited
    // for at the first barrier but here, behind the x-pencils of u, which need none of them.
@@ -1202,6 +1226,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
    }
    __syncthreads();
+   RMH_STAMP(25);
 #else
    if (LO4) { __syncthreads(); }
 #endif
@@ -1323,6 +1348,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[C::oF2 + (f * Q + q1) * D + k2] = tq2[k2]; }
       }
    }
+   RMH_STAMP(26);
 #if RMH_EARLY_PENCILS
    // (the column phase reads the nodes and U1, both complete since the barrier above; the face rows' output is read
    // after the next barrier -- only the lumped face fluxes of the RD scheme need it here)
@@ -1614,7 +1640,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int ix = i % D, i2 = i / D;
          const int idx[3] = {ix, i2 % D, i2 / D};
          const double *R2 = RMH_W(eb) + oR2;
-         double a0 = 0, a1 = 0, a2 = 0;
+         constexpr bool XB = BOTH && RMH_RD_XLEG;
+         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
          for (int jx = 0; jx < Q; jx++)
          {
@@ -1624,11 +1651,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             // R2[r][jx][iy + D*iz] -- in place it sits at [r][jx + Q*iy][iz] of R3
             const int o2 = C::INPLACE_Y ? (jx + Q * idx[1]) * D + idx[2] : jx * D2 + i2;
             constexpr int rs2 = C::INPLACE_Y ? Q2 * D : Q * D2;
-            a0 += bgx * R2[0 * rs2 + o2];
+            const double r0x = R2[0 * rs2 + o2];
+            a0 += bgx * r0x;
+            if (XB) { a3 += bx * r0x; } // the RD solver's z, Bernstein-tested along x (y and z follow below)
             a1 += bx * R2[1 * rs2 + o2];
             if (HAS_HO) { a2 += stab[oBg2 + jx * D + ix] * R2[2 * rs2 + o2]; }
          }
-         const double a0vol = a0;
+         const double a0vol = XB ? a3 : a0;
          // faces: the GL nodal basis does not vanish on the faces, every dof sees all six
 #pragma unroll
          for (int c = 0; c < (HAS_HO ? 3 : 0); c++)
@@ -1648,6 +1677,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    }
 
    double dlo[DR]; // du_LO of the RD solver (MODE 2 / 3)
+   RMH_STAMP(27);
 #pragma unroll
    for (int r = 0; r < DR; r++) { dlo[r] = 0.0; }
    if (LO4)
@@ -1660,7 +1690,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       __syncthreads(); // R2 has been consumed: the front of W is free
       if (BOTH)
       {
-         // z (GL-tested) -> z (Bernstein-tested): Cf (x) Cf (x) Cf through the sA / sB slots
+         // z (GL-tested along y and z; the x-leg above tested it with the Bernstein basis) -> z (Bernstein-tested):
+         // Cf along y and along z through the sA / sB slots
 #pragma unroll
          for (int r = 0; r < DR; r++)
          {
@@ -1668,9 +1699,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = zb[r]; }
          }
          __syncthreads();
-         for (int dir = 0; dir < 3; dir++)
+         constexpr int dir0 = RMH_RD_XLEG ? 1 : 0;
+         for (int dir = dir0; dir < 3; dir++)
          {
-            const int oin = (dir & 1) ? oSB : oSA, oout = (dir & 1) ? oSA : oSB;
+            const int oin = ((dir - dir0) & 1) ? oSB : oSA, oout = ((dir - dir0) & 1) ? oSA : oSB;
             const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
 #pragma unroll
             for (int r = 0; r < DR; r++)
@@ -1700,8 +1732,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          t1[r] = fmax(0., zb[r]);
          t2[r] = fmin(0., zb[r]);
       }
+      RMH_STAMP(28);
       batch_dot<C>(tid, t0, xSum, lds, s_acc, ring4);
       batch_dot2<C>(tid, t1, t2, rhoP, rhoN, lds, s_acc, ring4);
+      RMH_STAMP(29);
       // element extrema (el[0..1]) and the sums of the subcell fluctuations (8 partial sums each, el[2..17])
       if (C::WAVE_ALIGNED)
       {
@@ -1723,6 +1757,38 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
          }
       }
+      else if (NB == 1)
+      {
+         // one element per workgroup (p = 4, 5, 6): thread, wavefront (DPP), one slot of four doubles per wavefront --
+         // {min, max, sum of fluct^+, sum of fluct^-}; the readers combine the wavefronts' slots in order (one thread
+         // looping over the D^3 values and eight over the subcells were 10 % of the lo 4 stage at p = 6)
+         double lo = INFINITY, hi = -INFINITY, sp = 0.0, sn = 0.0;
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const bool in = tid + r * NT < D3;
+            lo = fmin(lo, in ? uu4[r] : INFINITY);
+            hi = fmax(hi, in ? uu4[r] : -INFINITY);
+         }
+         const double *fl = RMH_W(0) + C::oSub;
+#pragma unroll
+         for (int r = 0; r < (NS + NT - 1) / NT; r++)
+         {
+            const int m = tid + r * NT;
+            const double f = m < NS ? fl[m] : 0.0;
+            sp += fmax(0., f);
+            sn += fmin(0., f);
+         }
+         lo = wave_minmax<true>(lo);
+         hi = wave_minmax<false>(hi);
+         sp = wave_sum(sp);
+         sn = wave_sum(sn);
+         if ((tid & 63) == 63)
+         {
+            double *el = RMH_W(0) + oM1 + 4 * (tid >> 6);
+            el[0] = lo; el[1] = hi; el[2] = sp; el[3] = sn;
+         }
+      }
       else if (tid < NB)
       {
          const double *uu = RMH_W(tid) + oSA;
@@ -1740,6 +1806,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             a.xe_max[e0 + tid] = hi;
          }
       }
+      if (NB != 1 || C::WAVE_ALIGNED)
       {
          constexpr int CH = 8, CL = (NS + CH - 1) / CH;
          for (int k = tid; k < NB * CH; k += NT)
@@ -1758,6 +1825,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
       }
       __syncthreads();
+      RMH_STAMP(30);
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -1767,30 +1835,56 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int eb = t / D3, i = t % D3;
             const int ix = i % D, iy = (i / D) % D, iz = i / D2;
             const double *el = RMH_W(eb) + oM1, *fl = RMH_W(eb) + C::oSub;
-            const double xe_min = el[0], xe_max = el[1];
+            double xe_min = el[0], xe_max = el[1];
             double sumFluctP = 0.0, sumFluctN = 0.0;
-#pragma unroll
-            for (int c = 0; c < 8; c++)
+            if (NB == 1 && !C::WAVE_ALIGNED)
             {
-               sumFluctP += el[2 + c];
-               sumFluctN += el[10 + c];
+               sumFluctP = el[2];
+               sumFluctN = el[3];
+#pragma unroll
+               for (int w = 1; w < NT / 64; w++)
+               {
+                  xe_min = fmin(xe_min, el[4 * w]);
+                  xe_max = fmax(xe_max, el[4 * w + 1]);
+                  sumFluctP += el[4 * w + 2];
+                  sumFluctN += el[4 * w + 3];
+               }
+               if (!BOTH && t == 0 && e0 < a.e_end)
+               {
+                  a.xe_min[e0] = xe_min;
+                  a.xe_max[e0] = xe_max;
+               }
+            }
+            else
+            {
+#pragma unroll
+               for (int c = 0; c < 8; c++)
+               {
+                  sumFluctP += el[2 + c];
+                  sumFluctN += el[10 + c];
+               }
             }
             const double ui = uu4[r];
             double nwP = 0.0, nwN = 0.0;
+            // the (up to) eight subcells of this dof, without branches: a subcell outside the element is read at a
+            // clamped index with ratio 0; a ratio > 0 belongs to eq. (58) (subcell maximum), one < 0 -- stored negated
+            // -- to eq. (59) (subcell minimum)
+#pragma unroll
             for (int dz = 1; dz >= 0; dz--)
             {
+#pragma unroll
                for (int dy = 1; dy >= 0; dy--)
                {
+#pragma unroll
                   for (int dx = 1; dx >= 0; dx--)
                   {
                      const int mx = ix - dx, my = iy - dy, mz = iz - dz;
-                     if (mx >= 0 && mx < P && my >= 0 && my < P && mz >= 0 && mz < P)
-                     {
-                        const int m = mx + P * (my + P * mz);
-                        const double ratio = fl[3 * NS + m];
-                        if (fl[m] > 0.) { nwP += ratio * (fl[1 * NS + m] - ui); } // eq. (58)
-                        else { nwN += ratio * (fl[2 * NS + m] - ui); }            // eq. (59)
-                     }
+                     const bool in = mx >= 0 && mx < P && my >= 0 && my < P && mz >= 0 && mz < P;
+                     const int m = min(max(mx, 0), P - 1) + P * (min(max(my, 0), P - 1) + P * min(max(mz, 0), P - 1));
+                     const double ratio = in ? fl[2 * NS + m] : 0.0;
+                     const double d = fl[1 * NS + m] - ui;
+                     nwP += fmax(ratio, 0.) * d; // eq. (58)
+                     nwN -= fmin(ratio, 0.) * d; // eq. (59)
                   }
                }
             }
