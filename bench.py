@@ -14,7 +14,8 @@ Taylor-Green mesh motion, erfc bump), p = 3, -pa -ho 3 -lo 5 -fct 2 (the combina
 itself allows on a device, remhos.cpp:391-397), refined to --rs levels (default 5: 884 736 hex,
 56.6 M dofs).  At N = 1 the same JSON line carries a "p6" block: BASELINE.json configs[2]
 (periodic-cube -rs 4 -o 6, 37.9 M dofs), timed after the p = 3 region with the same K and W, a "transport" block (the
-same mesh with -p 0: the periodic behaviour the reference pins) and a "sustained" block (the p = 3 workload
+same mesh with -p 0: the periodic behaviour the reference pins), an "lo4" block (the p = 3 and p = 6 workloads with
+the subcell residual-distribution LO solver, -lo 4, inside the stage kernel) and a "sustained" block (the p = 3 workload
 for >= 200 steps with clock / power samples and the first-step / steady split).
 
 Local mass solve (`--mass-solve`): "pa" (default) = what -pa means in the reference, DGMassInverse stopped at abs 1e-8
@@ -222,7 +223,7 @@ _CASES = {}
 
 
 def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters=True, problem=None, mass_solve=None,
-            steps=None, warmup=None, smi_period=None, per_step=False, keep_state=False):
+            steps=None, warmup=None, smi_period=None, per_step=False, keep_state=False, lo=None):
     """Set up one configuration, time K steps after W warm-up steps, return the result fields.
     smi_period: sample rocm-smi from a host thread every so many seconds during the timed region (None: not at all --
     the headline figure is measured without instrumentation); per_step: HIP events between the steps (first / steady)."""
@@ -232,6 +233,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     from remhos_amd.stepper import Stepper
 
     problem = args.problem if problem is None else problem
+    lo = args.lo if lo is None else lo
     mass_solve = args.mass_solve if mass_solve is None else mass_solve
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -239,9 +241,9 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     weak = args.scaling == "weak" and world > 1
     # weak scaling: one -rs block per rank -- the directions that carry two blocks are refined once more
     extra = tuple(1 if (weak and part[d] == 2) else 0 for d in range(3))
-    cfg = make_config(args.mesh, rs, order, problem, -1.0, 0.5, lo_type=args.lo, part=part, rank=rank, rs_extra=extra)
+    cfg = make_config(args.mesh, rs, order, problem, -1.0, 0.5, lo_type=lo, part=part, rank=rank, rs_extra=extra)
     t0 = time.perf_counter()
-    key = (args.mesh, rs, order, problem, args.lo, part, rank, extra)
+    key = (args.mesh, rs, order, problem, lo, part, rank, extra)
     if key not in _CASES:  # (host-side case set-up, 3-4 s at -rs 5: shared by the blocks of one run)
         _CASES.clear()
         _CASES[key] = Case(lib, cfg)
@@ -319,7 +321,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     if one_kernel:
         # the dominant kernel is the whole stage: SURVEY 8(d) matrix-free per-dof figure
         ho_bytes = int(stage_alg_bytes_per_dof(order) * ne_owned * ndof)
-        kname = f"rmh::ho_kernel2<{order}, {3 if args.lo in (3, 4) else 1}> (whole RK stage)"
+        kname = f"rmh::ho_kernel2<{order}, {3 if lo in (3, 4) else 1}> (whole RK stage)"
     else:
         ho_bytes = ho_alg_bytes_per_element(order) * ne_owned
         kname = f"rmh::ho_kernel2<{order}, 0>"
@@ -327,7 +329,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     traffic, fp64, why = None, None, "not looked up"
     if with_counters:
         key = f"{args.mesh}-rs{rs}-o{order}-n{world}" + ("-stage" if one_kernel else "")
-        traffic, wi, why = stored_counters(key, mass_tol, args.lo)
+        traffic, wi, why = stored_counters(key, mass_tol, lo)
         if wi:
             # the kernel's real bound: FP64 VALU.  Issued lane-flops = wave64 instructions x 64 lanes x (2 for FMA)
             flops = 64.0 * (2.0 * wi["fma"] + wi["mul"] + wi["add"])
@@ -340,10 +342,10 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
         "ms_per_step": 1e3 * elapsed / steps,
         "config": {
             "workload": f"{args.mesh} -rs {rs}{'+' + ''.join(str(k) for k in extra) if any(extra) else ''} -o {order} -p {problem} "
-                        f"{'remap' if problem >= 10 else 'transport'}, -pa -ho 3 -lo {args.lo} -fct 2, RK3-SSP"
-                        + (" (BASELINE configs[1])" if (args.mesh, order, problem, args.lo, rs) == ("periodic-cube", 3, 10, 5, 5) and world == 1 else "")
-                        + (" (BASELINE configs[2])" if (args.mesh, order, problem, args.lo, rs) == ("periodic-cube", 6, 10, 5, 4) and world == 1 else "")
-                        + (" (BASELINE configs[3])" if (args.mesh, order, problem, args.lo) == ("periodic-cube", 3, 10, 5) and world > 1 else "")
+                        f"{'remap' if problem >= 10 else 'transport'}, -pa -ho 3 -lo {lo} -fct 2, RK3-SSP"
+                        + (" (BASELINE configs[1])" if (args.mesh, order, problem, lo, rs) == ("periodic-cube", 3, 10, 5, 5) and world == 1 else "")
+                        + (" (BASELINE configs[2])" if (args.mesh, order, problem, lo, rs) == ("periodic-cube", 6, 10, 5, 4) and world == 1 else "")
+                        + (" (BASELINE configs[3])" if (args.mesh, order, problem, lo) == ("periodic-cube", 3, 10, 5) and world > 1 else "")
                         + f"; {lattice} = {ne_global} hex, {global_dofs} dofs",
             "global_dofs": global_dofs,
             "elements": ne_global,
@@ -621,6 +623,18 @@ def main():
                      "note": "the mesh keeps moving: later stages of the remap need the same work per element; a clock or power limit "
                              "would show as step times rising with the sample's power at the cap and sclk falling"}
 
+    lo4 = None
+    if extras and default_case and args.lo == 5:
+        # the LO solver BASELINE.json's north_star names: subcell residual distribution (-lo 4) in the one-kernel stage
+        lo4 = {}
+        for name, (o4, rs4) in (("p3", (args.order, args.rs)), ("p6", (6, 4))):
+            r4 = measure(args, lib, o4, rs4, world, rank, dev, dist, backend, with_counters=False, lo=4)
+            lo4[name] = {"value": r4["value"], "unit": "MDOFs*RK-stage/s", "ms_per_step": r4["ms_per_step"], "steps": args.steps,
+                         "warmup": args.warmup, "avg_launch_ms": r4["roofline"]["avg_launch_ms"], "kernel": r4["roofline"]["kernel"],
+                         "roofline_hbm_model_frac": r4["roofline"]["frac"], "workload": r4["config"]["workload"],
+                         "final_mass": r4["config"]["final_mass"], "mass_cg_max_iters": r4["config"]["mass_cg_max_iters"]}
+        _CASES.clear()
+
     if rank == 0:
         out = {
             "metric": "MDOFs*RK-stage/s, 3D hex remap",
@@ -650,6 +664,8 @@ def main():
                                 "avg_launch_ms": transport["roofline"]["avg_launch_ms"], "roofline_hbm_model_frac": transport["roofline"]["frac"]}
         if sustained is not None:
             out["sustained"] = sustained
+        if lo4 is not None:
+            out["lo4"] = lo4
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, args.order, args.rs, args.mass_solve)
         print(json.dumps(out), flush=True)
