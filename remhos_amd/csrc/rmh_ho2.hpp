@@ -1212,7 +1212,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          // stored negated, its sign tells the dofs which of their two sums it belongs to.
          fl[0 * NS + m] = fluct;
          fl[1 * NS + m] = (fluct > 0.) ? umax : umin;
-         fl[2 * NS + m] = (fluct > 0.) ? fluct / (8 * umax - usum + eps) : -(fmin(0., fluct) / (8 * umin - usum - eps));
+         // (one division: the numerators are fluct itself in both cases)
+         const double ratio = fdiv(fluct, (fluct > 0.) ? 8 * umax - usum + eps : 8 * umin - usum - eps);
+         fl[2 * NS + m] = (fluct > 0.) ? ratio : -ratio;
       }
    }
    RMH_STAMP(24);

@@ -24,7 +24,9 @@ end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s
 NAMES = {-1: "A loads", 0: "B pencils", 1: "B face rows", 2: "C column", 3: "F y-leg", 4: "G dof x-leg + faces", 5: "I PCG prelude",
          9: "I sA write", 10: "I x-leg", 11: "I column", 12: "I y-back", 13: "I x-back", 8: "I dot 1 + update", 14: "I dot 2", 15: "I tail",
          6: "I exit + completion", 16: "J back-transform", 21: "K mass sums", 22: "K -", 17: "K bounds + clip", 18: "K pos/neg sums",
-         19: "K scale + stores", 20: "K extrema", 7: "end"}
+         19: "K scale + stores", 20: "K extrema", 7: "end",
+         23: "B traces -> LDS (lo 4: after the subcell pass)", 24: "B traces -> LDS", 25: "B face rows", 26: "B lumped face fluxes (lo 4)", 27: "G RD: z conversion",
+         28: "G RD: element sums", 29: "G RD: extrema + chunk sums", 30: "G RD: gather + weights"}
 
 
 def cls(op):
