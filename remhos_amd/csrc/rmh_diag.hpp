@@ -9,11 +9,14 @@
 // written once at the end of the kernel (a global atomic per stamp would be waited for by the next
 // s_waitcnt vmcnt(0) of the workgroup and show up as a phantom wait); one row of 32 counters per workgroup,
 // summed by the host.
+#ifndef RMH_STAMP_TID
+#define RMH_STAMP_TID 0
+#endif
 constexpr int RMH_STAMP_MAXWG = 1 << 18;
 __device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
 #define RMH_STAMP(k)                                                                   \
    do {                                                                                \
-      if (threadIdx.x == 0)                                                            \
+      if (threadIdx.x == RMH_STAMP_TID)                                                \
       {                                                                                \
          const unsigned long long now_ = clock64();                                    \
          s_stamp[k] += now_ - stamp_prev_;                                             \

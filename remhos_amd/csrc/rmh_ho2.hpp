@@ -22,6 +22,7 @@
 // (remhos_ho.cpp:79-80), lumped mass M_HO*1 (remhos.cpp:1632).
 #pragma once
 #include "rmh_kernels.hpp"
+#include <type_traits>
 
 namespace rmh
 {
@@ -31,6 +32,9 @@ namespace rmh
 // 20-40 % slower; kept as a compile-time option (the launch side sizes the grid accordingly).
 // lo 4 stage: the RD solver's z = K_vol u needs the Bernstein test basis; its x-direction comes out of the x-leg of phase G
 // as a second accumulator (one conversion leg less) -- not at p = 3, where that accumulator is the register that spills
+#ifndef RMH_COLSPLIT
+#define RMH_COLSPLIT 1
+#endif
 #ifndef RMH_RD_XLEG
 #define RMH_RD_XLEG (P >= 4)
 #endif
@@ -150,7 +154,10 @@ struct K2Cfg : TabLayout<P>
    static constexpr int PART = (WAVE_ALIGNED && DR <= 2) ? 0 : cmax(8, 2 * DOT_CH) * NB; // (the DPP paths need none)
    // fused stage: the 27 stencil indices of every element ([NB][27] ints), parked in LDS from phase A to the PCG prelude
    static constexpr int STI = (NB * 27 + 1) / 2;
-   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART + STI;
+   // split columns (p = 6, see ho_kernel2 phase C): w detJ of the columns that three lanes share lives in LDS, [column][qz]
+   static constexpr bool CSPL = RMH_COLSPLIT && NT == 128 && NB == 1 && Q2 > 64 && Q % 3 == 0 && 3 * (Q2 - 64) <= 64 && 6 * Q <= 64;
+   static constexpr int WDL = CSPL ? (Q2 - 64) * Q : 0;
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART + STI + WDL;
    // LDS allocation granule: a 54 096-byte kernel ran two workgroups per CU, a 52 560-byte one three (measured:
    // 6.3 k vs 8.6 k MDOFs*stage/s); 2 KiB granules are consistent with that
    static constexpr int LDS_BYTES = (8 * LDS_DOUBLES + 2047) / 2048 * 2048;
@@ -304,6 +311,15 @@ __device__ inline const double *tab_view()
 #ifndef RMH_WAVE_LOCAL
 #define RMH_WAVE_LOCAL 1
 #endif
+// nothing is scheduled across this point (keeps the LDS table reads of the split columns next to their uses: hoisted
+// to the top of a quadrature-point loop they cost ~70 VGPRs)
+__device__ inline void sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 template <bool WAVE_LOCAL>
 __device__ inline void sync_element()
 {
@@ -888,6 +904,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    int *s_flag = (int *)(s_acc + 4 * NB); // [4] "any element still active" flags (ring of 2 used)
    double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
    int *s_sti = (int *)(stab + C::N2 + C::PART); // [NB][27] stencil indices (fused stage)
+   double *s_wdl = stab + C::N2 + C::PART + C::STI; // [Q2 - 64][Q] w detJ of the split columns (p = 6)
 
    const int tid0 = threadIdx.x;
    static_assert(C::N2 <= RMH_TAB_STRIDE, "constant table too small");
@@ -931,6 +948,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #endif
    const int ptid = SPL ? (tid & 63) : tid; // task index of this thread in a split phase
    constexpr int PNT = SPL ? 64 : NT;
+   // (p = 6) column split: 81 quadrature columns on two wavefronts left the second one a full pass over 17 columns.  The
+   // first wavefront keeps columns 0..63; on the second, three lanes share a column -- a third of the qz range each, the
+   // partial z-leg sums added across the three lanes (ds_bpermute) -- and it takes the face rows off the first one's hands.
+   constexpr bool CSPL = SPL && C::CSPL;
+   const int frt = CSPL ? (tid ^ 64) : tid; // face-row index of this thread (round 0)
    const double *gtb = c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
    const double *gt = gtb;
    (void)gt;
@@ -1005,7 +1027,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int jp = 0; jp < NFR; jp++)
       {
-         const int fr = min(tid + jp * NT, NB * 6 * Q - 1);
+         const int fr = min(frt + jp * NT, NB * 6 * Q - 1);
          const double *fg = a.fgeo + (size_t)min(e0 + fr / (6 * Q), a.e_end - 1) * FaceGeo<P>::PER_ELEM + fr % (6 * Q);
 #pragma unroll
          for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[k * 6 * Q]; }
@@ -1238,7 +1260,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
    for (int jp = 0; jp < NFR; jp++)
    {
-      const int fr = tid + jp * NT;
+      const int fr = frt + jp * NT;
       if (fr >= NB * 6 * Q) { break; }
       const int eb = fr / (6 * Q), r = fr % (6 * Q);
       const int f = r / Q, q1 = r % Q;
@@ -1390,8 +1412,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    }
    RMH_STAMP(2);
    // ---- phase C: column threads: geometry, grad u, z-leg of the test contractions -------------------
-   const bool col = tid < NB * Q2;
-   const int ceb = col ? tid / Q2 : 0, cc = tid % Q2;
+   // column role: thread -> quadrature column cc = qx + Q qy; in the split wavefront (CSPL) three lanes share a column, lane
+   // 3 c + zt takes the third zt of its qz range
+   const int sl = tid - 64;
+   const bool zsplit = CSPL && wv == 1;
+   const bool col = CSPL ? (tid < 64 || sl < 3 * (Q2 - 64)) : tid < NB * Q2;
+   const int ceb = (col && !CSPL) ? tid / Q2 : 0;
+   const int cc = CSPL ? (tid < 64 ? tid : min(64 + sl / 3, Q2 - 1)) : tid % Q2;
+   const int zt = zsplit ? sl % 3 : 0;
    const int qx = cc % Q, qy = cc / Q;
    double wd[Q];
    double Bgy[D]; // GL basis row of this thread's qy (mass apply)
@@ -1400,8 +1428,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    for (int iz = 0; iz < D; iz++) { r0[iz] = 0; r1[iz] = 0; r2[iz] = 0; Bgy[iz] = 0; }
 #pragma unroll
    for (int qz = 0; qz < Q; qz++) { wd[qz] = 0; }
-   if (col)
-   {
+   // ZS: the split form -- NQ = Q / 3 quadrature points per lane, table rows of qz = zt NQ + j from the LDS copy (the index
+   // depends on the lane); otherwise the whole column with compile-time rows (scalar operands)
+   auto column_pass = [&](auto zs_) {
+      constexpr bool ZS = decltype(zs_)::value;
+      constexpr int NQ = ZS ? Q / 3 : Q;
+      const int zo1 = ZS ? zt * NQ : 0, zo3 = 3 * zo1, zoD = D * zo1;
+      auto T3 = [&](const double *gt, int o, int qz, int i) { return ZS ? stab[o + qz * 3 + i + zo3] : gt[o + qz * 3 + i]; };
+      auto TD = [&](const double *gt, int o, int qz, int i) { return ZS ? stab[o + qz * D + i + zoD] : gt[o + qz * D + i]; };
+      auto T1 = [&](const double *gt, int o, int qz) { return ZS ? stab[o + qz + zo1] : gt[o + qz]; };
       double Ly[3], dLy[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) { Ly[k] = stab[oL + qy * 3 + k]; dLy[k] = stab[odL + qy * 3 + k]; }
@@ -1409,7 +1444,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int k = 0; k < 3; k++) { Lx[k] = stab[oL + qx * 3 + k]; dLx[k] = stab[odL + qx * 3 + k]; }
       const double wxy = stab[oW + qx] * stab[oW + qy];
-      double Dq[3][Q];
+      double Dq[3][NQ], wl[NQ];
       {
          // pass 1: geometry.  x- and y-contractions of the 27 nodes of X(t) and V for this column
          // (broadcast LDS reads: all columns of an element read the same node)
@@ -1440,8 +1475,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
          }
 #pragma unroll
-         for (int qz = 0; qz < Q; qz++)
+         for (int qz = 0; qz < NQ; qz++)
          {
+            if (ZS) { sched_fence(); }
             const double *gt = RMH_COLTAB_LDS ? (const double *)stab : RMH_TABK();
             double J[3][3], v[3];
 #pragma unroll
@@ -1451,7 +1487,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
                for (int az = 0; az < 3; az++)
                {
-                  const double Lz = gt[oL + qz * 3 + az], dLz = gt[odL + qz * 3 + az];
+                  const double Lz = T3(gt, oL, qz, az), dLz = T3(gt, odL, qz, az);
                   j0 += Lz * A[comp][0][az];
                   j1 += Lz * A[comp][1][az];
                   j2 += dLz * A[comp][2][az];
@@ -1470,13 +1506,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
             const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
             const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
-            const double w3 = wxy * gt[oW + qz];
+            const double w3 = wxy * T1(gt, oW, qz);
             const double aw = a.alpha * w3;
             Dq[0][qz] = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
             Dq[1][qz] = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
             Dq[2][qz] = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
-            wd[qz] = w3 * detJ;
+            wl[qz] = w3 * detJ;
          }
+      }
+      // w detJ is needed again by the mass applies of the PCG: whole columns keep it in registers, split columns in LDS
+      // (in registers, any form of it costs the kernel ~60 VGPRs of spills around the column phase)
+#pragma unroll
+      for (int qz = 0; qz < NQ; qz++)
+      {
+         if (ZS) { if (HAS_HO) { s_wdl[(cc - 64) * Q + zo1 + qz] = wl[qz]; } }
+         else { wd[qz] = wl[qz]; }
       }
       // pass 2: grad u, D.grad u and the z-leg of the three test contractions
       const double *U1 = RMH_W(ceb) + oU1;
@@ -1504,41 +1548,64 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          UB[iz] = b0; UG[iz] = b1; UU[iz] = b2;
       }
 #pragma unroll
-      for (int qz = 0; qz < Q; qz++)
+      for (int qz = 0; qz < NQ; qz++)
       {
+         if (ZS) { sched_fence(); }
          const double *gt = RMH_COLTAB_LDS ? (const double *)stab : RMH_TABK();
          double gx = 0, gy = 0, gz = 0;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
          {
-            const double Bz = gt[oB + qz * D + iz], Gz = gt[oG + qz * D + iz];
+            const double Bz = TD(gt, oB, qz, iz), Gz = TD(gt, oG, qz, iz);
             gx += Bz * UB[iz];
             gy += Bz * UG[iz];
             gz += Gz * UU[iz];
          }
          const double g = Dq[0][qz] * gx + Dq[1][qz] * gy + Dq[2][qz] * gz;
-         const double wdq = wd[qz];
+         const double wdq = wl[qz];
+         if (ZS) { sched_fence(); }
          // test along z: r0: GL nodal basis x (D.grad u); r1: Bernstein x w detJ (lumped mass);
          //               r2: GL basis squared x w detJ (Jacobi diagonal)
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
          {
-            r0[iz] += gt[(HAS_HO ? oBg : oB) + qz * D + iz] * g;
-            r1[iz] += gt[oB + qz * D + iz] * wdq;
-            if (HAS_HO) { r2[iz] += gt[oBg2 + qz * D + iz] * wdq; }
+            r0[iz] += TD(gt, HAS_HO ? oBg : oB, qz, iz) * g;
+            r1[iz] += TD(gt, oB, qz, iz) * wdq;
+            if (HAS_HO) { r2[iz] += TD(gt, oBg2, qz, iz) * wdq; }
          }
+      }
+   };
+   if (col)
+   {
+      if (zsplit) { column_pass(std::integral_constant<bool, CSPL>()); }
+      else { column_pass(std::false_type()); }
+   }
+   RMH_STAMP(31);
+   if (zsplit)
+   {
+      // the three thirds of a column's z-leg sums, added in the order of qz (every lane of the wavefront takes part)
+      const int l1 = (tid + 1) & 63, l2 = (tid + 2) & 63;
+#pragma unroll
+      for (int iz = 0; iz < D; iz++)
+      {
+         r0[iz] = (r0[iz] + __shfl(r0[iz], l1)) + __shfl(r0[iz], l2);
+         r1[iz] = (r1[iz] + __shfl(r1[iz], l1)) + __shfl(r1[iz], l2);
+         if (HAS_HO) { r2[iz] = (r2[iz] + __shfl(r2[iz], l1)) + __shfl(r2[iz], l2); }
       }
    }
    __syncthreads(); // R3 overlays the phase A-C data: every thread is done with nodes, u, traces, U1
    if (col)
    {
       double *R3 = RMH_W(ceb) + oR3;
-#pragma unroll
-      for (int iz = 0; iz < D; iz++)
+      if (zt == 0)
       {
-         R3[(0 * Q2 + cc) * D + iz] = r0[iz];
-         R3[(1 * Q2 + cc) * D + iz] = r1[iz];
-         R3[(2 * Q2 + cc) * D + iz] = r2[iz];
+#pragma unroll
+         for (int iz = 0; iz < D; iz++)
+         {
+            R3[(0 * Q2 + cc) * D + iz] = r0[iz];
+            R3[(1 * Q2 + cc) * D + iz] = r1[iz];
+            R3[(2 * Q2 + cc) * D + iz] = r2[iz];
+         }
       }
       // (read here, not with the other rows of qy: it is first used by the mass apply and would only occupy registers
       // through the column phase)
@@ -2022,8 +2089,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       __syncthreads();
       RMH_STAMP(11);
-      if (col)
+      if (col && zt == 0) // (split columns: the first of the three lanes runs the whole column, w detJ from LDS)
       {
+         double rz[D], wq[Q];
+#pragma unroll
+         for (int iz = 0; iz < D; iz++) { rz[iz] = 0.0; }
+         if (zsplit)
+         {
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { wq[qz] = s_wdl[(cc - 64) * Q + qz]; }
+         }
+         else
+         {
+#pragma unroll
+            for (int qz = 0; qz < Q; qz++) { wq[qz] = wd[qz]; }
+         }
          const double *M1 = RMH_W(ceb) + oM1 + qx * S2;
          double Y[D];
 #pragma unroll
@@ -2034,9 +2114,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             for (int iy = 0; iy < D; iy++) { acc += Bgy[iy] * M1[iy + D * iz]; }
             Y[iz] = acc;
          }
-         double rz[D];
-#pragma unroll
-         for (int iz = 0; iz < D; iz++) { rz[iz] = 0.0; }
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
@@ -2044,7 +2121,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             double acc = 0.0;
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
-            acc *= wd[qz];
+            acc *= wq[qz];
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { rz[iz] += gt[oBg + qz * D + iz] * acc; }
          }

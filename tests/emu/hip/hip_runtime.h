@@ -72,6 +72,18 @@ inline double __shfl_xor(double v, int off)
    return r;
 }
 
+// value of lane `src` of the caller's wavefront (ds_bpermute)
+inline double __shfl(double v, int src)
+{
+   const unsigned t = threadIdx.x, base = t - (t & 63u);
+   HIPEMU_XCHG_SLOTS;
+   std::memcpy(&xa[t], &v, 8);
+   hipemu_wave_sync();
+   double r;
+   std::memcpy(&r, &xa[base + ((unsigned)src & 63u)], 8);
+   return r;
+}
+
 inline int __double2loint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b & 0xffffffffll); }
 inline int __double2hiint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b >> 32); }
 inline double __hiloint2double(int hi, int lo)

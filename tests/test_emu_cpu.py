@@ -58,6 +58,32 @@ def test_kernels_vs_oracle(lib, mesh, rs, p, prob, t):
     ctx.close()
 
 
+def test_split_columns_p6_emulated(lib):
+    """p = 6: two wavefronts per element; the second one runs the face rows and the 17 quadrature columns beyond the first 64
+    with three lanes per column (a third of the qz range each, ds_bpermute sums, w detJ of those columns in LDS).  HO kernel
+    and one-kernel stage against the oracle under the host emulation (GPU twins: tests/test_gpu_parity.py at p = 6)."""
+    from remhos_amd.capi import Context
+
+    p, t = 6, 0.3
+    cfg = Config(mesh="cube01_hex", rs=0, order=p, problem=10, dt=0.01, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    u = perturbed(r.u)
+    keep = {}
+    du_ref = r.stage(u, t, cfg.dt, keep)
+    du_ho, y, du = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+    ctx.setup(t)
+    ctx.ho_apply(u, du_ho)
+    tol = 1e-7  # (p = 6, the same as tests/test_gpu_parity.py: the local mass matrices are badly conditioned)
+    assert _rel(du_ho, keep["du_ho"]) < tol
+    ctx.stage_fused(u, cfg.dt, y, dt_rk=cfg.dt, du=du)
+    assert _rel(du, du_ref) < tol
+    assert _rel(y, u + cfg.dt * du_ref) < tol
+    ctx.close()
+
+
 def test_cpp_driver_and_stepper_vs_oracle(lib):
     """remhos() restated in C++ (rmhd_run: solver classes + RK3) and the Python stepper give the
     oracle's final mass / max after two RK3 steps of a remap."""

@@ -5,7 +5,8 @@ import torch
 from remhos_amd.capi import load_library
 from remhos_amd.case import Case, bind_driver, make_config
 from remhos_amd.stepper import Stepper
-lib = bind_driver(load_library())
+import os
+lib = bind_driver(load_library(os.environ.get("RMH_LIB")))  # (RMH_LIB: a variant built by tools/build_variant.sh)
 # (order, refinement, LO solver): the whole remap, bounds and positivity checked at the end
 pa = 0 if "--exact" in sys.argv else 1  # the -pa rule of the local mass solve (default) or the converged solve
 for order, rs, lo in ((3, 4, 5), (3, 4, 4), (4, 3, 5), (5, 3, 5), (6, 3, 5), (6, 2, 4)):
