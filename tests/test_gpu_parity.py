@@ -187,6 +187,8 @@ def test_lo_rdsubcell_parity(gpu, mesh, rs, p, prob, t):
                                              ("cube01_hex", 1, 2, 10, 0.3), ("periodic-cube", 1, 1, 10, 0.6),
                                              ("periodic-cube", 1, 3, 0, 0.0), ("cube01_hex", 1, 4, 10, 0.3),
                                              ("cube01_hex", 0, 6, 10, 0.3),
+                                             # split columns (p = 6) with all six neighbours present, remap and transport
+                                             ("periodic-cube", 0, 6, 10, 0.4), ("periodic-cube", 0, 6, 0, 0.0),
                                              # one-wavefront workgroups + face speed table on a periodic mesh (p = 5)
                                              ("periodic-cube", 0, 5, 10, 0.4), ("periodic-cube", 0, 5, 0, 0.0)])
 def test_one_kernel_stage(gpu, mesh, rs, p, prob, t):
