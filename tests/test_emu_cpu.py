@@ -84,6 +84,33 @@ def test_split_columns_p6_emulated(lib):
     ctx.close()
 
 
+def test_rd_one_element_workgroups_emulated(lib):
+    """Subcell residual distribution (lo 4) where a workgroup holds ONE element (p = 4: one wavefront): element extrema and
+    the sums of the subcell fluctuations come from thread / DPP reductions, the dofs gather their subcells without branches.
+    RD-only kernel and one-kernel lo 4 stage against the oracle under the host emulation (GPU twins:
+    tests/test_gpu_parity.py::test_lo_rdsubcell_parity, ::test_one_kernel_stage_lo4)."""
+    from remhos_amd.capi import Context
+
+    p, t = 4, 0.3
+    cfg = Config(mesh="cube01_hex", rs=0, order=p, problem=10, dt=0.01, t_final=0.7, lo=4)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st,
+                  subcell_vel=np.ascontiguousarray(r.Vs.transpose(0, 2, 1)))
+    u = perturbed(r.u)
+    keep = {}
+    du_ref = r.stage(u, t, cfg.dt, keep)
+    du_lo, y, du = np.zeros_like(u), np.zeros_like(u), np.zeros_like(u)
+    ctx.setup(t)
+    ctx.lo_rdsubcell(u, du_lo)
+    assert _rel(du_lo, keep["du_lo"]) < 1e-12
+    ctx.set_lo_type(4)
+    ctx.stage_fused(u, cfg.dt, y, dt_rk=cfg.dt, du=du)
+    assert _rel(du, du_ref) < 5e-10  # (tests/test_gpu_parity.py REL[4])
+    ctx.close()
+
+
 def test_cpp_driver_and_stepper_vs_oracle(lib):
     """remhos() restated in C++ (rmhd_run: solver classes + RK3) and the Python stepper give the
     oracle's final mass / max after two RK3 steps of a remap."""
