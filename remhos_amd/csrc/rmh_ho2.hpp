@@ -32,6 +32,13 @@ namespace rmh
 // 20-40 % slower; kept as a compile-time option (the launch side sizes the grid accordingly).
 // lo 4 stage: the RD solver's z = K_vol u needs the Bernstein test basis; its x-direction comes out of the x-leg of phase G
 // as a second accumulator (one conversion leg less) -- not at p = 3, where that accumulator is the register that spills
+// adj(J) v through two cross products in the column phase, and the XCD-aware batch map: small measured gains at p = 3 only
+#ifndef RMH_ADJ_CROSS
+#define RMH_ADJ_CROSS (P == 3)
+#endif
+#ifndef RMH_XCD_MAP
+#define RMH_XCD_MAP (P == 3)
+#endif
 #ifndef RMH_COLSPLIT
 #define RMH_COLSPLIT 1
 #endif
@@ -927,6 +934,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // loop -- a back edge costs them registers in the column phase for nothing)
    int blk = blockIdx.x;
    if (blk >= nblk) { return; }
+   if (RMH_XCD_MAP && !RMH_PERSIST_LOOP && gridDim.x == (unsigned)nblk)
+   {
+      // workgroups are handed to the 8 XCDs round-robin (blockIdx.x % 8): give every XCD -- every L2 -- one contiguous
+      // eighth of the element batches, so that the x- and y-neighbours whose traces and extrema an element reads were
+      // touched by workgroups of the same XCD a few batches earlier (+0.5 % at p = 3, -2 % at p = 6: p = 3 only)
+      const int xcd = blk & 7, j8 = blk >> 3, q8 = nblk >> 3, r8 = nblk & 7;
+      blk = xcd * q8 + min(xcd, r8) + j8;
+   }
+   const int blk0 = blk;
    do
    {
    const int e0 = a.e_begin + blk * NB;
@@ -956,7 +972,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    const double *gtb = c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
    const double *gt = gtb;
    (void)gt;
-   if (blk != (int)blockIdx.x) { __syncthreads(); } // the previous batch's last LDS reads precede this batch's stores
+   if (blk != blk0) { __syncthreads(); } // the previous batch's last LDS reads precede this batch's stores
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
    // all global loads are issued before the first LDS store so that they are in flight together
    // (neighbour indices first: the trace loads depend on them)
@@ -1495,22 +1511,43 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                }
                J[comp][0] = j0; J[comp][1] = j1; J[comp][2] = j2; v[comp] = vv;
             }
-            // adj(J), rows as in remhos_lo.cpp:1168-1180
-            const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-            const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
-            const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
-            const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
-            const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-            const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
-            const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
-            const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
-            const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-            const double detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
             const double w3 = wxy * T1(gt, oW, qz);
             const double aw = a.alpha * w3;
-            Dq[0][qz] = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
-            Dq[1][qz] = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
-            Dq[2][qz] = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
+            double detJ;
+            if (RMH_ADJ_CROSS)
+            {
+               // adj(J) v and det J through two cross products (c_k = dX/dxi_k, the columns of J; the rows of adj(J) are
+               // c1 x c2, c2 x c0, c0 x c1 -- remhos_lo.cpp:1168-1180 -- so (adj(J) v)_0 = v.(c1 x c2) = -c1.(v x c2),
+               // (adj(J) v)_1 = c0.(v x c2), (adj(J) v)_2 = v.(c0 x c1), det J = c2.(c0 x c1)): 24 instead of 30 operations
+               // per quadrature point; p = 3 only (+1.0 %; at p = 6 the different register lifetimes cost 8 %)
+               const double n0 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+               const double n1 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+               const double n2 = J[0][0] * J[1][1] - J[1][0] * J[0][1];
+               const double c0 = v[1] * J[2][2] - v[2] * J[1][2];
+               const double c1 = v[2] * J[0][2] - v[0] * J[2][2];
+               const double c2 = v[0] * J[1][2] - v[1] * J[0][2];
+               detJ = J[0][2] * n0 + J[1][2] * n1 + J[2][2] * n2;
+               Dq[0][qz] = -aw * (J[0][1] * c0 + J[1][1] * c1 + J[2][1] * c2);
+               Dq[1][qz] = aw * (J[0][0] * c0 + J[1][0] * c1 + J[2][0] * c2);
+               Dq[2][qz] = aw * (v[0] * n0 + v[1] * n1 + v[2] * n2);
+            }
+            else
+            {
+               // adj(J), rows as in remhos_lo.cpp:1168-1180
+               const double A11 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+               const double A12 = J[2][1] * J[0][2] - J[0][1] * J[2][2];
+               const double A13 = J[0][1] * J[1][2] - J[1][1] * J[0][2];
+               const double A21 = J[2][0] * J[1][2] - J[1][0] * J[2][2];
+               const double A22 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+               const double A23 = J[1][0] * J[0][2] - J[0][0] * J[1][2];
+               const double A31 = J[1][0] * J[2][1] - J[2][0] * J[1][1];
+               const double A32 = J[2][0] * J[0][1] - J[0][0] * J[2][1];
+               const double A33 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+               detJ = J[0][0] * A11 + J[0][1] * A21 + J[0][2] * A31;
+               Dq[0][qz] = aw * (A11 * v[0] + A12 * v[1] + A13 * v[2]);
+               Dq[1][qz] = aw * (A21 * v[0] + A22 * v[1] + A23 * v[2]);
+               Dq[2][qz] = aw * (A31 * v[0] + A32 * v[1] + A33 * v[2]);
+            }
             wl[qz] = w3 * detJ;
          }
       }
