@@ -59,13 +59,8 @@ namespace rmh
 // per SIMD: p = 6 7.43 k -> 7.63 k (column) -> 7.66 k (PCG); p = 5 -0.8 % / -8 %, p = 4 0, p = 3 -3.7 %.  At three
 // wavefronts per SIMD (p = 6 now) both are better off with scalar loads again: column phase 11.1 k -> 11.9 k (100 -> 32
 // B/lane of scratch, 17 % fewer LDS instructions); PCG legs, with the one or two iterations of the -pa rule, p = 6
-// 16.24 k -> 16.58 k, p = 3 18.29 k -> 18.04 k with the LDS copy, p = 4 -1.7 % with it: scalar loads everywhere.
-#ifndef RMH_COLTAB_LDS
-#define RMH_COLTAB_LDS 0
-#endif
-#ifndef RMH_PCGTAB_LDS
-#define RMH_PCGTAB_LDS 0
-#endif
+// 16.24 k -> 16.58 k, p = 3 18.29 k -> 18.04 k with the LDS copy, p = 4 -1.7 % with it: scalar loads everywhere (the two
+// compile-time switches RMH_COLTAB_LDS / RMH_PCGTAB_LDS went when the table pointers got their address-space type, tabp).
 // wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
 // other workgroups on the CU (0: off)
 #ifndef RMH_PRIO
@@ -281,14 +276,27 @@ __device__ inline double wave_sum(double v)
 // v_readlane than FMA instructions); views are taken per unrolled quadrature plane.  At p <= 4 the table fits
 // the scalar registers and re-loading costs more than the few spills (measured: p = 3 -8 %), so the view is
 // the table itself.
-template <int P>
-__device__ inline const double *tab_view()
-{
-   int z = 0;
+// Pointers into the constant table.  p >= 5 (table views, below): typed with their address space and made opaque as
+// POINTERS -- an SGPR pair, entries are scalar loads at immediate offsets from it.  With an opaque index added to the symbol
+// instead (rounds 1-2) every single entry got its own s_getpc_b64 + four 32-bit adds in front of its s_load: the y-leg of the
+// test contractions at p = 6 had 1742 scalar instructions for 252 FMAs; with the typed pointer the p = 6 stage has 1583
+// instead of 5057 scalar instructions per wavefront and runs 10 % faster (p = 5 +10 %, lo 4 at p = 6 +12 %, bit-identical).
+// p <= 4: the plain symbol as before (measured with the typed pointer: p = 4 -1.8 %, p = 3 +0.2 %).
 #if defined(__HIP_DEVICE_COMPILE__)
-   if (P >= 5) { asm volatile("" : "+s"(z)); }
+typedef const double __attribute__((address_space(4))) *tabp_const;
+#else
+typedef const double *tabp_const;
 #endif
-   return c_tab[P] + z;
+template <int P>
+using tabp_t = std::conditional_t<(P >= 5), tabp_const, const double *>;
+template <int P>
+__device__ inline tabp_t<P> tab_view()
+{
+   tabp_t<P> t = (tabp_t<P>)c_tab[P];
+#if defined(__HIP_DEVICE_COMPILE__)
+   if constexpr (P >= 5) { asm volatile("" : "+s"(t)); }
+#endif
+   return t;
 }
 #define RMH_TAB() tab_view<P>()
 #define RMH_TABK() (P >= 5 ? tab_view<P>() : gtb)
@@ -969,8 +977,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // partial z-leg sums added across the three lanes (ds_bpermute) -- and it takes the face rows off the first one's hands.
    constexpr bool CSPL = SPL && C::CSPL;
    const int frt = CSPL ? (tid ^ 64) : tid; // face-row index of this thread (round 0)
-   const double *gtb = c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
-   const double *gt = gtb;
+   typedef tabp_t<P> tabp;
+   tabp gtb = (tabp)c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
+   tabp gt = gtb;
    (void)gt;
    if (blk != blk0) { __syncthreads(); } // the previous batch's last LDS reads precede this batch's stores
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
@@ -1169,7 +1178,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int q = qlo; q < qhi; q++)
          {
-            const double *gt = RMH_TABK();
+            tabp gt = RMH_TABK();
             double ub = 0.0, ug = 0.0;
 #pragma unroll
             for (int ix = 0; ix < D; ix++)
@@ -1332,7 +1341,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int q2 = 0; q2 < Q; q2++)
       {
-         const double *gt = RMH_TABK();
+         tabp gt = RMH_TABK();
          double sq; // w_q1 w_q2 max(0, upw * v.n_out) at time t
          if constexpr (FC)
          {
@@ -1450,9 +1459,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       constexpr bool ZS = decltype(zs_)::value;
       constexpr int NQ = ZS ? Q / 3 : Q;
       const int zo1 = ZS ? zt * NQ : 0, zo3 = 3 * zo1, zoD = D * zo1;
-      auto T3 = [&](const double *gt, int o, int qz, int i) { return ZS ? stab[o + qz * 3 + i + zo3] : gt[o + qz * 3 + i]; };
-      auto TD = [&](const double *gt, int o, int qz, int i) { return ZS ? stab[o + qz * D + i + zoD] : gt[o + qz * D + i]; };
-      auto T1 = [&](const double *gt, int o, int qz) { return ZS ? stab[o + qz + zo1] : gt[o + qz]; };
+      auto T3 = [&](tabp gt, int o, int qz, int i) { return ZS ? stab[o + qz * 3 + i + zo3] : gt[o + qz * 3 + i]; };
+      auto TD = [&](tabp gt, int o, int qz, int i) { return ZS ? stab[o + qz * D + i + zoD] : gt[o + qz * D + i]; };
+      auto T1 = [&](tabp gt, int o, int qz) { return ZS ? stab[o + qz + zo1] : gt[o + qz]; };
       double Ly[3], dLy[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) { Ly[k] = stab[oL + qy * 3 + k]; dLy[k] = stab[odL + qy * 3 + k]; }
@@ -1494,7 +1503,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int qz = 0; qz < NQ; qz++)
          {
             if (ZS) { sched_fence(); }
-            const double *gt = RMH_COLTAB_LDS ? (const double *)stab : RMH_TABK();
+            tabp gt = RMH_TABK();
             double J[3][3], v[3];
 #pragma unroll
             for (int comp = 0; comp < 3; comp++)
@@ -1588,7 +1597,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int qz = 0; qz < NQ; qz++)
       {
          if (ZS) { sched_fence(); }
-         const double *gt = RMH_COLTAB_LDS ? (const double *)stab : RMH_TABK();
+         tabp gt = RMH_TABK();
          double gx = 0, gy = 0, gz = 0;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
@@ -1673,7 +1682,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            const double *gt = RMH_TABK();
+            tabp gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
@@ -1702,7 +1711,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int k1 = 0; k1 < D; k1++)
          {
-            const double *gt = RMH_TABK();
+            tabp gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int q1 = 0; q1 < Q; q1++) { acc += gt[oBg + q1 * D + k1] * in[q1]; }
@@ -2116,7 +2125,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
             for (int q = qlo; q < qhi; q++)
             {
-               const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
+               tabp gt = RMH_TABK();
                double acc = 0.0;
 #pragma unroll
                for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
@@ -2154,7 +2163,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
-            const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
+            tabp gt = RMH_TABK();
             double acc = 0.0;
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
@@ -2182,7 +2191,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
             for (int iy = ylo; iy < yhi; iy++)
             {
-               const double *gt = RMH_PCGTAB_LDS ? (const double *)stab : RMH_TABK();
+               tabp gt = RMH_TABK();
                double acc = 0.0;
 #pragma unroll
                for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
