@@ -36,6 +36,9 @@ namespace rmh
 #ifndef RMH_ADJ_CROSS
 #define RMH_ADJ_CROSS (P == 3)
 #endif
+#ifndef RMH_VIEW_MINP
+#define RMH_VIEW_MINP 4
+#endif
 #ifndef RMH_XCD_MAP
 #define RMH_XCD_MAP (P == 3)
 #endif
@@ -281,25 +284,27 @@ __device__ inline double wave_sum(double v)
 // instead (rounds 1-2) every single entry got its own s_getpc_b64 + four 32-bit adds in front of its s_load: the y-leg of the
 // test contractions at p = 6 had 1742 scalar instructions for 252 FMAs; with the typed pointer the p = 6 stage has 1583
 // instead of 5057 scalar instructions per wavefront and runs 10 % faster (p = 5 +10 %, lo 4 at p = 6 +12 %, bit-identical).
-// p <= 4: the plain symbol as before (measured with the typed pointer: p = 4 -1.8 %, p = 3 +0.2 %).
+// Views from p = 4 on (RMH_VIEW_MINP): with cheap views p = 4 gains 2.5-3 % over the plain symbol (cube01_hex -rs 5: 18.65 k ->
+// 19.17 k; fewer scalar-register spills to VGPR lanes), p = 3 loses 1.3-2.7 %, p = 2 +-0; p <= 3 keep the plain symbol
+// (typed but not opaque there: p = 4 -1.8 %, p = 3 +0.2 %).
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const double __attribute__((address_space(4))) *tabp_const;
 #else
 typedef const double *tabp_const;
 #endif
 template <int P>
-using tabp_t = std::conditional_t<(P >= 5), tabp_const, const double *>;
+using tabp_t = std::conditional_t<(P >= RMH_VIEW_MINP), tabp_const, const double *>;
 template <int P>
 __device__ inline tabp_t<P> tab_view()
 {
    tabp_t<P> t = (tabp_t<P>)c_tab[P];
 #if defined(__HIP_DEVICE_COMPILE__)
-   if constexpr (P >= 5) { asm volatile("" : "+s"(t)); }
+   if constexpr (P >= RMH_VIEW_MINP) { asm volatile("" : "+s"(t)); }
 #endif
    return t;
 }
 #define RMH_TAB() tab_view<P>()
-#define RMH_TABK() (P >= 5 ? tab_view<P>() : gtb)
+#define RMH_TABK() (P >= RMH_VIEW_MINP ? tab_view<P>() : gtb)
 
 // Synchronisation of an LDS hand-off between the lanes that own ONE element.  Where every (round, wavefront) of the dof
 // role holds exactly one element (p = 3: 64 dofs), the lanes of the hand-off are the lanes of one wavefront: its LDS
