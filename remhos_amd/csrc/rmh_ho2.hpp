@@ -39,6 +39,12 @@ namespace rmh
 #ifndef RMH_VIEW_MINP
 #define RMH_VIEW_MINP 4
 #endif
+#ifndef RMH_PENCIL_BACK
+#define RMH_PENCIL_BACK 1
+#endif
+#ifndef RMH_PENCIL_XLEG
+#define RMH_PENCIL_XLEG 1
+#endif
 #ifndef RMH_XCD_MAP
 #define RMH_XCD_MAP (P == 3)
 #endif
@@ -1738,6 +1744,44 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       uu4[r] = 0.0;
       if (LO4 && t < NB * D3) { uu4[r] = a.u[(size_t)min(e0 + t / D3, a.e_end - 1) * D3 + t % D3]; }
    }
+   // One element per workgroup, HO / lo 5 kernels (p >= 4): the x-leg as pencil tasks, in place -- a thread reads the Q
+   // inputs of a line (iy, iz) of one tensor once and writes its D outputs over the first D of them, table rows as scalar
+   // operands; the dof threads then pick up one value per tensor.  In the dof form every dof read Q inputs and Q table
+   // entries from LDS per tensor (p = 6: 162 LDS reads per thread, now 27 + 9).  Split workgroups divide the tensors, as in
+   // the y-leg.  Same sums in the same order.
+   constexpr bool PX = RMH_PENCIL_XLEG && NB == 1 && C::INPLACE_Y && !LO4 && !(RMH_CBG_REG);
+   if (PX)
+   {
+      constexpr int rs2 = Q2 * D;
+      for (int k = ptid; k < D2; k += PNT)
+      {
+         const int iy = k / D, iz = k % D;
+         split_outputs<SPL, C::NR>(wv, [&](auto rlo, auto rhi) {
+#pragma unroll
+            for (int r = rlo; r < rhi; r++)
+            {
+               double *line = RMH_W(0) + oR2 + r * rs2 + Q * iy * D + iz;
+               double in[Q];
+#pragma unroll
+               for (int jx = 0; jx < Q; jx++) { in[jx] = line[jx * D]; }
+#pragma unroll
+               for (int ix = 0; ix < D; ix++)
+               {
+                  tabp gt = RMH_TABK();
+                  double acc = 0.0;
+#pragma unroll
+                  for (int jx = 0; jx < Q; jx++)
+                  {
+                     const double w = (r == 0) ? gt[oBg + jx * D + ix] : (r == 2 ? gt[oBg2 + jx * D + ix] : gt[oB + jx * D + ix]);
+                     acc += w * in[jx];
+                  }
+                  line[ix * D] = acc;
+               }
+            }
+         });
+      }
+      __syncthreads();
+   }
    double rg[DR], mm[DR], dg[DR], zb[DR];
    // column ix of the GL basis table of each dof of this thread (x-legs): kept in registers through the PCG loop where
    // that is cheap (p <= 4); at p = 6 the 27 doubles starve the loop of registers -- every LDS read then reuses one
@@ -1762,8 +1806,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const double *R2 = RMH_W(eb) + oR2;
          constexpr bool XB = BOTH && RMH_RD_XLEG;
          double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+         if (PX)
+         {
+            const int o2 = (ix + Q * idx[1]) * D + idx[2];
+            a0 = R2[0 * (Q2 * D) + o2];
+            a1 = R2[1 * (Q2 * D) + o2];
+            a2 = R2[2 * (Q2 * D) + o2];
+         }
 #pragma unroll
-         for (int jx = 0; jx < Q; jx++)
+         for (int jx = 0; jx < (PX ? 0 : Q); jx++)
          {
             const double bgx = stab[(HAS_HO ? oBg : oB) + jx * D + ix];
             if (CBG_REG) { cBg[CBG_REG ? r : 0][jx] = bgx; }
@@ -1824,6 +1875,32 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          {
             const int oin = ((dir - dir0) & 1) ? oSB : oSA, oout = ((dir - dir0) & 1) ? oSA : oSB;
             const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
+            // (one element per workgroup: the directions before the last as pencil tasks, see the back-transform of phase J)
+            if (RMH_PENCIL_BACK && NB == 1 && dir < 2)
+            {
+               for (int k = ptid; k < D2; k += PNT)
+               {
+                  const int base = (dir == 0) ? k * D : (k % D) + (k / D) * D2;
+                  const double *src = RMH_W(0) + oin + base;
+                  double in[D];
+#pragma unroll
+                  for (int j = 0; j < D; j++) { in[j] = src[j * stride]; }
+                  double *dst = RMH_W(0) + oout + base;
+                  split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
+#pragma unroll
+                     for (int kk = klo; kk < khi; kk++)
+                     {
+                        tabp gt = RMH_TABK();
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D; j++) { acc += gt[C::oCf + kk * D + j] * in[j]; }
+                        dst[kk * stride] = acc;
+                     }
+                  });
+               }
+            }
+            else
+            {
 #pragma unroll
             for (int r = 0; r < DR; r++)
             {
@@ -1839,6 +1916,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                   if (dir == 2) { zb[r] = acc; }
                   else { RMH_W(eb)[oout + i] = acc; }
                }
+            }
             }
             __syncthreads();
          }
@@ -2306,6 +2384,36 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       const int oin = (dir & 1) ? oSB : oSA, oout = (dir & 1) ? oSA : oSB;
       const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
+      // one element per workgroup (p >= 4): the directions as pencil tasks -- a thread reads a line's D inputs
+      // once and forms its D outputs (split workgroups: half of them) with the table row as scalar operands; a dof thread
+      // reads D inputs and D table entries from LDS for ONE output (p = 6: 42 instead of 7 LDS reads per thread and
+      // direction).  Same sums in the same order.  The dof threads read their outputs behind the barrier of the last direction.
+      constexpr bool PJ = RMH_PENCIL_BACK && NB == 1;
+      if (PJ)
+      {
+         for (int k = ptid; k < D2; k += PNT)
+         {
+            const int base = (dir == 0) ? k * D : (dir == 1 ? (k % D) + (k / D) * D2 : k);
+            const double *src = RMH_W(0) + oin + base;
+            double in[D];
+#pragma unroll
+            for (int j = 0; j < D; j++) { in[j] = src[j * stride]; }
+            double *dst = RMH_W(0) + oout + base;
+            split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
+#pragma unroll
+               for (int kk = klo; kk < khi; kk++)
+               {
+                  tabp gt = RMH_TABK();
+                  double acc = 0.0;
+#pragma unroll
+                  for (int j = 0; j < D; j++) { acc += gt[oCi + kk * D + j] * in[j]; }
+                  dst[kk * stride] = acc;
+               }
+            });
+         }
+      }
+      else
+      {
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -2321,6 +2429,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             if (dir == 2) { xg[r] = acc; }
             else { RMH_W(eb)[oout + i] = acc; }
          }
+      }
       }
       if (FUSED && dir == 0)
       {
@@ -2367,6 +2476,16 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       constexpr bool WL = RMH_WAVE_LOCAL && C::WAVE_ALIGNED;
       if (dir < 2) { sync_element<WL>(); }
       else { __syncthreads(); }
+      if (PJ && dir == 2)
+      {
+         // (the pencil form leaves the last direction's outputs in LDS: the dof threads pick up theirs)
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            if (t < D3) { xg[r] = RMH_W(0)[oout + t]; }
+         }
+      }
    }
    RMH_STAMP(16);
 #pragma unroll
