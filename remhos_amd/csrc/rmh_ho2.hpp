@@ -45,6 +45,9 @@ namespace rmh
 #ifndef RMH_PENCIL_XLEG
 #define RMH_PENCIL_XLEG 1
 #endif
+#ifndef RMH_PENCIL_BACK_NB
+#define RMH_PENCIL_BACK_NB 1
+#endif
 #ifndef RMH_XCD_MAP
 #define RMH_XCD_MAP (P == 3)
 #endif
@@ -2388,17 +2391,18 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       // once and forms its D outputs (split workgroups: half of them) with the table row as scalar operands; a dof thread
       // reads D inputs and D table entries from LDS for ONE output (p = 6: 42 instead of 7 LDS reads per thread and
       // direction).  Same sums in the same order.  The dof threads read their outputs behind the barrier of the last direction.
-      constexpr bool PJ = RMH_PENCIL_BACK && NB == 1;
+      constexpr bool PJ = RMH_PENCIL_BACK && (NB == 1 || RMH_PENCIL_BACK_NB);
       if (PJ)
       {
-         for (int k = ptid; k < D2; k += PNT)
+         for (int k0 = ptid; k0 < NB * D2; k0 += PNT)
          {
+            const int eb = k0 / D2, k = k0 % D2;
             const int base = (dir == 0) ? k * D : (dir == 1 ? (k % D) + (k / D) * D2 : k);
-            const double *src = RMH_W(0) + oin + base;
+            const double *src = RMH_W(eb) + oin + base;
             double in[D];
 #pragma unroll
             for (int j = 0; j < D; j++) { in[j] = src[j * stride]; }
-            double *dst = RMH_W(0) + oout + base;
+            double *dst = RMH_W(eb) + oout + base;
             split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
 #pragma unroll
                for (int kk = klo; kk < khi; kk++)
@@ -2473,7 +2477,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       // (p = 3: the directions hand over within the wavefront that owns the element; one workgroup barrier at the end
       // publishes the box table)
-      constexpr bool WL = RMH_WAVE_LOCAL && C::WAVE_ALIGNED;
+      constexpr bool WL = RMH_WAVE_LOCAL && C::WAVE_ALIGNED && !PJ;
       if (dir < 2) { sync_element<WL>(); }
       else { __syncthreads(); }
       if (PJ && dir == 2)
@@ -2483,7 +2487,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int r = 0; r < DR; r++)
          {
             const int t = tid + r * NT;
-            if (t < D3) { xg[r] = RMH_W(0)[oout + t]; }
+            if (t < NB * D3) { xg[r] = RMH_W(t / D3)[oout + t % D3]; }
          }
       }
    }
