@@ -48,6 +48,9 @@ namespace rmh
 #ifndef RMH_PENCIL_BACK_NB
 #define RMH_PENCIL_BACK_NB 1
 #endif
+#ifndef RMH_LUMP_LATE
+#define RMH_LUMP_LATE 1
+#endif
 #ifndef RMH_XCD_MAP
 #define RMH_XCD_MAP (P == 3)
 #endif
@@ -1414,14 +1417,16 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    RMH_STAMP(26);
 #if RMH_EARLY_PENCILS
    // (the column phase reads the nodes and U1, both complete since the barrier above; the face rows' output is read
-   // after the next barrier -- only the lumped face fluxes of the RD scheme need it here)
-   if (LO4) { __syncthreads(); }
+   // after the next barrier -- only the lumped face fluxes of the RD scheme need it here.  Split columns, p = 6: there the
+   // face rows run on the second wavefront BESIDE the first one's column pass, so the lumped fluxes wait until both are done)
+   constexpr bool LUMP_LATE = LO4 && CSPL && RMH_LUMP_LATE;
+   if (LO4 && !LUMP_LATE) { __syncthreads(); }
 #else
+   constexpr bool LUMP_LATE = false;
    __syncthreads();
 #endif
 
-   if (LO4)
-   {
+   auto lumped_face_fluxes = [&]() {
       // lumped upwind face fluxes (ApplyFaceTerms3D, remhos_lo.cpp:795-871), gathered per dof:
       // (B^T D B 1)_i (u_nbr,i - u_i) with the face rows already tested along q2
       for (int t = tid; t < NB * D3; t += NT)
@@ -1448,7 +1453,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
          RMH_W(eb)[C::oDuf + i] = acc;
       }
-   }
+   };
+   if (LO4 && !LUMP_LATE) { lumped_face_fluxes(); }
    RMH_STAMP(2);
    // ---- phase C: column threads: geometry, grad u, z-leg of the test contractions -------------------
    // column role: thread -> quadrature column cc = qx + Q qy; in the split wavefront (CSPL) three lanes share a column, lane
@@ -1652,6 +1658,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          r1[iz] = (r1[iz] + __shfl(r1[iz], l1)) + __shfl(r1[iz], l2);
          if (HAS_HO) { r2[iz] = (r2[iz] + __shfl(r2[iz], l1)) + __shfl(r2[iz], l2); }
       }
+   }
+   if (LUMP_LATE)
+   {
+      __syncthreads(); // the face rows are complete
+      lumped_face_fluxes();
    }
    __syncthreads(); // R3 overlays the phase A-C data: every thread is done with nodes, u, traces, U1
    if (col)
