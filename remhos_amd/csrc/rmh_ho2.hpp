@@ -51,6 +51,9 @@ namespace rmh
 #ifndef RMH_LUMP_LATE
 #define RMH_LUMP_LATE 1
 #endif
+#ifndef RMH_TRACE_JUMP
+#define RMH_TRACE_JUMP 1
+#endif
 #ifndef RMH_XCD_MAP
 #define RMH_XCD_MAP (P == 3)
 #endif
@@ -1285,15 +1288,32 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #if RMH_EARLY_PENCILS
    // The neighbour traces are the only loads that depend on another load (the neighbour index): they are not waited
    // for at the first barrier but here, behind the x-pencils of u, which need none of them.
+   // What is stored is the JUMP u_nbr - u_own at the face dof (RMH_TRACE_JUMP): the Q face rows of a face each formed the
+   // same D^2 differences from two LDS reads apiece (p = 6: 98 reads and 49 subtractions per row, on the wavefront that is
+   // the longer pole of the workgroup); now one read and one subtraction per trace value here, D^2 reads per row there.
+   constexpr bool TJ = RMH_TRACE_JUMP;
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
       const int k = tid + j * NT;
-      if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
+      if (k < NB * 6 * D2)
+      {
+         double own = 0.0;
+         if (TJ)
+         {
+            const int r6 = k % (6 * D2);
+            const int f = r6 / D2, r = r6 % D2;
+            const int c = f >> 1, side = f & 1;
+            const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
+            own = RMH_W(k / (6 * D2))[oU + (side ? P * strc : 0) + (r % D) * str1 + (r / D) * str2];
+         }
+         RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j] - own;
+      }
    }
    __syncthreads();
    RMH_STAMP(25);
 #else
+   constexpr bool TJ = false;
    if (LO4) { __syncthreads(); }
 #endif
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
@@ -1349,7 +1369,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       {
          double acc = 0.0;
 #pragma unroll
-         for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * (un[i1 + D * i2] - uo[i1 * d1 + i2 * d2]); }
+         for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * (TJ ? un[i1 + D * i2] : un[i1 + D * i2] - uo[i1 * d1 + i2 * d2]); }
          jr[i2] = acc;
       }
       double tq[D], tq2[D];
@@ -1448,7 +1468,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                double coef = 0.0;
 #pragma unroll
                for (int q1 = 0; q1 < Q; q1++) { coef += stab[oB + q1 * D + i1] * F[q1 * D]; }
-               acc += coef * (RMH_W(eb)[oNb + f * D2 + i1 + D * i2] - ui);
+               acc += coef * (TJ ? RMH_W(eb)[oNb + f * D2 + i1 + D * i2] : RMH_W(eb)[oNb + f * D2 + i1 + D * i2] - ui);
             }
          }
          RMH_W(eb)[C::oDuf + i] = acc;
