@@ -210,6 +210,16 @@ __device__ inline double dpp_add(double v)
    return v + __hiloint2double(hi2, lo2);
 }
 
+// the value of the lane selected by the DPP control (0 where the control has no source lane)
+template <int CTRL>
+__device__ inline double dpp_value(double v)
+{
+   const int lo = __double2loint(v), hi = __double2hiint(v);
+   const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+   const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+   return __hiloint2double(hi2, lo2);
+}
+
 // the same for controls that give every lane a valid source (quad_perm, row mirrors over all rows): no
 // "old" value, hence no zero-initialisation of the destination
 template <int CTRL>
@@ -1481,10 +1491,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // 3 c + zt takes the third zt of its qz range
    const int sl = tid - 64;
    const bool zsplit = CSPL && wv == 1;
-   const bool col = CSPL ? (tid < 64 || sl < 3 * (Q2 - 64)) : tid < NB * Q2;
+   // (split wavefront: five triples per 16-lane row, the sixteenth lane idle -- the three partial sums of a column then
+   // meet by DPP row shifts; with the triples packed across rows they needed ds_bpermute)
+   static_assert(!CSPL || 20 >= Q2 - 64, "split columns: four rows of five triples");
+   const int srow = (sl >> 4) & 3, sin = sl & 15;
+   const int scc = 64 + srow * 5 + sin / 3;
+   const bool col = CSPL ? (tid < 64 || (sin < 15 && scc < Q2)) : tid < NB * Q2;
    const int ceb = (col && !CSPL) ? tid / Q2 : 0;
-   const int cc = CSPL ? (tid < 64 ? tid : min(64 + sl / 3, Q2 - 1)) : tid % Q2;
-   const int zt = zsplit ? sl % 3 : 0;
+   const int cc = CSPL ? (tid < 64 ? tid : min(scc, Q2 - 1)) : tid % Q2;
+   const int zt = zsplit ? (sin % 3) % 3 : 0;
    const int qx = cc % Q, qy = cc / Q;
    double wd[Q];
    double Bgy[D]; // GL basis row of this thread's qy (mass apply)
@@ -1669,14 +1684,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    RMH_STAMP(31);
    if (zsplit)
    {
-      // the three thirds of a column's z-leg sums, added in the order of qz (every lane of the wavefront takes part)
-      const int l1 = (tid + 1) & 63, l2 = (tid + 2) & 63;
+      // the three thirds of a column's z-leg sums, added in the order of qz (DPP row_shl:1 and row_shl:2: the values of
+      // the next two lanes of the row; every lane of the wavefront takes part)
 #pragma unroll
       for (int iz = 0; iz < D; iz++)
       {
-         r0[iz] = (r0[iz] + __shfl(r0[iz], l1)) + __shfl(r0[iz], l2);
-         r1[iz] = (r1[iz] + __shfl(r1[iz], l1)) + __shfl(r1[iz], l2);
-         if (HAS_HO) { r2[iz] = (r2[iz] + __shfl(r2[iz], l1)) + __shfl(r2[iz], l2); }
+         r0[iz] = (r0[iz] + dpp_value<0x101>(r0[iz])) + dpp_value<0x102>(r0[iz]);
+         r1[iz] = (r1[iz] + dpp_value<0x101>(r1[iz])) + dpp_value<0x102>(r1[iz]);
+         if (HAS_HO) { r2[iz] = (r2[iz] + dpp_value<0x101>(r2[iz])) + dpp_value<0x102>(r2[iz]); }
       }
    }
    if (LUMP_LATE)

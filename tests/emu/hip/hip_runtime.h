@@ -104,6 +104,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
    const unsigned row = lane >> 4, inrow = lane & 15u;
    int srclane = -1;
    if (ctrl >= 0 && ctrl <= 0xFF) { srclane = (int)((lane & ~3u) + ((ctrl >> (2 * (lane & 3u))) & 3)); } // quad_perm
+   else if (ctrl > 0x100 && ctrl <= 0x10F) { srclane = (inrow + (ctrl & 15) < 16) ? (int)(lane + (ctrl & 15)) : -1; }     // row_shl:n
    else if (ctrl == 0x140) { srclane = (int)(row * 16 + (15 - inrow)); }                                  // row_mirror
    else if (ctrl == 0x141) { srclane = (int)(row * 16 + (inrow < 8 ? 7 - inrow : 23 - inrow)); }          // row_half_mirror
    else if (ctrl == 0x142) { srclane = (row >= 1) ? (int)(row * 16 - 1) : -1; }                           // row_bcast:15
