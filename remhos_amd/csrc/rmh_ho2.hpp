@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    constexpr int PNT = SPL ? 64 : NT;
    // (p = 6) column split: 81 quadrature columns on two wavefronts left the second one a full pass over 17 columns.  The
    // first wavefront keeps columns 0..63; on the second, three lanes share a column -- a third of the qz range each, the
-   // partial z-leg sums added across the three lanes (ds_bpermute) -- and it takes the face rows off the first one's hands.
+   // partial z-leg sums added across the three lanes (DPP row shifts) -- and it takes the face rows off the first one's hands.
    constexpr bool CSPL = SPL && C::CSPL;
    const int frt = CSPL ? (tid ^ 64) : tid; // face-row index of this thread (round 0)
    typedef tabp_t<P> tabp;

@@ -60,7 +60,7 @@ def test_kernels_vs_oracle(lib, mesh, rs, p, prob, t):
 
 def test_split_columns_p6_emulated(lib):
     """p = 6: two wavefronts per element; the second one runs the face rows and the 17 quadrature columns beyond the first 64
-    with three lanes per column (a third of the qz range each, ds_bpermute sums, w detJ of those columns in LDS).  HO kernel
+    with three lanes per column (a third of the qz range each, DPP row-shift sums, w detJ of those columns in LDS).  HO kernel
     and one-kernel stage against the oracle under the host emulation (GPU twins: tests/test_gpu_parity.py at p = 6)."""
     from remhos_amd.capi import Context
 
