@@ -32,7 +32,9 @@ namespace rmh
 // 20-40 % slower; kept as a compile-time option (the launch side sizes the grid accordingly).
 // lo 4 stage: the RD solver's z = K_vol u needs the Bernstein test basis; its x-direction comes out of the x-leg of phase G
 // as a second accumulator (one conversion leg less) -- not at p = 3, where that accumulator is the register that spills
-// adj(J) v through two cross products in the column phase, and the XCD-aware batch map: small measured gains at p = 3 only
+// adj(J) v through two cross products in the column phase: a small measured gain at p = 3 only; the XCD-aware batch map:
+// every order (re-measured at the end of round 3: p = 4 +1.8 %, p = 6 +0.5 %, p = 5 -0.4 %; earlier, with p = 6 bound by its scalar
+// instructions, it had measured -2 % there)
 #ifndef RMH_ADJ_CROSS
 #define RMH_ADJ_CROSS (P == 3)
 #endif
@@ -55,7 +57,7 @@ namespace rmh
 #define RMH_TRACE_JUMP 1
 #endif
 #ifndef RMH_XCD_MAP
-#define RMH_XCD_MAP (P == 3)
+#define RMH_XCD_MAP 1
 #endif
 #ifndef RMH_COLSPLIT
 #define RMH_COLSPLIT 1
@@ -976,7 +978,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       // workgroups are handed to the 8 XCDs round-robin (blockIdx.x % 8): give every XCD -- every L2 -- one contiguous
       // eighth of the element batches, so that the x- and y-neighbours whose traces and extrema an element reads were
-      // touched by workgroups of the same XCD a few batches earlier (+0.5 % at p = 3, -2 % at p = 6: p = 3 only)
+      // touched by workgroups of the same XCD a few batches earlier (p = 3: HBM traffic per launch 3.71 -> 2.50 GB)
       const int xcd = blk & 7, j8 = blk >> 3, q8 = nblk >> 3, r8 = nblk & 7;
       blk = xcd * q8 + min(xcd, r8) + j8;
    }
