@@ -16,6 +16,7 @@
 #include "../rmh.h"
 
 #include <cstddef>
+#include <vector>
 
 namespace remhos
 {
@@ -368,21 +369,26 @@ public:
    void Step(Vector &x, real_t &t, real_t &dt) override;
 };
 
-// remhos_solvers.hpp:94-126, remhos_solvers.cpp:42-250.  The masks (UseMask / AddMasked / UpdateMask) are not built: the
+// remhos_solvers.hpp:94-126: an explicit Runge-Kutta tableau run as a chain of limited forward Euler legs (PlanLegs, in
+// rmh_driver.hip, derives the legs from the tableau).  The masks (UseMask / AddMasked / UpdateMask) are not built: the
 // reference's driver switches them off for every run (remhos.cpp:502-507).
 class RKIDPSolver : public IDPODESolver
 {
-   const int s;
-   const real_t *a, *b, *c;
-   real_t *d;
-   Vector *dxs;
-   // Constructs the coefficients that turn eq. (2.16) of JLG's paper into an update that only uses the previous
-   // limited updates (remhos_solvers.cpp:42-96).
-   void ConstructD();
+public:
+   struct EulerLeg
+   {
+      real_t from = 0., span = 0.; // pseudo-time fractions of the step: the leg starts at from and is span long
+      std::vector<real_t> w;       // unlimited rate of leg i = w[i] * (HO rate at the chain's state) + sum_{k<i} w[k] * limited rate k
+      bool lands = true;           // the state advances by this leg
+   };
+   static std::vector<EulerLeg> PlanLegs(int stages, const real_t *a_packed, const real_t *b_row, const real_t *c_abs);
+
+private:
+   const std::vector<EulerLeg> legs;
+   std::vector<Vector> limited; // limited rates of the legs of the current step
 
 public:
-   RKIDPSolver(int s_, const real_t a_[], const real_t b_[], const real_t c_[]);
-   ~RKIDPSolver();
+   RKIDPSolver(int stages, const real_t a_packed[], const real_t b_row[], const real_t c_abs[]);
    void Init(LimitedTimeDependentOperator &f_) override;
    void Step(Vector &x, real_t &t, real_t &dt) override;
 };

@@ -350,7 +350,7 @@ void ForwardEulerIDPSolver::Init(LimitedTimeDependentOperator &f_)
 }
 void ForwardEulerIDPSolver::Step(Vector &x, real_t &t, real_t &dt)
 {
-   // remhos_solvers.cpp:30-40
+   // one limited leg over the whole step (the reference's -s 11, remhos_solvers.cpp:30-40)
    f->SetTime(t);
    f->SetDt(dt);
    f->MultUnlimited(x, dx);
@@ -359,108 +359,89 @@ void ForwardEulerIDPSolver::Step(Vector &x, real_t &t, real_t &dt)
    t += dt;
 }
 
-void RKIDPSolver::ConstructD()
+// An explicit Runge-Kutta method  X_i = x_n + dt sum_j A_ij k_j  (last row: the weights b, abscissa 1) run as a chain of
+// LIMITED forward Euler legs (the reference's RKIDPSolver, remhos_solvers.hpp:94-126; masks absent, remhos.cpp:502-507).
+// The chain stands at a state that is itself a row of the tableau, "here"; leg i has to carry it to row i over the
+// pseudo-time span = abscissa_i - at.  As an Euler rate that is
+//      U_i = sum_j (A_ij - here_j) / span * k_j ,
+// but the earlier k_j are gone: what the chain kept of stage j is its limited rate L_j = limit(U_j).  Reading U_j = L_j
+// backwards gives every earlier k_j as a combination of L_0 .. L_j ("worth"), and U_i becomes
+//      U_i = w_i k_i + sum_{k<i} w_k L_k .
+// A leg whose successor's abscissa does not lie ahead of its own is limited and remembered, but the chain stays put.
+std::vector<RKIDPSolver::EulerLeg> RKIDPSolver::PlanLegs(int stages, const real_t *a_packed, const real_t *b_row, const real_t *c_abs)
 {
-   // Convert high-order to Forward Euler factors (remhos_solvers.cpp:42-96)
-   d = new real_t[s * (s + 1) / 2]();
-   const real_t *a_n = a; // new coeff line
-   const real_t *a_o = a; // old coeff line
-   int i_o = -1;          // old stage
-   real_t c_o = 0.;       // old time fraction
-   for (int i = 0; i < s; i++)
+   auto row = [&](int i) { return (i < stages - 1) ? a_packed + i * (i + 1) / 2 : b_row; };
+   auto abscissa = [&](int i) { return (i < stages - 1) ? c_abs[i] : real_t(1); };
+   std::vector<std::vector<real_t>> worth(stages, std::vector<real_t>(stages, 0.)); // k_j = sum_k worth[j][k] L_k
+   std::vector<real_t> here(stages, 0.);
+   real_t at = 0.;
+   std::vector<EulerLeg> legs(stages);
+   for (int i = 0; i < stages; i++)
    {
-      const real_t c_n = (i < s - 1) ? c[i] : 1.; // new time fraction
-      const real_t dc = c_n - c_o;                // time fraction diff
-      real_t *di = d + i * (i + 1) / 2;
+      EulerLeg &leg = legs[i];
+      leg.from = at;
+      leg.span = abscissa(i) - at;
+      RMH_VERIFY(leg.span > 0. && row(i)[i] != 0., "tableau cannot be run as forward Euler legs");
+      leg.w.assign(i + 1, 0.);
       for (int j = 0; j < i; j++)
       {
-         const real_t a_oj = (j <= i_o) ? a_o[j] : 0.; // old coeff
-         const real_t m = (a_n[j] - a_oj) / dc;        // old HO update coeff
-         if (m == 0.) { di[j] = 0.; continue; }
-         // Express j-th HO update by Forward Euler updates
-         const real_t *dj = d + j * (j + 1) / 2;
-         const real_t dij = m / dj[j];
-         for (int k = 0; k < j; k++) { di[k] -= dj[k] * dij; }
-         di[j] = dij;
+         const real_t g = (row(i)[j] - here[j]) / leg.span;
+         if (g == 0.) { continue; }
+         for (int k = 0; k <= j; k++) { leg.w[k] += g * worth[j][k]; }
       }
-      di[i] = a_n[i] / dc;
-      // Update stage
-      const double c_next = (i < s - 2) ? c[i + 1] : 1.;
-      if (c_next > c_n) { i_o = i; c_o = c_n; a_o = a_n; }
-      if (i < s - 2) { a_n += i + 1; }
-      else { a_n = b; }
+      leg.w[i] = row(i)[i] / leg.span;
+      for (int k = 0; k < i; k++) { worth[i][k] = -leg.w[k] / leg.w[i]; }
+      worth[i][i] = 1. / leg.w[i];
+      leg.lands = (i == stages - 1) || abscissa(i + 1) > abscissa(i);
+      if (leg.lands)
+      {
+         at = abscissa(i);
+         for (int j = 0; j < stages; j++) { here[j] = (j <= i) ? row(i)[j] : 0.; }
+      }
    }
+   return legs;
 }
 
-RKIDPSolver::RKIDPSolver(int s_, const real_t a_[], const real_t b_[], const real_t c_[]) : s(s_), a(a_), b(b_), c(c_)
+RKIDPSolver::RKIDPSolver(int stages, const real_t a_packed[], const real_t b_row[], const real_t c_abs[])
+   : legs(PlanLegs(stages, a_packed, b_row, c_abs)), limited(stages)
 {
-   dxs = new Vector[s];
-   ConstructD();
-}
-RKIDPSolver::~RKIDPSolver()
-{
-   delete[] dxs;
-   delete[] d;
 }
 void RKIDPSolver::Init(LimitedTimeDependentOperator &f_)
 {
    IDPODESolver::Init(f_);
-   for (int i = 0; i < s; i++) { dxs[i].SetSize(f->Height()); }
+   for (Vector &v : limited) { v.SetSize(f->Height()); }
 }
 void RKIDPSolver::Step(Vector &x, real_t &t, real_t &dt)
 {
-   // remhos_solvers.cpp:171-250 with use_masks = false (remhos.cpp:502-507)
-   real_t c_o = 0.;
-   // Perform the first step
    f->SetTime(t);
-   f->SetDt(c[0] * dt);
-   f->MultUnlimited(x, dxs[0]);
-   f->LimitMult(x, dxs[0]);
-   // Update state
+   for (size_t i = 0; i < legs.size(); i++)
    {
-      const double c_next = (s > 2) ? c[1] : 1.;
-      if (c_next > c[0]) // only when advancing after
+      const EulerLeg &leg = legs[i];
+      Vector &rate = limited[i];
+      f->SetDt(leg.span * dt);
+      f->MultUnlimited(x, rate); // k_i at the state (and mesh position) the chain stands at
+      if (i > 0 || leg.w[0] != 1.)
       {
-         add(x, c[0] * dt, dxs[0], x);
-         f->SetTime(t + c[0] * dt);
-         c_o = c[0];
+         add(leg.w[i], rate, (i > 0) ? leg.w[0] : 0., limited[0], rate);
+         for (size_t k = 1; k < i; k++) { add(rate, leg.w[k], limited[k], rate); }
       }
-   }
-   // Step through higher stages
-   const real_t *d_i = d + 1;
-   for (int i = 1; i < s; i++)
-   {
-      const real_t c_n = (i < s - 1) ? c[i] : 1.;
-      const real_t dc = c_n - c_o;
-      const real_t dct = dc * dt;
-      // Explicit HO step
-      f->SetDt(dct);
-      f->MultUnlimited(x, dxs[i]);
-      // Form the unlimited update for the stage: it converts eq. (2.16) in JLG's paper into an update using the
-      // previous limited updates.
-      add(d_i[i], dxs[i], d_i[0], dxs[0], dxs[i]);
-      for (int j = 1; j < i; j++) { add(dxs[i], d_i[j], dxs[j], dxs[i]); }
-      // Limit the step (always a Forward Euler step).
-      f->LimitMult(x, dxs[i]);
-      // Update the state
-      const double c_next = (i < s - 2) ? c[i + 1] : 1.;
-      if (i == s - 1 || c_next > c_n) // only when advancing after
+      f->LimitMult(x, rate); // rate: U_i in, L_i out
+      if (leg.lands)
       {
-         f->SetTime(t + c_n * dt);
-         add(x, dct, dxs[i], x);
-         c_o = c_n;
+         add(x, leg.span * dt, rate, x);
+         f->SetTime(t + (leg.from + leg.span) * dt);
       }
-      d_i += i + 1;
    }
    t += dt;
 }
 
-// 2-stage, 2nd order / 3-stage, 3rd order (remhos_solvers.cpp:252-260)
-const real_t RK2IDPSolver::a[] = {.5};
+// midpoint rule and the three-stage third-order method that the reference runs as -s 12 / -s 13 (remhos_solvers.cpp:252-260):
+// lower-triangular rows packed one after the other, weights, abscissae
+const real_t RK2IDPSolver::a[] = {1. / 2.};
 const real_t RK2IDPSolver::b[] = {0., 1.};
-const real_t RK2IDPSolver::c[] = {.5};
-const real_t RK3IDPSolver::a[] = {1. / 3., 0., 2. / 3.};
-const real_t RK3IDPSolver::b[] = {.25, 0., .75};
+const real_t RK2IDPSolver::c[] = {1. / 2.};
+const real_t RK3IDPSolver::a[] = {1. / 3., /**/ 0., 2. / 3.};
+const real_t RK3IDPSolver::b[] = {1. / 4., 0., 3. / 4.};
 const real_t RK3IDPSolver::c[] = {1. / 3., 2. / 3.};
 
 // ---- RK3 SSP [MFEM RK3SSPSolver::Step] -------------------------------------------------------------
