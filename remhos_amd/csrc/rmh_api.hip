@@ -629,6 +629,7 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    RMH_ENTER(c);
    extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
+   if (c->ng > 0 && c->gh_foreign) { return fail(RMH_ERR_STATE, "the ghost extrema hold another field's values (rmh_exchange_minmax_*): exchange u first"); }
    LimitArgs la;
    la.u = u;
    la.du_ho = du_ho;
@@ -687,10 +688,17 @@ int rmh_stage_fused_chain(rmh_ctx *c, const double *u, double dt, const double *
    }
    if (c->lo_type == 3 && c->p < 2) { return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 3 needs order >= 2"); }
    if (c->ng > 0 && (!c->u_ghost || !c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost data not set"); }
+   if (c->ng > 0 && c->gh_foreign) { return fail(RMH_ERR_STATE, "the ghost extrema hold another field's values (rmh_exchange_minmax_*): exchange u first"); }
    int rc = 0;
    // Element extrema of the stage input.  They are at hand only if the caller PRESENTS the token the stage that wrote u
    // returned -- its statement that u is that stage's untouched output.  Anything else (no token, a stale one, a vector
    // that was modified since) costs one streaming pass.  The ranges of one stage share the extrema of its first call.
+   if (c->stage_open && (u != c->stage_u || dt != c->stage_dt))
+   {
+      // the ranges of one stage must name the same input and step: the extrema at hand are those of the first call's u
+      c->stage_open = false;
+      return fail(RMH_ERR_STATE, "rmh_stage_fused_range: the ranges of one stage must pass the same u and dt (stage abandoned)");
+   }
    if (!c->stage_open)
    {
       if (in_token == 0 || in_token != c->xe_token)
@@ -699,16 +707,21 @@ int rmh_stage_fused_chain(rmh_ctx *c, const double *u, double dt, const double *
          if (rc) { return rc; }
       }
       c->stage_open = true;
+      c->stage_u = u;
+      c->stage_dt = dt;
    }
    c->xe_token = 0; // (until this stage is finished, no token is valid)
    if (e_end > e_begin)
    {
       EventPair ep;
       rc = timer_begin(c, 0, ep);
-      if (rc) { return rc; }
-      RMH_DISPATCH(c, rc = launch_stage_fused<P>(c, u, dt, x_base, a, b, dt_rk, y_out, du, e_begin, e_end));
-      if (rc) { return rc; }
-      rc = timer_end(c, 0, ep);
+      if (!rc) { RMH_DISPATCH(c, rc = launch_stage_fused<P>(c, u, dt, x_base, a, b, dt_rk, y_out, du, e_begin, e_end)); }
+      if (!rc) { rc = timer_end(c, 0, ep); }
+      if (rc)
+      {
+         c->stage_open = false; // a failed stage leaves no extrema behind: the next one recomputes them
+         return rc;
+      }
    }
    if (finish)
    {

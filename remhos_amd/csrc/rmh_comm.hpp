@@ -606,6 +606,7 @@ int rmh_exchange_end(rmh_ctx *c)
       RMH_HIP(hipStreamWaitEvent(c->stream, x->ev_done, 0));
    }
    x->gen_end++;
+   c->gh_foreign = false; // the ghost extrema are again those of the vector rmh_exchange_begin packed
    return RMH_OK;
 }
 
@@ -693,6 +694,9 @@ int rmh_exchange_minmax_end(rmh_ctx *c)
    RMH_HIP(hipEventRecord(x->ev_done, x->xs));
    RMH_HIP(hipStreamWaitEvent(c->stream, x->ev_done, 0));
    x->mm_end++;
+   // the ghost extrema now belong to the caller's field (the ratio s of product remap), not to the vector whose traces the
+   // ghosts hold: the limiters of that vector refuse them until the next rmh_exchange_begin / _end refreshes them
+   c->gh_foreign = true;
    return RMH_OK;
 }
 

@@ -51,8 +51,11 @@ struct rmh_ctx
    // stage returned that token, and only a caller that presents it gets them reused (rmh_stage_fused_chain)
    unsigned long long xe_token = 0, xe_counter = 0;
    bool stage_open = false; // between the first range call of a stage and its finishing call
+   const double *stage_u = nullptr; // input vector and step of the open stage (its ranges must agree)
+   double stage_dt = 0.0;
    int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
    const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
+   bool gh_foreign = false; // ghost extrema overwritten by rmh_exchange_minmax_* (another field's) since the last exchange of u
    int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)
    int gh_compact = 0; // 1: ghost records are [min | max | D^2 face trace] cells (rmh_exchange_setup, compact)
    double rel_tol = 1e-14, abs_tol = 0.0;

@@ -28,6 +28,15 @@ __device__ unsigned long long g_stamps[RMH_STAMP_MAXWG][32];
       __syncthreads();                                                                 \
       if (threadIdx.x < 32 && blockIdx.x < RMH_STAMP_MAXWG) { g_stamps[blockIdx.x][threadIdx.x] += s_stamp[threadIdx.x]; } \
    } while (0)
+#elif defined(RMH_STOP_AT)
+// diagnostic build only (tools/pmc_variants.sh): the kernel ends at phase mark RMH_STOP_AT, so that counters can be
+// attributed to phases by differences between builds.  The test on a kernel argument (always true) keeps the compiler
+// from discarding the work in front of the mark; the outputs are garbage.
+#define RMH_STAMP(k)                                                  \
+   do {                                                               \
+      if ((k) == RMH_STOP_AT && a.max_iter != -12345) { return; }     \
+   } while (0)
+#define RMH_STAMP_FLUSH()
 #elif defined(RMH_PHASE_MARKS)
 // diagnostic compile to assembly only (tools/isa_phases.py): a comment per phase boundary in the .s file
 #define RMH_STAMP(k) asm volatile("; RMH_PHASE " #k)

@@ -723,8 +723,9 @@ extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, i
          ti_total++;
          if (dtc)
          {
-            // remhos.cpp:1178-1197
-            const double dt_ratio = adv.GetTimeStepRatio();
+            // remhos.cpp:1178-1197; the estimate is the minimum over the ranks of a partition (MPI_Allreduce(MIN),
+            // remhos.cpp:1993): every rank takes the same accept / repeat decision, hence issues the same exchanges
+            const double dt_ratio = reduce(adv.GetTimeStepRatio(), 1);
             if (dt_ratio < 1.)
             {
                // Repeat with the proper time step.

@@ -125,15 +125,20 @@ struct K2Cfg : TabLayout<P>
 #ifndef RMH_NB3
 #define RMH_NB3 (NT / Q2)
 #endif
-   static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : (P == 3 ? RMH_NB3 : NT / Q2)));
+   // p = 2: 9 elements, not the 10 whose columns fit -- their 243 dofs take ONE round of the dof role where 270 take two
+   // (-rs 5: 9.3 k -> 11.2 k MDOFs*stage/s, bit-identical)
+#ifndef RMH_NB2
+#define RMH_NB2 (NT / Q2 < NT / D3 ? NT / Q2 : NT / D3)
+#endif
+   static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : (P == 3 ? RMH_NB3 : (P == 2 ? RMH_NB2 : NT / Q2))));
    // HO + RD in one kernel carries more LDS per element: one element less.  p = 3, -rs 5, MDOFs*stage/s by
    // elements per workgroup and workgroups per CU (round 1, before / after the LDS diet of the RD extras):
    // 7 @ 1: 4.1 k; 6 @ 2: 6.5 k; 5 @ 2: 5.8 k; 4 @ 3: 7.4 k; 5 @ 3: 7.7 k; 6 @ 3: 8.6 k -- occupancy first, then
    // lane utilisation of the column phases (NB x 36 of 256 lanes).
 #ifndef RMH_BOTH_DROP
-#define RMH_BOTH_DROP 1
+#define RMH_BOTH_DROP 0
 #endif
-   static constexpr int NB = (LO4 && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0; // (the RD-only kernel carries the same extras)
+   static constexpr int NB = (LO4 && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0;
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
@@ -141,35 +146,51 @@ struct K2Cfg : TabLayout<P>
    //   phases C-G : [R3 3 Q2 D | R2 3 Q D2]
    //   PCG, J     : [sA D3 | M1 / R2' Q S2 | R3' Q2 D | sB D3]
    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-   static constexpr int S2 = D2 + 1; // padded row stride of U1 / M1 (bank conflicts)
-   static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
+#ifndef RMH_S2PAD
+#define RMH_S2PAD 1
+#endif
+#ifndef RMH_TRACE_PAD
+#define RMH_TRACE_PAD 0
+#endif
+#ifndef RMH_EL_MOD
+#define RMH_EL_MOD 2
+#endif
+   static constexpr int S2 = D2 + RMH_S2PAD; // padded row stride of U1 / M1 (bank conflicts)
+   static constexpr int FS = D2 + RMH_TRACE_PAD; // stride of the six faces' traces
+   static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * FS, PA = oU1 + 2 * Q * S2;
+   // slot of trace value r6 = f * D2 + r in the trace buffer
+   __host__ __device__ static constexpr int trace_slot(int r6) { return FS == D2 ? r6 : (r6 / D2) * FS + r6 % D2; }
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
    // volume rhs by the 1-D change of test basis Cf along y and z (phi^B_i = sum_k C[k][i] l_k; the x-leg of phase G
    // tests with both bases), not by a fourth tensor through phases C-G.
    static constexpr int NR = 3;
    // INPLACE_Y: the y-leg writes its D outputs over the first D of the Q inputs of its own line (R2 inside R3)
-   static constexpr bool INPLACE_Y = RMH_INPLACE_Y;
+   static constexpr bool INPLACE_Y = RMH_INPLACE_Y || LO4;
    static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * Q2 * D, PF = INPLACE_Y ? NR * Q2 * D : oR2 + NR * Q * D2;
    static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
-   // lo 4 (subcell residual distribution) extras: sub-mesh node positions behind the phase A-C data,
-   // subcell data [3][NS] and the lumped face flux per dof behind the face buffer
+   // lo 4 (subcell residual distribution) extras behind the work region: the face rows -- GL-tested for the HO part, and
+   // Bernstein-tested s rows for the RD solver (a second set when HO and RD share the kernel) -- whose slots hold the
+   // sub-mesh node positions until the subcell pass has consumed them (it runs in front of the face rows); then the
+   // subcell data [3][NS].  The lumped face flux per dof is written after the column pass (nodes, u, traces and U1 are dead
+   // by then) behind the in-place test tensors, and read by the RD part in front of the PCG.
    static constexpr int NS = P * P * P;
-   static constexpr int oXs = PA;
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
-   // the sub-mesh nodes are consumed by the subcell pass before the face rows are formed: the
-   // Bernstein-tested s rows of the RD solver take their place when HO and RD share the kernel
+   static constexpr int XT = LO4 ? cmax(RF * (BOTH ? 2 : 1), 3 * D3) : RF;
    // (+108: stencil and box table of the fused limiter, see phase J; +2: the element's sum of the right-hand side and
    // its volume, kept from the PCG prelude to the constant-mode completion, see batch_dot_keep2)
    static constexpr int oKeep = PCG + 108;
-   static constexpr int W = cmax(PA + (LO4 ? cmax(3 * D3, BOTH ? RF : 0) : 0), cmax(PF, oKeep + 2));
+   // (behind the traces, which the lumped fluxes read while they write it, and behind everything the RD part uses)
+   static constexpr int oDuf = cmax(cmax(PF, PCG), oU1);
+   static constexpr int W = cmax(PA, cmax(LO4 ? oDuf + D3 : PF, oKeep + 2));
    static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
-   static constexpr int oF2 = BOTH ? oXs : oF;        // s rows (Bernstein basis) of the RD solver
-   static constexpr int oSub = oF + RF, oDuf = oSub + 3 * NS;
+   static constexpr int oF2 = BOTH ? oF + RF : oF;    // s rows (Bernstein basis) of the RD solver
+   static constexpr int oXs = oF;                     // sub-mesh nodes [3][D3], phases A-B
+   static constexpr int oSub = oF + XT;
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
-   static constexpr int EL0 = W + RF + (LO4 ? 3 * NS + D3 : 0);
-   static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
+   static constexpr int EL0 = W + XT + (LO4 ? 3 * NS : 0);
+   static constexpr int EL = EL0 + ((RMH_EL_MOD - EL0 % 32) + 32) % 32;
    // partial sums of the generic reductions: chunks of 64 dofs (one wavefront each), 8 chunks for small elements
    static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
    static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
@@ -287,6 +308,33 @@ __device__ inline double wave_minmax(double v)
    v = dpp_minmax<0x143, 0xC, IS_MIN>(v);
    return v;
 }
+
+// the value of lane L of the wavefront in all its lanes (on the device: two v_readlane_b32 into a scalar register pair)
+template <int L>
+__device__ inline double wave_bcast(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+#else
+   return __shfl(v, L);
+#endif
+}
+
+// Element sums where a wavefront holds whole elements in its dof rounds (p = 3: 64 dofs): the totals of the DPP reduction
+// go from their lane straight to all lanes of the wavefront -- the lanes that want them -- instead of through LDS and a
+// workgroup barrier (same sums, same order)
+#ifndef RMH_WAVE_DOT
+#define RMH_WAVE_DOT 1
+#endif
+#ifndef RMH_WD_A
+#define RMH_WD_A 1
+#endif
+#ifndef RMH_WD_B
+#define RMH_WD_B 1
+#endif
+#ifndef RMH_WD_C
+#define RMH_WD_C 1
+#endif
 
 // sum over the 64 lanes of a wavefront in a fixed order; valid in lane 63
 __device__ inline double wave_sum(double v)
@@ -447,6 +495,12 @@ __device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double
       x = dpp_add_all<0x141>(x); // row_half_mirror
       x = dpp_add_all<0x140>(x); // row_mirror: every lane of a row holds the row total
       x = dpp_add<0x142, 0xA>(x); // row_bcast:15 into rows 1 and 3: half-wave totals
+      if (RMH_WAVE_DOT && RMH_WD_A)
+      {
+         out[0] = wave_bcast<31>(x);
+         out[C::DR == 2 ? 1 : 0] = wave_bcast<63>(x);
+         return;
+      }
       if (lane == 31) { cur[wave] = x; }
       if (lane == 63 && (C::NT / C::D3 + wave) < C::NB) { cur[C::NT / C::D3 + wave] = x; }
    }
@@ -572,6 +626,14 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
       x = dpp_add_all<0x4E>(x);
       x = dpp_add_all<0x141>(x);
       x = dpp_add_all<0x140>(x);
+      if (RMH_WAVE_DOT && RMH_WD_B)
+      {
+         outv[0] = wave_bcast<15>(x);
+         outw[0] = wave_bcast<31>(x);
+         outv[C::DR == 2 ? 1 : 0] = wave_bcast<47>(x);
+         outw[C::DR == 2 ? 1 : 0] = wave_bcast<63>(x);
+         return;
+      }
       const int e1 = C::NT / C::D3 + wave;
       if (lane == 15) { curv[wave] = x; }
       if (lane == 31) { curw[wave] = x; }
@@ -657,6 +719,17 @@ __device__ inline void batch_dot_keep2(const int tid, const double (&v)[C::DR], 
       y = dpp_add_all<0x140>(y);
       x = dpp_add<0x142, 0xA>(x);
       const int e1 = C::NT / C::D3 + wave;
+      if (RMH_WAVE_DOT && RMH_WD_C)
+      {
+         // (the kept sums are read by the dof threads of their element -- this wavefront -- behind later barriers)
+         if (lane == 15) { (lds + wave * C::EL)[C::oKeep] = y; }
+         if (lane == 31) { (lds + wave * C::EL)[C::oKeep + 1] = y; }
+         if (lane == 47 && e1 < C::NB) { (lds + e1 * C::EL)[C::oKeep] = y; }
+         if (lane == 63 && e1 < C::NB) { (lds + e1 * C::EL)[C::oKeep + 1] = y; }
+         outv[0] = wave_bcast<31>(x);
+         outv[C::DR == 2 ? 1 : 0] = wave_bcast<63>(x);
+         return;
+      }
       if (lane == 31) { cur[wave] = x; }
       if (lane == 63 && e1 < C::NB) { cur[e1] = x; }
       if (lane == 15) { (lds + wave * C::EL)[C::oKeep] = y; }
@@ -1015,6 +1088,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    (void)gt;
    if (blk != blk0) { __syncthreads(); } // the previous batch's last LDS reads precede this batch's stores
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
+   // ("any element still active" flags of the PCG loop: cleared here, in front of the first barrier -- the wavefronts reach
+   // the prelude of the mass solve, where the first flag is raised, without a common barrier in between when their element
+   // sums stay in the wavefront, RMH_WAVE_DOT)
+   if (tid < 4) { s_flag[tid] = 0; }
    // all global loads are issued before the first LDS store so that they are in flight together
    // (neighbour indices first: the trace loads depend on them)
    if (!prefetched) { load_batch<C, FUSED>(a, true, e0, tid, nbi, sti, gx0, gv, gu); }
@@ -1116,7 +1193,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    for (int j = 0; j < NLN; j++)
    {
       const int k = tid + j * NT;
-      if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j]; }
+      if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + C::trace_slot(k % (6 * D2))] = gn[j]; }
    }
 #endif
 #pragma unroll
@@ -1319,7 +1396,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
             own = RMH_W(k / (6 * D2))[oU + (side ? P * strc : 0) + (r % D) * str1 + (r / D) * str2];
          }
-         RMH_W(k / (6 * D2))[oNb + k % (6 * D2)] = gn[j] - own;
+         RMH_W(k / (6 * D2))[oNb + C::trace_slot(k % (6 * D2))] = gn[j] - own;
       }
    }
    __syncthreads();
@@ -1374,7 +1451,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       // traces: contraction of (u_nbr - u_own) along i1
       const int dc = axis_stride<D>(c), d1 = axis_stride<D>(c1), d2 = axis_stride<D>(c2);
       const double *uo = RMH_W(eb) + oU + (side ? P * dc : 0);
-      const double *un = RMH_W(eb) + oNb + f * D2;
+      const double *un = RMH_W(eb) + oNb + f * C::FS;
       double jr[D];
 #pragma unroll
       for (int i2 = 0; i2 < D; i2++)
@@ -1451,8 +1528,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // (the column phase reads the nodes and U1, both complete since the barrier above; the face rows' output is read
    // after the next barrier -- only the lumped face fluxes of the RD scheme need it here.  Split columns, p = 6: there the
    // face rows run on the second wavefront BESIDE the first one's column pass, so the lumped fluxes wait until both are done)
-   constexpr bool LUMP_LATE = LO4 && CSPL && RMH_LUMP_LATE;
-   if (LO4 && !LUMP_LATE) { __syncthreads(); }
+   constexpr bool LUMP_LATE = LO4;
 #else
    constexpr bool LUMP_LATE = false;
    __syncthreads();
@@ -1480,7 +1556,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                double coef = 0.0;
 #pragma unroll
                for (int q1 = 0; q1 < Q; q1++) { coef += stab[oB + q1 * D + i1] * F[q1 * D]; }
-               acc += coef * (TJ ? RMH_W(eb)[oNb + f * D2 + i1 + D * i2] : RMH_W(eb)[oNb + f * D2 + i1 + D * i2] - ui);
+               acc += coef * (TJ ? RMH_W(eb)[oNb + f * C::FS + i1 + D * i2] : RMH_W(eb)[oNb + f * C::FS + i1 + D * i2] - ui);
             }
          }
          RMH_W(eb)[C::oDuf + i] = acc;
@@ -1909,6 +1985,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       const double eps = 1.E-15, gamma = 1.0;
       double t0[DR], t1[DR], t2[DR], xSum[DR], rhoP[DR], rhoN[DR];
       int ring4 = 0;
+      constexpr bool WD = RMH_WAVE_DOT && C::WAVE_ALIGNED && DR == 2; // element sums stay in the wavefront (see wave_bcast)
       __syncthreads(); // R2 has been consumed: the front of W is free
       if (BOTH)
       {
@@ -1976,7 +2053,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
-         if (t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = uu4[r]; }
+         if (!WD && t < NB * D3) { RMH_W(t / D3)[oSA + t % D3] = uu4[r]; }
          t0[r] = uu4[r];
          t1[r] = fmax(0., zb[r]);
          t2[r] = fmin(0., zb[r]);
@@ -1986,7 +2063,55 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       batch_dot2<C>(tid, t1, t2, rhoP, rhoN, lds, s_acc, ring4);
       RMH_STAMP(29);
       // element extrema (el[0..1]) and the sums of the subcell fluctuations (8 partial sums each, el[2..17])
-      if (C::WAVE_ALIGNED)
+      double elo[DR], ehi[DR], sfP[DR], sfN[DR];
+#pragma unroll
+      for (int r = 0; r < DR; r++) { elo[r] = 0; ehi[r] = 0; sfP[r] = 0; sfN[r] = 0; }
+      if (WD)
+      {
+         // p = 3: a wavefront holds the whole element in each of its dof rounds -- the sums of the subcell fluctuations are
+         // formed in the dof role (dof i < NS reads subcell i) like the other element sums, and the extrema with one packed
+         // reduction (see the extrema of the new state in phase K); everything stays in the wavefront: no LDS, no barrier
+         double fp[DR], fn[DR];
+#pragma unroll
+         for (int r = 0; r < DR; r++)
+         {
+            const int t = tid + r * NT;
+            const double f = (t < NB * D3 && t % D3 < NS) ? (RMH_W(t / D3) + C::oSub)[t % D3] : 0.0;
+            fp[r] = fmax(0., f);
+            fn[r] = fmin(0., f);
+         }
+         batch_dot2<C>(tid, fp, fn, sfP, sfN, lds, s_acc, ring4);
+         const bool has1 = tid + NT < NB * D3;
+         double y0 = uu4[0], y1 = has1 ? uu4[DR == 2 ? 1 : 0] : INFINITY;
+         double z0 = -uu4[0], z1 = has1 ? -uu4[DR == 2 ? 1 : 0] : INFINITY;
+         swap32(y0, y1);
+         swap32(z0, z1);
+         double mn = fmin(y0, y1), nx = fmin(z0, z1);
+         swap16(mn, nx);
+         double x = fmin(mn, nx); // rows: {min round 0, -max round 0, min round 1, -max round 1}
+         x = dpp_minmax<0xB1, 0xF, true>(x);
+         x = dpp_minmax<0x4E, 0xF, true>(x);
+         x = dpp_minmax<0x141, 0xF, true>(x);
+         x = dpp_minmax<0x140, 0xF, true>(x);
+         elo[0] = wave_bcast<15>(x);
+         ehi[0] = -wave_bcast<31>(x);
+         elo[DR == 2 ? 1 : 0] = wave_bcast<47>(x);
+         ehi[DR == 2 ? 1 : 0] = -wave_bcast<63>(x);
+         if (!BOTH)
+         {
+#pragma unroll
+            for (int r = 0; r < DR; r++)
+            {
+               const int t = tid + r * NT;
+               if ((tid & 63) == 0 && t < NB * D3 && e0 + t / D3 < a.e_end)
+               {
+                  a.xe_min[e0 + t / D3] = elo[r];
+                  a.xe_max[e0 + t / D3] = ehi[r];
+               }
+            }
+         }
+      }
+      else if (C::WAVE_ALIGNED)
       {
 #pragma unroll
          for (int r = 0; r < DR; r++)
@@ -2055,7 +2180,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             a.xe_max[e0 + tid] = hi;
          }
       }
-      if (NB != 1 || C::WAVE_ALIGNED)
+      if (!WD && (NB != 1 || C::WAVE_ALIGNED))
       {
          constexpr int CH = 8, CL = (NS + CH - 1) / CH;
          for (int k = tid; k < NB * CH; k += NT)
@@ -2073,7 +2198,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             el[10 + k % CH] = sn;
          }
       }
-      __syncthreads();
+      if (!WD) { __syncthreads(); }
       RMH_STAMP(30);
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -2084,9 +2209,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int eb = t / D3, i = t % D3;
             const int ix = i % D, iy = (i / D) % D, iz = i / D2;
             const double *el = RMH_W(eb) + oM1, *fl = RMH_W(eb) + C::oSub;
-            double xe_min = el[0], xe_max = el[1];
-            double sumFluctP = 0.0, sumFluctN = 0.0;
-            if (NB == 1 && !C::WAVE_ALIGNED)
+            double xe_min = WD ? elo[r] : el[0], xe_max = WD ? ehi[r] : el[1];
+            double sumFluctP = sfP[r], sumFluctN = sfN[r];
+            if (WD) {}
+            else if (NB == 1 && !C::WAVE_ALIGNED)
             {
                sumFluctP = el[2];
                sumFluctN = el[3];
@@ -2208,7 +2334,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    double xg[DR], dd[DR], nom[DR], tol[DR], tmp[DR], red[DR];
    int its[DR];
    int ring = 0;
-   if (tid < 4) { s_flag[tid] = 0; }
 #pragma unroll
    for (int r = 0; r < DR; r++)
    {
