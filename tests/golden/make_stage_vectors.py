@@ -4,7 +4,7 @@ small meshes, computed by the CPU oracle (oracle/remhos_oracle.py, itself pinned
 tests/golden/reference_kat.json).  The reference holds no per-stage vectors ("parity unpinned at stage
 granularity"), so these are the committed fixtures the GPU parity tests and the CPU port are checked against.
 
-    python tests/golden/make_stage_vectors.py        # rewrites the .npz files (deterministic: no RNG)
+    python tests/golden/make_stage_vectors.py [name ...]     # rewrites the .npz files (deterministic: no RNG)
 
 Stored per case: the C-ABI layout (x0, vel [ne][3][27], face_nbr [ne][6], stencil27 [ne][27], subcell_vel), the
 stage input u, t, dt and the oracle's du_ho, du_lo, umin, umax, du, lumped mass m.
@@ -31,12 +31,20 @@ CASES = [
     # the -pa rule of the local mass solve: DGMassInverse's abs 1e-8 (remhos_ho.cpp:79-80) + the product's completion steps
     # (oracle: ho_solve = "pa"); the fixture carries mass_solve = "pa" and the oracle's PCG iteration count
     ("remap_p3_lo5_pa", "cube01_hex", 1, 3, 10, 5, 0, 0.5),
+    # the high orders of BASELINE configs[2] (round 4)
+    ("remap_p5_lo5", "cube01_hex", 0, 5, 10, 5, 0, 0.4),
+    ("remap_p6_lo5", "periodic-cube", 0, 6, 10, 5, 0, 0.5),
+    ("remap_p6_lo4", "cube01_hex", 0, 6, 10, 4, 0, 0.3),
+    ("remap_p6_lo5_pa", "periodic-cube", 0, 6, 10, 5, 0, 0.5),
 ]
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])  # (names given: write only those files -- the others stay byte for byte what is committed)
     for name, mesh, rs, p, prob, lo, bt, t in CASES:
+        if only and name not in only:
+            continue
         pa = name.endswith("_pa")
         cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=lo, bounds_type=bt, ho_solve="pa" if pa else "exact")
         r = Remhos(cfg)

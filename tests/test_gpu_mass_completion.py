@@ -102,7 +102,7 @@ def test_pa_rule_run_against_converged_run(lib, mesh, rs, p, steps):
 
 
 @pytest.mark.parametrize("mesh,rs,p,t", [("cube01_hex", 1, 2, 0.4), ("cube01_hex", 2, 3, 0.6), ("periodic-cube", 1, 3, 0.3),
-                                         ("cube01_hex", 1, 4, 0.5), ("periodic-cube", 0, 6, 0.5)])
+                                         ("cube01_hex", 1, 4, 0.5), ("cube01_hex", 0, 5, 0.4), ("periodic-cube", 0, 6, 0.5)])
 def test_pa_rule_is_dgmassinverse_rule(lib, mesh, rs, p, t):
     """The -pa rule against the oracle's restatement of the SAME algorithm (Remhos.mass_cg: Jacobi-PCG in the GL basis stopped
     at (D^-1 r, r) <= (1e-8)^2 like DGMassInverse, remhos_ho.cpp:79-80, + the two completion steps): the same number of
@@ -132,5 +132,5 @@ def test_pa_rule_is_dgmassinverse_rule(lib, mesh, rs, p, t):
     err = float(np.abs(du.cpu().numpy() - ref).max() / np.abs(ref).max())
     print(mesh, rs, p, "iterations GPU / oracle", it, r.cg_iters, "rel err", err)
     assert it == r.cg_iters and 0 < it < 20
-    assert err < {2: 1e-12, 3: 2e-10, 4: 5e-10, 6: 1e-7}[p]
+    assert err < {2: 1e-12, 3: 2e-10, 4: 5e-10, 5: 5e-9, 6: 1e-7}[p]
     ctx.close()
