@@ -185,6 +185,9 @@ int rmh_exchange_peer(rmh_ctx *ctx, int peer_index, int *rank, long long *send_o
  * :1934 stopwatch maxima, :1993 dt estimate): vals[n] HOST doubles, in place; op 0 = sum, 1 = min, 2 = max.
  * Synchronises.  Not on the hot path. */
 int rmh_allreduce(rmh_ctx *ctx, double *vals, int n, int op);
+/* Number of ranks of the context's RCCL communicator as the communicator itself reports it (ncclCommCount; MPI_Comm_size
+ * of the reference's pmesh.GetComm(), remhos.cpp:459-463); 0 without one. */
+int rmh_comm_count(rmh_ctx *ctx, int *nranks);
 
 /* HOSolver::CalcHOSolution (remhos_ho.hpp:38, LocalInverseHOSolver remhos_ho.cpp:84-129):
  * du = M^-1 (K_vol + K_face) u with an element-local, tightly converged mass solve.

@@ -98,7 +98,7 @@ typedef struct {
    int timed_stages;                          /* stages inside the stopwatches / the wall clock (all but the warm-up) */
    int n_peers;                               /* neighbour ranks of this rank's block                                  */
    int transport;                             /* 0 none, 1 RCCL send/recv, 2 same-process device copies               */
-   int pad_;
+   int comm_ranks;                            /* ranks of the RCCL communicator as it reports them (ncclCommCount); 0: none */
    long long send_bytes_per_stage, recv_bytes_per_stage; /* this rank's halo records per RK stage                     */
    /* -ps (remhos.cpp:1404, 1416-1434): */
    double final_mass_us, mass0_us, mass_loss_us, s_max;

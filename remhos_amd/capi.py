@@ -21,7 +21,7 @@ SYMBOLS = [
     "rmh_last_cg_iters", "rmh_set_mass_tol", "rmh_get_mass_tol", "rmh_set_mass_completion", "rmh_set_lo_type", "rmh_set_bounds_type", "rmh_set_dt_control",
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
     "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
-    "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_minmax_begin", "rmh_exchange_minmax_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce",
+    "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_minmax_begin", "rmh_exchange_minmax_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce", "rmh_comm_count",
     "rmh_build_tables", "rmh_product_ratio", "rmh_elem_minmax_masked", "rmh_fct_product",
 ]
 

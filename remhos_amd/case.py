@@ -46,7 +46,7 @@ class RmhdResult(C.Structure):
         ("t_rhs", C.c_double), ("t_inv", C.c_double), ("t_lo", C.c_double), ("t_fct", C.c_double), ("t_total", C.c_double),
         ("fom_rhs", C.c_double), ("fom_inv", C.c_double), ("fom_lo", C.c_double), ("fom_fct", C.c_double), ("fom", C.c_double),
         ("wall", C.c_double), ("fom_wall", C.c_double), ("cg_iters_max", C.c_int), ("repeats", C.c_int),
-        ("timed_stages", C.c_int), ("n_peers", C.c_int), ("transport", C.c_int), ("pad_", C.c_int),
+        ("timed_stages", C.c_int), ("n_peers", C.c_int), ("transport", C.c_int), ("comm_ranks", C.c_int),
         ("send_bytes_per_stage", C.c_longlong), ("recv_bytes_per_stage", C.c_longlong),
         ("final_mass_us", C.c_double), ("mass0_us", C.c_double), ("mass_loss_us", C.c_double), ("s_max", C.c_double),
         ("has_errors", C.c_int), ("pad2_", C.c_int), ("err_l1", C.c_double), ("err_l2", C.c_double), ("err_linf", C.c_double),

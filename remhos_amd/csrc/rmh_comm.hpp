@@ -31,6 +31,7 @@ struct Rccl
    int (*GetUniqueId)(UniqueId *) = nullptr;
    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
    int (*CommDestroy)(Comm) = nullptr;
+   int (*CommCount)(Comm, int *) = nullptr;
    int (*GroupStart)() = nullptr;
    int (*GroupEnd)() = nullptr;
    int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -60,6 +61,7 @@ static Rccl &rccl()
    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+   r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
    r.Send = (decltype(r.Send))sym("ncclSend");
@@ -720,6 +722,16 @@ int rmh_exchange_peer(rmh_ctx *c, int k, int *rank, long long *send_offset, long
    if (send_doubles) { *send_doubles = p.send_n; }
    if (recv_offset) { *recv_offset = p.recv_off; }
    if (recv_doubles) { *recv_doubles = p.recv_n; }
+   return RMH_OK;
+}
+
+int rmh_comm_count(rmh_ctx *c, int *nranks)
+{
+   if (!c || !nranks) { return fail(RMH_ERR_INVALID, "null argument"); }
+   *nranks = 0;
+   Exchange *x = c->xch;
+   if (!x || !x->comm) { return RMH_OK; } // no communicator: 0 ranks
+   RMH_NCCL(rccl().CommCount(x->comm, nranks));
    return RMH_OK;
 }
 

@@ -1181,6 +1181,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    res->timed_stages = 3 * (ti_total - timed_from);
    res->n_peers = (int)blocks[0].cd.peers.size();
    res->transport = rccl ? 1 : (nranks > 1 ? 2 : 0);
+   if (rccl) { (void)rmh_comm_count(blocks[0].ctx, &res->comm_ranks); }
    {
       long long sd = 0, gd = 0;
       if (res->n_peers > 0) { (void)rmh_exchange_buffers(blocks[0].ctx, nullptr, &sd, nullptr, &gd); }
