@@ -235,14 +235,13 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.bounds_type = c->bounds_type;
    a.dt_est = c->dt_control ? c->d_dt_est : nullptr;
    a.rd_subcell = c->lo_type == 3 ? 0 : 1;
-   // persistent workgroups: as many as the chip holds at once (CUs x workgroups per CU); each works through the
-   // element batches blockIdx.x, blockIdx.x + gridDim.x, ... and prefetches its next batch (ho_kernel2)
+   // one workgroup per batch of NB elements (the kernel maps blockIdx.x to a batch XCD-aware)
    if (c->lo_type == 4 || c->lo_type == 3)
    {
       constexpr int P4 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the caller)
       using C = K2Cfg<P4, true, true>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
-      const int grid = c->persist > 0 ? std::min(nblk, c->n_cu * C::WG_PER_CU * c->persist) : nblk;
+      const int grid = nblk;
       if (FaceGeo<P4>::used(3))
       {
          if (int rc = ensure_face_table<P4>(c)) { return rc; }
@@ -254,7 +253,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    {
       using C = K2Cfg<P>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
-      const int grid = c->persist > 0 ? std::min(nblk, c->n_cu * C::WG_PER_CU * c->persist) : nblk;
+      const int grid = nblk;
       if (FaceGeo<P>::used(1))
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
@@ -382,13 +381,6 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->device = L->device;
    c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
    c->gh_ustride = c->ndof;
-#if RMH_PERSIST_LOOP
-   if (const char *v = std::getenv("RMH_PERSIST")) { c->persist = std::max(0, std::atoi(v)); } // (tuning aid)
-   {
-      int n = 0;
-      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, L->device) == hipSuccess && n > 0) { c->n_cu = n; }
-   }
-#endif
    // every failure past this point releases the context and whatever it already owns
    const int rc = create_device_state(c, L);
    if (rc) { rmh_destroy(c); return rc; }

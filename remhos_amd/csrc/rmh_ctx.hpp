@@ -7,9 +7,6 @@
 #include <string>
 #include <vector>
 
-#ifndef RMH_PERSIST_LOOP
-#define RMH_PERSIST_LOOP 0
-#endif
 
 namespace rmh
 {
@@ -66,8 +63,6 @@ struct rmh_ctx
    double *d_dt_est = nullptr; // running minimum of UpdateTimeStepEstimate; null while dt control is off
    bool dt_control = false;
    int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
-   int n_cu = 256;     // compute units of the device
-   int persist = RMH_PERSIST_LOOP; // fused stage: workgroups per CU slot (0: one workgroup per element batch)
    // stopwatches (TimingData, remhos_tools.hpp:52-64)
    bool timers_on = false;
    double tacc[4] = {0, 0, 0, 0};

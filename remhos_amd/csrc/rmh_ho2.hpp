@@ -27,66 +27,31 @@
 namespace rmh
 {
 
-// Persistent workgroups with register prefetch of the next batch (see ho_kernel2): built and measured in round 2 --
-// the back edge costs the column phase its last registers (60-170 B/lane of scratch at p = 3, 4) and the kernel ran
-// 20-40 % slower; kept as a compile-time option (the launch side sizes the grid accordingly).
-// lo 4 stage: the RD solver's z = K_vol u needs the Bernstein test basis; its x-direction comes out of the x-leg of phase G
-// as a second accumulator (one conversion leg less) -- not at p = 3, where that accumulator is the register that spills
-// adj(J) v through two cross products in the column phase: a small measured gain at p = 3 only; the XCD-aware batch map:
-// every order (re-measured at the end of round 3: p = 4 +1.8 %, p = 6 +0.5 %, p = 5 -0.4 %; earlier, with p = 6 bound by its scalar
-// instructions, it had measured -2 % there)
+// The compile-time switches that remain are the ones whose value differs per order or per kernel, each with its measured
+// effect; variants that were built, measured and rejected (persistent workgroups with register prefetch, wave priorities,
+// traces stored as values, per-dof back-transform and x-leg, whole second wavefront for the 17 extra columns of p = 6, ...)
+// are kept as patches with their numbers under tools/experiments/, not as dead branches of the product kernel.
+//
+// adj(J) v and det J through two cross products in the column phase: a small measured gain at p = 3 only (at p = 6 the
+// different register lifetimes cost 8 %)
 #ifndef RMH_ADJ_CROSS
 #define RMH_ADJ_CROSS (P == 3)
 #endif
+// fresh views of the constant table per unrolled quadrature plane from this order on (see tab_view)
 #ifndef RMH_VIEW_MINP
 #define RMH_VIEW_MINP 4
 #endif
-#ifndef RMH_PENCIL_BACK
-#define RMH_PENCIL_BACK 1
-#endif
-#ifndef RMH_PENCIL_XLEG
-#define RMH_PENCIL_XLEG 1
-#endif
-#ifndef RMH_PENCIL_BACK_NB
-#define RMH_PENCIL_BACK_NB 1
-#endif
-#ifndef RMH_LUMP_LATE
-#define RMH_LUMP_LATE 1
-#endif
-#ifndef RMH_TRACE_JUMP
-#define RMH_TRACE_JUMP 1
-#endif
-#ifndef RMH_XCD_MAP
-#define RMH_XCD_MAP 1
-#endif
-#ifndef RMH_COLSPLIT
-#define RMH_COLSPLIT 1
-#endif
+// lo 4 stage: the RD solver's z = K_vol u needs the Bernstein test basis; its x-direction comes out of the x-leg of phase G
+// as a second accumulator (one conversion leg less) -- not at p = 3, where that accumulator is the register that spills
 #ifndef RMH_RD_XLEG
 #define RMH_RD_XLEG (P >= 4)
 #endif
-#ifndef RMH_PERSIST_LOOP
-#define RMH_PERSIST_LOOP 0
-#endif
-
 // y-leg of the test contractions in place: less LDS per workgroup, more workgroups per CU (p = 6: 30 -> 21 KB, the sixth
-// workgroup; p = 5: 11.5 k -> 12.7 k MDOFs*stage/s, p = 4: 13.4 k -> 14.1 k; p = 3: -1.3 %, the registers limit it anyway)
+// workgroup; p = 5: 11.5 k -> 12.7 k MDOFs*stage/s, p = 4: 13.4 k -> 14.1 k; p = 3: -1.3 %, the registers limit it anyway).
+// The lo 4 kernels use it at every order: it is what lets 7 elements share a workgroup at p = 3 (K2Cfg).
 #ifndef RMH_INPLACE_Y
 #define RMH_INPLACE_Y (P >= 4)
 #endif
-// Table rows of the qz loops of the column phase / of the three legs of the PCG's mass apply from the LDS copy
-// (uniform-address reads, in order with the other LDS traffic) instead of scalar loads.  Measured at two wavefronts
-// per SIMD: p = 6 7.43 k -> 7.63 k (column) -> 7.66 k (PCG); p = 5 -0.8 % / -8 %, p = 4 0, p = 3 -3.7 %.  At three
-// wavefronts per SIMD (p = 6 now) both are better off with scalar loads again: column phase 11.1 k -> 11.9 k (100 -> 32
-// B/lane of scratch, 17 % fewer LDS instructions); PCG legs, with the one or two iterations of the -pa rule, p = 6
-// 16.24 k -> 16.58 k, p = 3 18.29 k -> 18.04 k with the LDS copy, p = 4 -1.7 % with it: scalar loads everywhere (the two
-// compile-time switches RMH_COLTAB_LDS / RMH_PCGTAB_LDS went when the table pointers got their address-space type, tabp).
-// wave priority of the latency-bound second half of the kernel (PCG ... limiter) over the FMA-dense first half of the
-// other workgroups on the CU (0: off)
-#ifndef RMH_PRIO
-#define RMH_PRIO 0
-#endif
-
 
 template <int P, bool LO4 = false, bool BOTH = false>
 struct K2Cfg : TabLayout<P>
@@ -97,48 +62,15 @@ struct K2Cfg : TabLayout<P>
    // threads per workgroup: 256 (4 wavefronts, one per SIMD) at p <= 3, where several elements fill the lanes of the
    // column phases.  p = 4, 5: ONE wavefront and one element per workgroup (Q^2 = 49 and 64 columns on 64 lanes): no
    // barrier synchronises more than a wavefront, the element sums are a thread-local sum + one DPP wave sum
-   // (p = 4, -rs 4: 12.4 k -> 13.4 k MDOFs*stage/s; p = 5: 9.6 k -> 11.6 k).  p = 6 (81 columns): two wavefronts, one element.
-#ifndef RMH_NT6
-#define RMH_NT6 128
-#endif
-#ifndef RMH_NT5
-#define RMH_NT5 64
-#endif
-#ifndef RMH_NT4
-#define RMH_NT4 64
-#endif
-#ifndef RMH_NT3
-#define RMH_NT3 256
-#endif
-   static constexpr int NT = (P == 6) ? RMH_NT6 : (P == 5 ? RMH_NT5 : (P == 4 ? RMH_NT4 : (P == 3 ? RMH_NT3 : 256)));
-#ifndef RMH_NB6
-#define RMH_NB6 1
-#endif
-#ifndef RMH_NB5
-#define RMH_NB5 1
-#endif
-#ifndef RMH_NB4
-#define RMH_NB4 1
-#endif
-   // elements per workgroup: as many as fill the 256 lanes in the column phases, fewer where the LDS
-   // footprint would otherwise limit the CU to one workgroup (measured per order)
-#ifndef RMH_NB3
-#define RMH_NB3 (NT / Q2)
-#endif
-   // p = 2: 9 elements, not the 10 whose columns fit -- their 243 dofs take ONE round of the dof role where 270 take two
-   // (-rs 5: 9.3 k -> 11.2 k MDOFs*stage/s, bit-identical)
-#ifndef RMH_NB2
-#define RMH_NB2 (NT / Q2 < NT / D3 ? NT / Q2 : NT / D3)
-#endif
-   static constexpr int NB0 = (P == 6) ? RMH_NB6 : (P == 5 ? RMH_NB5 : (P == 4 ? RMH_NB4 : (P == 3 ? RMH_NB3 : (P == 2 ? RMH_NB2 : NT / Q2))));
-   // HO + RD in one kernel carries more LDS per element: one element less.  p = 3, -rs 5, MDOFs*stage/s by
-   // elements per workgroup and workgroups per CU (round 1, before / after the LDS diet of the RD extras):
-   // 7 @ 1: 4.1 k; 6 @ 2: 6.5 k; 5 @ 2: 5.8 k; 4 @ 3: 7.4 k; 5 @ 3: 7.7 k; 6 @ 3: 8.6 k -- occupancy first, then
-   // lane utilisation of the column phases (NB x 36 of 256 lanes).
-#ifndef RMH_BOTH_DROP
-#define RMH_BOTH_DROP 0
-#endif
-   static constexpr int NB = (LO4 && NB0 > 2) ? NB0 - RMH_BOTH_DROP : NB0;
+   // (p = 4, -rs 4: 12.4 k -> 13.4 k MDOFs*stage/s; p = 5: 9.6 k -> 11.6 k).  p = 6 (81 columns): two wavefronts, one element
+   // (more elements per workgroup at p >= 4 was measured in every shape the LDS admits: -7 ... -53 %).
+   static constexpr int NT = (P == 6) ? 128 : ((P == 5 || P == 4) ? 64 : 256);
+   // elements per workgroup at p <= 3: as many as fill the 256 lanes in the column phases -- p = 3: 7 (252 lanes; on 128- or
+   // 192-thread workgroups with 3 / 5 elements -10 % / -4 %) -- but at p = 2 9, not the 10 whose columns fit: their 243 dofs
+   // take ONE round of the dof role where 270 take two (-rs 5: 9.3 k -> 11.2 k MDOFs*stage/s, bit-identical)
+   static constexpr int NB = (P >= 4) ? 1 : ((P == 2) ? (NT / Q2 < NT / D3 ? NT / Q2 : NT / D3) : NT / Q2);
+   // (HO + RD in one kernel used to carry one element less -- 6 at p = 3 -- for the LDS of the RD extras; with the layout below
+   // all 7 fit at three workgroups per CU: lo 4 at p = 3 12.4 k -> 13.1 k MDOFs*stage/s)
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
@@ -146,20 +78,14 @@ struct K2Cfg : TabLayout<P>
    //   phases C-G : [R3 3 Q2 D | R2 3 Q D2]
    //   PCG, J     : [sA D3 | M1 / R2' Q S2 | R3' Q2 D | sB D3]
    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-#ifndef RMH_S2PAD
-#define RMH_S2PAD 1
-#endif
-#ifndef RMH_TRACE_PAD
-#define RMH_TRACE_PAD 0
-#endif
-#ifndef RMH_EL_MOD
-#define RMH_EL_MOD 2
-#endif
-   static constexpr int S2 = D2 + RMH_S2PAD; // padded row stride of U1 / M1 (bank conflicts)
-   static constexpr int FS = D2 + RMH_TRACE_PAD; // stride of the six faces' traces
-   static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * FS, PA = oU1 + 2 * Q * S2;
-   // slot of trace value r6 = f * D2 + r in the trace buffer
-   __host__ __device__ static constexpr int trace_slot(int r6) { return FS == D2 ? r6 : (r6 / D2) * FS + r6 % D2; }
+   // Strides and the LDS banks (round 4, tools/pmc_variants.sh with builds that end at a phase mark: SQ_LDS_BANK_CONFLICT of
+   // the p = 3 stage by phase -- face rows 30 %, y-leg 21 %, back-transform 18 %, R3 stores 13 %, column pass 12 %).  S2: the
+   // odd row stride of U1 / M1 keeps the y-back stores of the PCG conflict-free (an even stride lets the column pass read with
+   // ds_read_b128: -6 % LDS cycles, +16 % conflicts elsewhere, +-0 in time).  Padding the six trace blocks (D^2 + 2) and other
+   // element strides (== 8 or 24 mod 32) took 13-25 % of the conflicts away at -0.5 ... +0.2 % in time; the face-major order of
+   // the face rows (ho_kernel2) takes 23 % at +0.25 % and needs the element stride == 2 (mod 32).
+   static constexpr int S2 = D2 + 1; // padded row stride of U1 / M1
+   static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
    // volume rhs by the 1-D change of test basis Cf along y and z (phi^B_i = sum_k C[k][i] l_k; the x-leg of phase G
@@ -168,7 +94,13 @@ struct K2Cfg : TabLayout<P>
    // INPLACE_Y: the y-leg writes its D outputs over the first D of the Q inputs of its own line (R2 inside R3)
    static constexpr bool INPLACE_Y = RMH_INPLACE_Y || LO4;
    static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * Q2 * D, PF = INPLACE_Y ? NR * Q2 * D : oR2 + NR * Q * D2;
-   static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D3;
+   // JS: plane stride of the intermediates of the back-transform (phase J) -- D^2 + D at p = 3, where 16 lines of an
+   // element otherwise start in 4 LDS banks
+#ifndef RMH_JPAD
+#define RMH_JPAD ((P == 3) ? D : 0)
+#endif
+   static constexpr int JS = D2 + RMH_JPAD;
+   static constexpr int oSA = 0, oM1 = D3, oR3c = oM1 + Q * S2, oSB = oR3c + Q2 * D, PCG = oSB + D * JS;
    // lo 4 (subcell residual distribution) extras behind the work region: the face rows -- GL-tested for the HO part, and
    // Bernstein-tested s rows for the RD solver (a second set when HO and RD share the kernel) -- whose slots hold the
    // sub-mesh node positions until the subcell pass has consumed them (it runs in front of the face rows); then the
@@ -190,7 +122,7 @@ struct K2Cfg : TabLayout<P>
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
    static constexpr int EL0 = W + XT + (LO4 ? 3 * NS : 0);
-   static constexpr int EL = EL0 + ((RMH_EL_MOD - EL0 % 32) + 32) % 32;
+   static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
    // partial sums of the generic reductions: chunks of 64 dofs (one wavefront each), 8 chunks for small elements
    static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
    static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
@@ -198,7 +130,7 @@ struct K2Cfg : TabLayout<P>
    // fused stage: the 27 stencil indices of every element ([NB][27] ints), parked in LDS from phase A to the PCG prelude
    static constexpr int STI = (NB * 27 + 1) / 2;
    // split columns (p = 6, see ho_kernel2 phase C): w detJ of the columns that three lanes share lives in LDS, [column][qz]
-   static constexpr bool CSPL = RMH_COLSPLIT && NT == 128 && NB == 1 && Q2 > 64 && Q % 3 == 0 && 3 * (Q2 - 64) <= 64 && 6 * Q <= 64;
+   static constexpr bool CSPL = NT == 128 && NB == 1 && Q2 > 64 && Q % 3 == 0 && 3 * (Q2 - 64) <= 64 && 6 * Q <= 64;
    static constexpr int WDL = CSPL ? (Q2 - 64) * Q : 0;
    static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART + STI + WDL;
    // LDS allocation granule: a 54 096-byte kernel ran two workgroups per CU, a 52 560-byte one three (measured:
@@ -207,23 +139,19 @@ struct K2Cfg : TabLayout<P>
    // workgroups per CU the LDS budget admits (160 KiB); launch bounds ask for the matching registers
    static constexpr int WG_PER_CU = cmax(1, (160 * 1024) / LDS_BYTES > 1024 / NT ? 1024 / NT : (160 * 1024) / LDS_BYTES);
    // launch bound: wavefronts per SIMD that the LDS budget admits (a workgroup has NT / 64 wavefronts on 4 SIMDs)
-#ifndef RMH_MAXW
-#define RMH_MAXW 8
-#endif
    static constexpr int WAVES_PER_SIMD0 = cmax(1, WG_PER_CU * (NT / 64) / 4);
    // p = 6: LDS admits 5 workgroups of 2 wavefronts per CU = 2.5 per SIMD, which the registers only allow at <= 168
    // VGPRs.  Asking for 3 costs 100 B/lane of scratch in the column phase and still wins (9.65 k -> 10.0 k
    // MDOFs*stage/s; with the x-leg basis rows in registers through the PCG loop it was 248 B/lane and -12 %).
+   // (the compiler honours the bound only as far as the kernel's LDS admits that occupancy: the lo 4 kernel at p = 6 -- 35 KB,
+   // four workgroups per CU -- keeps its 214 VGPRs whatever is asked for)
 #ifndef RMH_WAVES6
 #define RMH_WAVES6 3
 #endif
 #ifndef RMH_WAVES5
 #define RMH_WAVES5 3
 #endif
-#ifndef RMH_WAVES6_LO4
-#define RMH_WAVES6_LO4 0
-#endif
-   static constexpr int WAVES_PER_SIMD = (P == 6 && LO4 && RMH_WAVES6_LO4 > 0) ? RMH_WAVES6_LO4 : (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4 && RMH_WAVES5 > 0) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > RMH_MAXW ? RMH_MAXW : WAVES_PER_SIMD0));
+   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0));
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
@@ -326,17 +254,11 @@ __device__ inline double wave_bcast(double v)
 // Element sums where a wavefront holds whole elements in its dof rounds (p = 3: 64 dofs): the totals of the DPP reduction
 // go from their lane straight to all lanes of the wavefront -- the lanes that want them -- instead of through LDS and a
 // workgroup barrier (same sums, same order)
+#ifndef RMH_FACE_MAJOR
+#define RMH_FACE_MAJOR (P == 3)
+#endif
 #ifndef RMH_WAVE_DOT
 #define RMH_WAVE_DOT 1
-#endif
-#ifndef RMH_WD_A
-#define RMH_WD_A 1
-#endif
-#ifndef RMH_WD_B
-#define RMH_WD_B 1
-#endif
-#ifndef RMH_WD_C
-#define RMH_WD_C 1
 #endif
 
 // sum over the 64 lanes of a wavefront in a fixed order; valid in lane 63
@@ -384,30 +306,17 @@ __device__ inline tabp_t<P> tab_view()
 #define RMH_TAB() tab_view<P>()
 #define RMH_TABK() (P >= RMH_VIEW_MINP ? tab_view<P>() : gtb)
 
-// Synchronisation of an LDS hand-off between the lanes that own ONE element.  Where every (round, wavefront) of the dof
-// role holds exactly one element (p = 3: 64 dofs), the lanes of the hand-off are the lanes of one wavefront: its LDS
-// operations execute in order, so only the compiler must not reorder them -- no workgroup barrier.  Other orders: barrier.
 // The upwind face speeds can come from a table made once per context (face_geom_kernel): w_q v.n_out(q, t) is a quadratic
 // in the pseudo-time t (the mesh moves linearly), three coefficients per face quadrature point.
 //   0: never; 1: in every kernel; 2: where it pays -- everywhere but the p = 3 HO / lo 5 kernels, which run at the
 //   board's power limit: there the FP64 work saved and the HBM bytes added cancel (tools/power_probe.py: same
 //   throughput at 130 MHz lower clocks), and the table would more than double the stage's HBM traffic.
-// x-leg basis rows of a thread's dofs in registers through the PCG loop (see ho_kernel2, phase G)
-// p = 6: pencil-type phases split over the two wavefronts (see split_outputs)
-#ifndef RMH_SPLIT2
-#define RMH_SPLIT2 1
-#endif
-#ifndef RMH_CBG_REG
-#define RMH_CBG_REG (DR * Q <= 12)
-#endif
 #ifndef RMH_FACE_COEF
 #define RMH_FACE_COEF 2
 #endif
-#ifndef RMH_EARLY_PENCILS
-#define RMH_EARLY_PENCILS 1
-#endif
-#ifndef RMH_WAVE_LOCAL
-#define RMH_WAVE_LOCAL 1
+// x-leg basis rows of a thread's dofs in registers through the PCG loop (see ho_kernel2, phase G)
+#ifndef RMH_CBG_REG
+#define RMH_CBG_REG (DR * Q <= 12)
 #endif
 // nothing is scheduled across this point (keeps the LDS table reads of the split columns next to their uses: hoisted
 // to the top of a quadrature-point loop they cost ~70 VGPRs)
@@ -415,23 +324,6 @@ __device__ inline void sched_fence()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
-template <bool WAVE_LOCAL>
-__device__ inline void sync_element()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-   if (WAVE_LOCAL)
-   {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-   }
-   else { __syncthreads(); }
-#elif defined(HIPEMU)
-   if (WAVE_LOCAL) { hipemu_wave_sync(); }
-   else { __syncthreads(); }
 #endif
 }
 
@@ -498,7 +390,7 @@ __device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double
       x = dpp_add_all<0x141>(x); // row_half_mirror
       x = dpp_add_all<0x140>(x); // row_mirror: every lane of a row holds the row total
       x = dpp_add<0x142, 0xA>(x); // row_bcast:15 into rows 1 and 3: half-wave totals
-      if (RMH_WAVE_DOT && RMH_WD_A)
+      if (RMH_WAVE_DOT)
       {
          out[0] = wave_bcast<31>(x);
          out[C::DR == 2 ? 1 : 0] = wave_bcast<63>(x);
@@ -629,7 +521,7 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
       x = dpp_add_all<0x4E>(x);
       x = dpp_add_all<0x141>(x);
       x = dpp_add_all<0x140>(x);
-      if (RMH_WAVE_DOT && RMH_WD_B)
+      if (RMH_WAVE_DOT)
       {
          outv[0] = wave_bcast<15>(x);
          outw[0] = wave_bcast<31>(x);
@@ -722,7 +614,7 @@ __device__ inline void batch_dot_keep2(const int tid, const double (&v)[C::DR], 
       y = dpp_add_all<0x140>(y);
       x = dpp_add<0x142, 0xA>(x);
       const int e1 = C::NT / C::D3 + wave;
-      if (RMH_WAVE_DOT && RMH_WD_C)
+      if (RMH_WAVE_DOT)
       {
          // (the kept sums are read by the dof threads of their element -- this wavefront -- behind later barriers)
          if (lane == 15) { (lds + wave * C::EL)[C::oKeep] = y; }
@@ -902,18 +794,15 @@ __global__ void face_geom_kernel(const double *x0, const double *vel, const doub
 }
 
 // Primary global loads of one element batch (phase A): face-neighbour indices, stencil indices (fused stage), Q2
-// nodes of x0 and v, u.  The fused stage calls it for the NEXT batch of a persistent workgroup at the start of its
-// limiter phase, so that the loads are in flight while the current batch finishes (see ho_kernel2).
+// nodes of x0 and v, u.
 template <class C, bool FUSED, int NLN, int NLS, int NLX, int NLU>
-__device__ inline void load_batch(const HoArgs &a, const bool on, const int e0, const int tid, int (&nbi)[NLN], int (&sti)[NLS], double (&gx0)[NLX],
+__device__ inline void load_batch(const HoArgs &a, const int e0, const int tid, int (&nbi)[NLN], int (&sti)[NLS], double (&gx0)[NLX],
                                   double (&gv)[NLX], double (&gu)[NLU])
 {
    constexpr int NT = C::NT, NB = C::NB, D2 = C::D2, D3 = C::D3;
-#if !RMH_PERSIST_LOOP
    // Straight-line loads: lanes past the end of a list load its last entry again (never stored) instead of branching
    // around the load.  With branches the compiler cannot count the loads in flight and drains ALL of them
    // (s_waitcnt vmcnt(0)) where only the neighbour indices -- issued first -- are needed to issue the trace loads.
-   (void)on;
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
@@ -943,52 +832,6 @@ __device__ inline void load_batch(const HoArgs &a, const bool on, const int e0, 
       const int e = min(e0 + k / D3, a.e_end - 1);
       gu[j] = a.u[(size_t)e * D3 + k % D3];
    }
-#else
-#pragma unroll
-   for (int j = 0; j < NLN; j++)
-   {
-      const int k = tid + j * NT;
-      nbi[j] = -1;
-      if (on && k < NB * 6 * D2)
-      {
-         const int eb = k / (6 * D2), f = (k % (6 * D2)) / D2;
-         nbi[j] = a.face_nbr[(size_t)min(e0 + eb, a.e_end - 1) * 6 + f];
-      }
-   }
-   // fused stage: the indices of the 27 stencil elements are needed before the PCG loop (their extrema are loaded
-   // there); loaded here with everything else so that no index -> value round trip is exposed later
-#pragma unroll
-   for (int j = 0; j < NLS; j++)
-   {
-      const int k = tid + j * NT;
-      sti[j] = -1;
-      if (FUSED && on && k < NB * 27) { sti[j] = a.stencil27[(size_t)min(e0 + k / 27, a.e_end - 1) * 27 + k % 27]; }
-   }
-#pragma unroll
-   for (int j = 0; j < NLX; j++)
-   {
-      const int k = tid + j * NT;
-      gx0[j] = 0.0; gv[j] = 0.0;
-      if (on && k < NB * 81)
-      {
-         const int eb = k / 81, i = k % 81;
-         const int e = min(e0 + eb, a.e_end - 1);
-         gx0[j] = a.x0[(size_t)e * 81 + i];
-         gv[j] = a.vel[(size_t)e * 81 + i];
-      }
-   }
-#pragma unroll
-   for (int j = 0; j < NLU; j++)
-   {
-      const int k = tid + j * NT;
-      gu[j] = 0.0;
-      if (on && k < NB * D3)
-      {
-         const int e = min(e0 + k / D3, a.e_end - 1);
-         gu[j] = a.u[(size_t)e * D3 + k % D3];
-      }
-   }
-#endif
 }
 
 // FUSED = false: HOSolver::CalcHOSolution (writes du_HO, lumped mass, element extrema of u).
@@ -1035,22 +878,16 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                  oCi = C::oCi;
 
    // ---- phase A: loads ----------------------------------------------------------------------
-   // Persistent workgroups: the grid may be smaller than the number of element batches (the fused stage is launched
-   // with as many workgroups as the chip holds); a workgroup then works through batches blockIdx.x, blockIdx.x +
-   // gridDim.x, ... and issues the primary loads of its next batch at the start of the limiter phase of the current
-   // one, so that only the (index-dependent) neighbour-trace loads are waited for at the top of a batch.
+   // (one batch of NB elements per workgroup)
    constexpr int NLX = (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
    constexpr int NLS = (NB * 27 + NT - 1) / NT;
    const int nblk = (a.e_end - a.e_begin + NB - 1) / NB;
    int nbi[NLN], sti[NLS];
    double gx0[NLX], gv[NLX], gu[NLU];
    int itmax = 0, cg_known = 0;
-   bool prefetched = false;
-   // (only the fused stage is launched with a persistent grid: the other modes get one batch per workgroup and no
-   // loop -- a back edge costs them registers in the column phase for nothing)
    int blk = blockIdx.x;
    if (blk >= nblk) { return; }
-   if (RMH_XCD_MAP && !RMH_PERSIST_LOOP && gridDim.x == (unsigned)nblk)
+   if (gridDim.x == (unsigned)nblk)
    {
       // workgroups are handed to the 8 XCDs round-robin (blockIdx.x % 8): give every XCD -- every L2 -- one contiguous
       // eighth of the element batches, so that the x- and y-neighbours whose traces and extrema an element reads were
@@ -1058,21 +895,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       const int xcd = blk & 7, j8 = blk >> 3, q8 = nblk >> 3, r8 = nblk & 7;
       blk = xcd * q8 + min(xcd, r8) + j8;
    }
-   const int blk0 = blk;
-   do
-   {
    const int e0 = a.e_begin + blk * NB;
-   // the thread index and the table base are made opaque per batch: everything derived from them (thread roles,
-   // LDS addresses, basis-table rows in registers) is then recomputed per batch instead of being hoisted out of the
-   // batch loop and kept live -- and spilled -- through all of it
-   int tid_ = tid0, zt_ = 0;
-#if defined(__HIP_DEVICE_COMPILE__) && RMH_PERSIST_LOOP
-   asm volatile("" : "+v"(tid_));
-   asm volatile("" : "+s"(zt_));
-#endif
-   const int tid = tid_;
+   const int tid = tid0;
    // (p = 6) split of the pencil-type phases over the two wavefronts of the workgroup, see split_outputs
-   constexpr bool SPL = RMH_SPLIT2 && NT == 128 && NB == 1;
+   constexpr bool SPL = NT == 128 && NB == 1;
 #if defined(__HIP_DEVICE_COMPILE__)
    const int wv = SPL ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
 #else
@@ -1086,10 +912,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    constexpr bool CSPL = SPL && C::CSPL;
    const int frt = CSPL ? (tid ^ 64) : tid; // face-row index of this thread (round 0)
    typedef tabp_t<P> tabp;
-   tabp gtb = (tabp)c_tab[P] + zt_; // constant memory: compile-time indices become scalar loads
+   tabp gtb = (tabp)c_tab[P]; // constant memory: compile-time indices become scalar loads
    tabp gt = gtb;
    (void)gt;
-   if (blk != blk0) { __syncthreads(); } // the previous batch's last LDS reads precede this batch's stores
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
    // ("any element still active" flags of the PCG loop: cleared here, in front of the first barrier -- the wavefronts reach
    // the prelude of the mass solve, where the first flag is raised, without a common barrier in between when their element
@@ -1097,7 +922,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    if (tid < 4) { s_flag[tid] = 0; }
    // all global loads are issued before the first LDS store so that they are in flight together
    // (neighbour indices first: the trace loads depend on them)
-   if (!prefetched) { load_batch<C, FUSED>(a, true, e0, tid, nbi, sti, gx0, gv, gu); }
+   load_batch<C, FUSED>(a, e0, tid, nbi, sti, gx0, gv, gu);
    // table copy for lane-dependent indexing: loaded behind the element data, stored with it (a copy loop at the top of
    // the kernel put a full memory round trip in front of the first element load)
    constexpr int NLT = (C::N2 + NT - 1) / NT;
@@ -1157,6 +982,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    }
    // face speed coefficients of this thread's face rows (youngest loads: first used after the second barrier)
    constexpr bool FC = FaceGeo<P>::used(MODE);
+   // face-major order of the face rows of a multi-element workgroup: row index = (face, element, q1).  The lanes of an LDS
+   // access group then work on ONE face of several elements -- the same node and trace offsets, element blocks apart (EL == 2
+   // mod 32: different banks) -- instead of on several faces of one element, whose trace blocks (D^2 doubles apart) and face
+   // nodes share banks (tools/pmc_variants.sh: the face rows were 30 % of the p = 3 stage's bank conflicts)
+   constexpr bool FMJ = RMH_FACE_MAJOR && NB > 1;
    constexpr int NFR = (NB * 6 * Q + NT - 1) / NT;
    double fgc[NFR][3 * Q];
    if constexpr (FC)
@@ -1165,7 +995,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int jp = 0; jp < NFR; jp++)
       {
          const int fr = min(frt + jp * NT, NB * 6 * Q - 1);
-         const double *fg = a.fgeo + (size_t)min(e0 + fr / (6 * Q), a.e_end - 1) * FaceGeo<P>::PER_ELEM + fr % (6 * Q);
+         const int feb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q), frow = FMJ ? (fr / (NB * Q)) * Q + fr % Q : fr % (6 * Q);
+         const double *fg = a.fgeo + (size_t)min(e0 + feb, a.e_end - 1) * FaceGeo<P>::PER_ELEM + frow;
 #pragma unroll
          for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[k * 6 * Q]; }
       }
@@ -1191,14 +1022,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       const int k = tid + j * NT;
       if (k < NB * D3) { RMH_W(k / D3)[oU + k % D3] = gu[j]; }
    }
-#if !RMH_EARLY_PENCILS
-#pragma unroll
-   for (int j = 0; j < NLN; j++)
-   {
-      const int k = tid + j * NT;
-      if (k < NB * 6 * D2) { RMH_W(k / (6 * D2))[oNb + C::trace_slot(k % (6 * D2))] = gn[j]; }
-   }
-#endif
 #pragma unroll
    for (int j = 0; j < NLT; j++) { if (tid + j * NT < C::N2) { stab[tid + j * NT] = gtab[j]; } }
    if (FUSED)
@@ -1377,37 +1200,27 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
    }
    RMH_STAMP(24);
-#if RMH_EARLY_PENCILS
    // The neighbour traces are the only loads that depend on another load (the neighbour index): they are not waited
    // for at the first barrier but here, behind the x-pencils of u, which need none of them.
-   // What is stored is the JUMP u_nbr - u_own at the face dof (RMH_TRACE_JUMP): the Q face rows of a face each formed the
-   // same D^2 differences from two LDS reads apiece (p = 6: 98 reads and 49 subtractions per row, on the wavefront that is
-   // the longer pole of the workgroup); now one read and one subtraction per trace value here, D^2 reads per row there.
-   constexpr bool TJ = RMH_TRACE_JUMP;
+   // What is stored is the JUMP u_nbr - u_own at the face dof: the Q face rows of a face each formed the same D^2
+   // differences from two LDS reads apiece (p = 6: 98 reads and 49 subtractions per row, on the wavefront that is the
+   // longer pole of the workgroup); now one read and one subtraction per trace value here, D^2 reads per row there.
 #pragma unroll
    for (int j = 0; j < NLN; j++)
    {
       const int k = tid + j * NT;
       if (k < NB * 6 * D2)
       {
-         double own = 0.0;
-         if (TJ)
-         {
-            const int r6 = k % (6 * D2);
-            const int f = r6 / D2, r = r6 % D2;
-            const int c = f >> 1, side = f & 1;
-            const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
-            own = RMH_W(k / (6 * D2))[oU + (side ? P * strc : 0) + (r % D) * str1 + (r / D) * str2];
-         }
-         RMH_W(k / (6 * D2))[oNb + C::trace_slot(k % (6 * D2))] = gn[j] - own;
+         const int r6 = k % (6 * D2);
+         const int f = r6 / D2, r = r6 % D2;
+         const int c = f >> 1, side = f & 1;
+         const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
+         const double own = RMH_W(k / (6 * D2))[oU + (side ? P * strc : 0) + (r % D) * str1 + (r / D) * str2];
+         RMH_W(k / (6 * D2))[oNb + r6] = gn[j] - own;
       }
    }
    __syncthreads();
    RMH_STAMP(25);
-#else
-   constexpr bool TJ = false;
-   if (LO4) { __syncthreads(); }
-#endif
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
@@ -1416,8 +1229,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       const int fr = frt + jp * NT;
       if (fr >= NB * 6 * Q) { break; }
-      const int eb = fr / (6 * Q), r = fr % (6 * Q);
-      const int f = r / Q, q1 = r % Q;
+      const int eb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q);
+      const int f = FMJ ? fr / (NB * Q) : (fr % (6 * Q)) / Q, q1 = fr % Q;
       const int c = f >> 1, side = f & 1;
       const int c1 = axis_next(c), c2 = axis_next2(c);
       double xd[3][3], xl[3][3], vl[3][3]; // [comp][a2]
@@ -1451,17 +1264,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
          w1 = stab[oW + q1];
       }
-      // traces: contraction of (u_nbr - u_own) along i1
-      const int dc = axis_stride<D>(c), d1 = axis_stride<D>(c1), d2 = axis_stride<D>(c2);
-      const double *uo = RMH_W(eb) + oU + (side ? P * dc : 0);
-      const double *un = RMH_W(eb) + oNb + f * C::FS;
+      // traces: contraction of the jumps u_nbr - u_own along i1
+      const double *un = RMH_W(eb) + oNb + f * D2;
       double jr[D];
 #pragma unroll
       for (int i2 = 0; i2 < D; i2++)
       {
          double acc = 0.0;
 #pragma unroll
-         for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * (TJ ? un[i1 + D * i2] : un[i1 + D * i2] - uo[i1 * d1 + i2 * d2]); }
+         for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * un[i1 + D * i2]; }
          jr[i2] = acc;
       }
       double tq[D], tq2[D];
@@ -1527,13 +1338,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
    }
    RMH_STAMP(26);
-#if RMH_EARLY_PENCILS
-   // (the column phase reads the nodes and U1, both complete since the barrier above; the face rows' output is read
-   // after the next barrier -- only the lumped face fluxes of the RD scheme need it here.  Split columns, p = 6: there the
-   // face rows run on the second wavefront BESIDE the first one's column pass, so the lumped fluxes wait until both are done)
-#else
-   __syncthreads();
-#endif
+   // (no barrier: the column phase reads the nodes and U1, both complete since the barrier above; the face rows' output is
+   // read after the next one.  Split columns, p = 6: the face rows run on the second wavefront BESIDE the first one's column pass)
 
    // lumped upwind face fluxes of the RD solver (ApplyFaceTerms3D, remhos_lo.cpp:795-871): (B^T D B 1)_i (u_nbr,i - u_i) with
    // the face rows already tested along q2.  Pass 1, tasks (element, face, line i2): the Q tested rows of the line are read
@@ -1541,7 +1347,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // replaces the jump.  Pass 2, dof role: a dof adds the products of the (up to three) faces it lies on, in the order of
    // the axes.  (Gathered per dof in one pass, every face dof read its Q rows and Q table entries from LDS: p = 6 2.9 k LDS
    // reads per element instead of 1.0 k.)
-   static_assert(TJ, "the lumped face fluxes take the traces as jumps");
    auto lumped_face_products = [&]() {
       for (int k = ptid; k < NB * 6 * D; k += PNT)
       {
@@ -1551,7 +1356,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          double in[Q];
 #pragma unroll
          for (int q1 = 0; q1 < Q; q1++) { in[q1] = F[q1 * D]; }
-         double *tr = RMH_W(eb) + oNb + f * C::FS + D * i2;
+         double *tr = RMH_W(eb) + oNb + f * D2 + D * i2;
          split_outputs<SPL, D>(wv, [&](auto lo_, auto hi_) {
 #pragma unroll
             for (int i1 = lo_; i1 < hi_; i1++)
@@ -1579,7 +1384,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             {
                const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
                const int f = 2 * c + (ic == P ? 1 : 0);
-               acc += RMH_W(eb)[oNb + f * C::FS + idx[c1] + D * idx[c2]];
+               acc += RMH_W(eb)[oNb + f * D2 + idx[c1] + D * idx[c2]];
             }
          }
          RMH_W(eb)[C::oDuf + i] = acc;
@@ -1826,9 +1631,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // ---- phase F: y-leg of the three test contractions (R2 overlays U1) ---------------------------------
    // (split workgroups: the three tensors are divided between the wavefronts -- r = 0, 1 / r = 2 -- not the outputs of
    // a line: in place, a line's outputs overwrite its own inputs)
-   for (int k = ptid; k < NB * Q * D; k += PNT)
+   // (several elements per workgroup: the Q D tasks of an element start at a multiple of 16 lanes where the workgroup has
+   // the threads -- p = 3: 24 tasks in 32 lanes -- so that the 16-lane groups of the LDS accesses do not straddle two
+   // element blocks, whose lines would share banks)
+   constexpr int TPE = (NB > 1 && NB * ((Q * D + 15) / 16 * 16) <= NT) ? (Q * D + 15) / 16 * 16 : Q * D;
+   for (int k = ptid; k < NB * TPE; k += PNT)
    {
-      const int eb = k / (Q * D), rem = k % (Q * D);
+      const int eb = k / TPE, rem = k % TPE;
+      if (rem >= Q * D) { continue; }
       const int q = rem / D, iz = rem % D;
       split_outputs<SPL, C::NR>(wv, [&](auto rlo, auto rhi) {
 #pragma unroll
@@ -1900,7 +1710,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // operands; the dof threads then pick up one value per tensor.  In the dof form every dof read Q inputs and Q table
    // entries from LDS per tensor (p = 6: 162 LDS reads per thread, now 27 + 9).  Split workgroups divide the tensors, as in
    // the y-leg.  Same sums in the same order.
-   constexpr bool PX = RMH_PENCIL_XLEG && NB == 1 && C::INPLACE_Y && !LO4 && !(RMH_CBG_REG);
+   constexpr bool PX = NB == 1 && C::INPLACE_Y && !LO4 && !(RMH_CBG_REG);
    if (PX)
    {
       constexpr int rs2 = Q2 * D;
@@ -2028,7 +1838,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int oin = ((dir - dir0) & 1) ? oSB : oSA, oout = ((dir - dir0) & 1) ? oSA : oSB;
             const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
             // (one element per workgroup: the directions before the last as pencil tasks, see the back-transform of phase J)
-            if (RMH_PENCIL_BACK && NB == 1 && dir < 2)
+            if (NB == 1 && dir < 2)
             {
                for (int k = ptid; k < D2; k += PNT)
                {
@@ -2306,7 +2116,12 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             }
          }
       }
-      if (!BOTH) { continue; }
+      if (!BOTH)
+      {
+         RMH_STAMP(7);
+         RMH_STAMP_FLUSH();
+         return;
+      }
       __syncthreads(); // the PCG reuses the front of W
    }
    RMH_STAMP(5);
@@ -2318,9 +2133,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // the kernarg segment: held in scalar registers from the kernel's first instruction they cost ~30 SGPRs through
    // phases A-J and push table values into VGPR-lane spills
    LateArgs L = late_args(a);
-#if defined(__HIP_DEVICE_COMPILE__) && RMH_PRIO
-   __builtin_amdgcn_s_setprio(RMH_PRIO); // PCG, back-transform, limiter: short dependent phases between barriers
-#endif
    // fused stage: the global reads of the limiter part are issued here so that they are in flight during
    // the PCG iterations (u is an L2 hit: this workgroup read it in phase A)
    double uu[DR], xb[DR], slo[NLS], shi[NLS];
@@ -2461,9 +2273,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       __syncthreads();
       RMH_STAMP(12);
       static_assert(!SPL || NB * Q * D <= 64, "split phases: one task per lane");
-      for (int k = ptid; k < NB * Q * D; k += PNT)
+      for (int k = ptid; k < NB * TPE; k += PNT)
       {
-         const int eb = k / (Q * D), rem = k % (Q * D);
+         const int eb = k / TPE, rem = k % TPE;
+         if (rem >= Q * D) { continue; }
          const int q = rem / D, iz = rem % D;
          const double *R3 = RMH_W(eb) + oR3c + q * D + iz;
          double in[Q];
@@ -2583,54 +2396,38 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    for (int dir = 0; dir < 3; dir++)
    {
       const int oin = (dir & 1) ? oSB : oSA, oout = (dir & 1) ? oSA : oSB;
-      const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
-      // one element per workgroup (p >= 4): the directions as pencil tasks -- a thread reads a line's D inputs
-      // once and forms its D outputs (split workgroups: half of them) with the table row as scalar operands; a dof thread
-      // reads D inputs and D table entries from LDS for ONE output (p = 6: 42 instead of 7 LDS reads per thread and
-      // direction).  Same sums in the same order.  The dof threads read their outputs behind the barrier of the last direction.
-      constexpr bool PJ = RMH_PENCIL_BACK && (NB == 1 || RMH_PENCIL_BACK_NB);
-      if (PJ)
+      // The directions as pencil tasks: a thread reads a line's D inputs once and forms its D outputs (split workgroups:
+      // half of them) with the table row as scalar operands; in the dof role every output read D inputs and D table entries
+      // from LDS (p = 6: 42 instead of 7 LDS reads per thread and direction; p = 3 +0.5 %, lo 4 +2.3 %).  Same sums in the
+      // same order.  The dof threads read their outputs behind the barrier of the last direction.
+      // The intermediates of directions 0 and 1 are stored with the z-planes JS apart (the input of direction 0 is plain):
+      // the lines of direction 1 -- (ix, iz), inputs D apart -- otherwise start D^2 apart, i.e. in D banks (p = 3: 4-way
+      // conflicts, 18 % of the stage's)
+      constexpr int JS = C::JS;
+      const int sin_ = (dir == 0) ? 1 : (dir == 1 ? D : JS), zin = (dir == 0) ? D2 : JS; // input: stride along the line, plane stride
+      const int sout = (dir == 0) ? 1 : (dir == 1 ? D : D2), zout = (dir == 2) ? D2 : JS;
+      for (int k0 = ptid; k0 < NB * D2; k0 += PNT)
       {
-         for (int k0 = ptid; k0 < NB * D2; k0 += PNT)
-         {
-            const int eb = k0 / D2, k = k0 % D2;
-            const int base = (dir == 0) ? k * D : (dir == 1 ? (k % D) + (k / D) * D2 : k);
-            const double *src = RMH_W(eb) + oin + base;
-            double in[D];
+         const int eb = k0 / D2, k = k0 % D2;
+         // line k: (iy, iz) = (k % D, k / D) along x; (ix, iz) along y; (ix, iy) along z
+         const int bin = (dir == 0) ? D * (k % D) + zin * (k / D) : (dir == 1 ? (k % D) + zin * (k / D) : k);
+         const int bout = (dir == 0) ? D * (k % D) + zout * (k / D) : (dir == 1 ? (k % D) + zout * (k / D) : k);
+         const double *src = RMH_W(eb) + oin + bin;
+         double in[D];
 #pragma unroll
-            for (int j = 0; j < D; j++) { in[j] = src[j * stride]; }
-            double *dst = RMH_W(eb) + oout + base;
-            split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
+         for (int j = 0; j < D; j++) { in[j] = src[j * sin_]; }
+         double *dst = RMH_W(eb) + oout + bout;
+         split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
 #pragma unroll
-               for (int kk = klo; kk < khi; kk++)
-               {
-                  tabp gt = RMH_TABK();
-                  double acc = 0.0;
+            for (int kk = klo; kk < khi; kk++)
+            {
+               tabp gt = RMH_TABK();
+               double acc = 0.0;
 #pragma unroll
-                  for (int j = 0; j < D; j++) { acc += gt[oCi + kk * D + j] * in[j]; }
-                  dst[kk * stride] = acc;
-               }
-            });
-         }
-      }
-      else
-      {
-#pragma unroll
-      for (int r = 0; r < DR; r++)
-      {
-         const int t = tid + r * NT;
-         if (t < NB * D3)
-         {
-            const int eb = t / D3, i = t % D3;
-            const int k = (i / stride) % D;
-            const double *src = RMH_W(eb) + oin + i - k * stride;
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < D; j++) { acc += stab[oCi + k * D + j] * src[j * stride]; }
-            if (dir == 2) { xg[r] = acc; }
-            else { RMH_W(eb)[oout + i] = acc; }
-         }
-      }
+               for (int j = 0; j < D; j++) { acc += gt[oCi + kk * D + j] * in[j]; }
+               dst[kk * sout] = acc;
+            }
+         });
       }
       if (FUSED && dir == 0)
       {
@@ -2674,12 +2471,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
       // (p = 3: the directions hand over within the wavefront that owns the element; one workgroup barrier at the end
       // publishes the box table)
-      constexpr bool WL = RMH_WAVE_LOCAL && C::WAVE_ALIGNED && !PJ;
-      if (dir < 2) { sync_element<WL>(); }
-      else { __syncthreads(); }
-      if (PJ && dir == 2)
+      __syncthreads();
+      if (dir == 2)
       {
-         // (the pencil form leaves the last direction's outputs in LDS: the dof threads pick up theirs)
+         // (the last direction's outputs are in LDS, in the plain layout: the dof threads pick up theirs)
 #pragma unroll
          for (int r = 0; r < DR; r++)
          {
@@ -2741,14 +2536,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       // ---- phase K: LimitMult + RK update (W is free: the last back-transform leg ended with a barrier) ----
       constexpr double eps = 1.0e-15;
-      // next batch of this (persistent) workgroup: primary loads in flight during the limiter
-      // (without a next batch the call only resets the registers: a definite assignment, so that this batch's values
-      // are not kept live -- and spilled -- around the loop)
-      if (RMH_PERSIST_LOOP)
-      {
-         prefetched = blk + (int)gridDim.x < nblk;
-         load_batch<C, FUSED>(a, prefetched, a.e_begin + (blk + (int)gridDim.x) * NB, tid, nbi, sti, gx0, gv, gu);
-      }
       RMH_STAMP(21);
       // MassBasedAvg: ubar = sum m (u + dt du_HO) / sum m
       // (with the constant-mode completion: du_HO += c, and the element's new mass is sum m u + dt 1^T b)
@@ -2964,7 +2751,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
       }
    }
-   } while (RMH_PERSIST_LOOP && FUSED && (blk += (int)gridDim.x) < nblk); // batches of this workgroup
    // diagnostics: max PCG iteration count over the launch.  A global atomic per wavefront on ONE
    // address serialises at the memory side (~5 ns each: 3 ms per launch at 500 k wavefronts), so the
    // atomic is issued only when it can raise the (monotone) maximum.
