@@ -318,6 +318,18 @@ __device__ inline tabp_t<P> tab_view()
 #ifndef RMH_CBG_REG
 #define RMH_CBG_REG (DR * Q <= 12)
 #endif
+// "Some element of the batch is still active": many work-items store the same 1 into one LDS word between two barriers.  A
+// relaxed atomic store -- the same ds_write_b32 on the device -- says so, and the host emulation under ThreadSanitizer
+// (tests/test_sanitizers.py) then reports real races only.
+__device__ inline void raise_flag(int *flag)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+   __atomic_store_n(flag, 1, __ATOMIC_RELAXED);
+#endif
+}
+
 // nothing is scheduled across this point (keeps the LDS table reads of the split columns next to their uses: hoisted
 // to the top of a quadrature-point loop they cost ~70 VGPRs)
 __device__ inline void sched_fence()
@@ -2192,7 +2204,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          act[r] = (tid + r * NT < NB * D3) && (nom[r] > tol[r]);
          any = any || act[r];
       }
-      if (any) { s_flag[0] = 1; } // visible after the first barrier of the loop
+      if (any) { raise_flag(&s_flag[0]); } // visible after the first barrier of the loop
    }
    for (int it = 0; it < a.max_iter; it++)
    {
@@ -2354,7 +2366,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          act[r] = act[r] && (nom[r] > tol[r]);
          any = any || act[r];
       }
-      if (any) { s_flag[(it + 1) & 1] = 1; } // read after the first barrier of the next iteration
+      if (any) { raise_flag(&s_flag[(it + 1) & 1]); } // read after the first barrier of the next iteration
    }
 
    RMH_STAMP(6);

@@ -13,8 +13,12 @@ EMU = os.path.join(ROOT, "tests", "emu", "librmh_emu.so")
 def emu_library_path():
     """The kernel sources compiled with g++ against tests/emu (TEST INFRASTRUCTURE, never loaded by the product):
     brought up to date with the sources once per test session (`make emu` is incremental)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "remhos_amd", "csrc"), "emu"])
-    return EMU
+    # RMH_EMU_VARIANT = asan | tsan: the same sources built under a host sanitizer (tests/test_sanitizers.py runs the emulation
+    # tests again in a child process that preloads the sanitizer's runtime)
+    variant = os.environ.get("RMH_EMU_VARIANT", "")
+    target = "emu" + ("-" + variant if variant else "")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "remhos_amd", "csrc"), target])
+    return EMU.replace("librmh_emu.so", f"librmh_emu_{variant}.so") if variant else EMU
 
 
 def layout_from_oracle(r):
