@@ -22,6 +22,7 @@ ap.add_argument("--rs", type=int, default=4)
 ap.add_argument("--order", type=int, default=3)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--full-records", action="store_true")
+ap.add_argument("--no-overlap", action="store_true", help="exchange first, then ONE launch over all elements: the RCCL kernel alone on the GPU")
 args = ap.parse_args()
 if args.full_records:
     os.environ["RMH_COMPACT"] = "0"
@@ -29,7 +30,7 @@ lib = bind_driver(load_library())
 out = {}
 for wrap in (0, 1):
     case = Case(lib, make_config("periodic-cube", args.rs, args.order, 10, -1.0, 0.5, pa=1, self_wrap=wrap))
-    st = Stepper(lib, case, device="cuda:0")
+    st = Stepper(lib, case, device="cuda:0", overlap=not args.no_overlap)
     for _ in range(2):
         st.step(case.dt)
     torch.cuda.synchronize()
