@@ -108,21 +108,29 @@ struct K2Cfg : TabLayout<P>
    // by then) behind the in-place test tensors, and read by the RD part in front of the PCG.
    static constexpr int NS = P * P * P;
    static constexpr int RF = 6 * Q * D; // face rows tested along q2
-   static constexpr int XT = LO4 ? cmax(RF * (BOTH ? 2 : 1), 3 * D3) : RF;
-   // (+108: stencil and box table of the fused limiter, see phase J; +2: the element's sum of the right-hand side and
-   // its volume, kept from the PCG prelude to the constant-mode completion, see batch_dot_keep2)
-   static constexpr int oKeep = PCG + 108;
-   // (behind the traces, which the lumped fluxes read while they write it, and behind everything the RD part uses)
-   static constexpr int oDuf = cmax(cmax(PF, PCG), oU1);
-   static constexpr int W = cmax(PA, cmax(LO4 ? oDuf + D3 : PF, oKeep + 2));
+   // One-element workgroups of the lo 4 kernels (p >= 4) are short of LDS, not of lanes: there the lumped face flux lives behind
+   // the face rows instead of in the work region, and the tables of the fused limiter (+108: stencil and box table, see phase
+   // J; +2: the element's sum of the right-hand side and its volume, kept from the PCG prelude to the constant-mode completion,
+   // see batch_dot_keep2) go where the GL-tested face rows were -- consumed in phase G, long before the PCG prelude.  p = 6:
+   // 35 -> 32 KB per workgroup (room for a fifth workgroup per CU, which the registers do not admit: see WAVES_PER_SIMD);
+   // p = 4, 5: +-0.
+   static constexpr bool SLIM = LO4 && NB == 1;
+   static constexpr int RFA = RF * (BOTH ? 2 : 1); // all face rows
+   static constexpr int XT = LO4 ? cmax(RFA + (SLIM ? D3 : 0), 3 * D3) : RF;
+   static constexpr int oDufW = cmax(cmax(PF, PCG), oU1); // (behind the traces, which the lumped fluxes read while they write it, and behind everything the RD part uses)
+   static constexpr int W = SLIM ? cmax(PA, cmax(PF, PCG)) : cmax(PA, cmax(LO4 ? oDufW + D3 : PF, PCG + 110));
    static constexpr int oF = W;                       // s*jump rows (GL basis) -- or the s rows in the RD-only kernel
    static constexpr int oF2 = BOTH ? oF + RF : oF;    // s rows (Bernstein basis) of the RD solver
    static constexpr int oXs = oF;                     // sub-mesh nodes [3][D3], phases A-B
+   static constexpr int oDuf = SLIM ? oF + RFA : oDufW;
+   static constexpr int oLim = SLIM ? oF : PCG;       // limiter tables [108] and the two kept sums
+   static constexpr int oKeep = oLim + 108;
+   static_assert(!SLIM || RF >= 110, "no room for the limiter tables in the face rows");
    static constexpr int oSub = oF + XT;
    // element block stride: 16-byte aligned, and == 2 (mod 32) doubles so that the same offset of
    // neighbouring elements (two elements share most wavefronts) falls into different LDS banks
    static constexpr int EL0 = W + XT + (LO4 ? 3 * NS : 0);
-   static constexpr int EL = EL0 + ((2 - EL0 % 32) + 32) % 32;
+   static constexpr int EL = (NB == 1) ? EL0 + (EL0 & 1) : EL0 + ((2 - EL0 % 32) + 32) % 32;
    // partial sums of the generic reductions: chunks of 64 dofs (one wavefront each), 8 chunks for small elements
    static constexpr int DOT_CH = D3 >= 64 ? (D3 + 63) / 64 : 8;
    static constexpr bool WAVE_ALIGNED = (D3 % 64) == 0; // every (round, wavefront) holds one element
@@ -143,14 +151,15 @@ struct K2Cfg : TabLayout<P>
    // p = 6: LDS admits 5 workgroups of 2 wavefronts per CU = 2.5 per SIMD, which the registers only allow at <= 168
    // VGPRs.  Asking for 3 costs 100 B/lane of scratch in the column phase and still wins (9.65 k -> 10.0 k
    // MDOFs*stage/s; with the x-leg basis rows in registers through the PCG loop it was 248 B/lane and -12 %).
-   // (the compiler honours the bound only as far as the kernel's LDS admits that occupancy: the lo 4 kernel at p = 6 -- 35 KB,
-   // four workgroups per CU -- keeps its 214 VGPRs whatever is asked for)
+   // (the compiler honours the bound only as far as the kernel's LDS admits that occupancy)
 #ifndef RMH_WAVES6
 #define RMH_WAVES6 3
 #endif
 #ifndef RMH_WAVES5
 #define RMH_WAVES5 3
 #endif
+   // (lo 4 at p = 6, round 4: with the slim layout below the kernel's LDS admits a fifth workgroup per CU, i.e. 2.5 wavefronts per
+   // SIMD; asking for 3 gives 168 VGPRs + 76 B/lane of scratch and 10.0 k instead of 11.7 k MDOFs*stage/s -- it stays at 2)
    static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0));
 };
 
@@ -2392,15 +2401,15 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    {
       // limiter: the stencil extrema go to LDS behind the PCG buffers and the box table (smin at [PCG + 54, +27),
       // smax at [PCG + 81, +27)); the barriers of the back-transform publish them and the box table made from them
-      static_assert(C::W - C::PCG >= 108, "no room for the stencil and the box table behind the PCG buffers");
+      static_assert(C::SLIM || C::W - C::PCG >= 108, "no room for the stencil and the box table behind the PCG buffers");
 #pragma unroll
       for (int j = 0; j < NLS; j++)
       {
          const int k = tid + j * NT;
          if (k < NB * 27)
          {
-            RMH_W(k / 27)[C::PCG + 54 + k % 27] = slo[j];
-            RMH_W(k / 27)[C::PCG + 81 + k % 27] = shi[j];
+            RMH_W(k / 27)[C::oLim + 54 + k % 27] = slo[j];
+            RMH_W(k / 27)[C::oLim + 81 + k % 27] = shi[j];
          }
       }
    }
@@ -2449,7 +2458,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int k = tid; k < NB * 27; k += NT)
       {
          const int eb = k / 27, s3 = k % 27;
-         const double *smin = RMH_W(eb) + C::PCG + 54, *smax = RMH_W(eb) + C::PCG + 81;
+         const double *smin = RMH_W(eb) + C::oLim + 54, *smax = RMH_W(eb) + C::oLim + 81;
          double lo = INFINITY, hi = -INFINITY;
          if (L.bounds_type == 0)
          {
@@ -2477,8 +2486,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                hi = fmax(hi, smax[fs[q]]);
             }
          }
-         RMH_W(eb)[C::PCG + s3] = lo;
-         RMH_W(eb)[C::PCG + 27 + s3] = hi;
+         RMH_W(eb)[C::oLim + s3] = lo;
+         RMH_W(eb)[C::oLim + 27 + s3] = hi;
       }
       }
       // (p = 3: the directions hand over within the wavefront that owns the element; one workgroup barrier at the end
@@ -2584,7 +2593,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int eb = t / D3, i = t % D3;
             const int bx = i % D, by = (i / D) % D, bz = i / D2;
             const int s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
-            const double lo = RMH_W(eb)[C::PCG + s3], hi = RMH_W(eb)[C::PCG + 27 + s3];
+            const double lo = RMH_W(eb)[C::oLim + s3], hi = RMH_W(eb)[C::oLim + 27 + s3];
             const double ubar = fdiv(mass[r], vol[r]);
             if (!BOTH) { dlo[r] = fdiv(ubar - uu[r], L.dt); } // MassBasedAvg; with RD dlo is already there
             dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi));

@@ -2,7 +2,7 @@
 file bench.py reads `roofline.traffic` and `roofline_fp64` from.  Every entry is stamped with the hash of the kernel
 sources it was measured on (bench.py refuses an entry whose hash differs), the mass tolerance and the LO solver.
 
-    python tools/update_traffic.py <tag> [mass-solve] [round]        (reads gpurun_out/prof_<tag>/ and gpurun_out/pmc_<tag>/)
+    python tools/update_traffic.py <tag> [mass-solve] [round] [lo]   (reads gpurun_out/prof_<tag>/ and gpurun_out/pmc_<tag>/)
 
 FETCH_SIZE on gfx950 under-reports coalesced reads (MI355X_MICROARCH.md: exactly 1/2 for 16-byte-per-lane streams); for
 this kernel's 8-byte-per-lane loads the factor was calibrated in round 1 on limit_fused_kernel, whose read bytes are
@@ -21,7 +21,9 @@ from bench import MASS_SOLVE, kernel_source_hash, stage_alg_bytes_per_dof  # noq
 FETCH_CAL = 1.771
 tag = sys.argv[1]
 solve = sys.argv[2] if len(sys.argv) > 2 else "pa"  # --mass-solve of the profiled bench command
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r04"
+lo = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+mode = 3 if lo in (3, 4) else 1
 
 
 def counters(pattern):
@@ -38,7 +40,7 @@ insts = counters(f"pmc_{tag}/a/**/*counter_collection.csv")
 path = os.path.join(ROOT, "profiles", "traffic_ho_kernel.json")
 out = json.load(open(path))
 for order, rs, ne in ((3, 5, 884736), (6, 4, 110592)):
-    kname = next((k for k in fetch if f"ho_kernel2<{order}, 1>" in k), None)
+    kname = next((k for k in fetch if f"ho_kernel2<{order}, {mode}>" in k), None)
     if not kname:
         print("no dispatches of order", order)
         continue
@@ -46,12 +48,13 @@ for order, rs, ne in ((3, 5, 884736), (6, 4, 110592)):
     f_kib, w_kib = avg(fetch, "FETCH_SIZE"), avg(write, "WRITE_SIZE")
     ndof = (order + 1) ** 3
     ent = {
-        "kernel": f"ho_kernel2<{order},1> (whole RK stage, -lo 5)",
-        "kernel_src_sha": kernel_source_hash(), "mass_tol": MASS_SOLVE[solve][1], "lo": 5,
+        "kernel": f"ho_kernel2<{order},{mode}> (whole RK stage, -lo {lo})",
+        "kernel_src_sha": kernel_source_hash(), "mass_tol": MASS_SOLVE[solve][1], "lo": lo,
         "fetch_size_kib": f_kib, "write_size_kib": w_kib, "fetch_calibration": FETCH_CAL,
         "hbm_bytes_per_launch": int(1024 * (FETCH_CAL * f_kib + w_kib)),
-        "algorithmic_bytes_per_launch": int(stage_alg_bytes_per_dof(order) * ne * ndof),
-        "source": f"profiles/{rnd}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh {tag})",
+        "hbm_bytes_per_launch_x2": int(1024 * (2.0 * f_kib + w_kib)),  # the guide's FETCH_SIZE correction for gfx950
+        "algorithmic_bytes_per_launch": int(stage_alg_bytes_per_dof(order, lo) * ne * ndof),
+        "source": f"profiles/{rnd}{'_lo4' if lo == 4 else ''}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh {tag})",
     }
     if kname in insts and "SQ_INSTS_VALU_FMA_F64" in insts[kname]:
         ent["fp64_wave_insts_per_launch"] = {
@@ -59,6 +62,6 @@ for order, rs, ne in ((3, 5, 884736), (6, 4, 110592)):
             "add": avg(insts, "SQ_INSTS_VALU_ADD_F64"), "all_valu": avg(insts, "SQ_INSTS_VALU"),
             "source": "rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU (tools/pmc_insts.sh), wave64 instructions",
         }
-    out[f"periodic-cube-rs{rs}-o{order}-n1-stage"] = ent
+    out[f"periodic-cube-rs{rs}-o{order}-n1-stage" + ("-lo4" if lo == 4 else "")] = ent
     print(order, ent["hbm_bytes_per_launch"] / 1e9, "GB per launch measured,", ent["algorithmic_bytes_per_launch"] / 1e9, "GB algorithmic")
 json.dump(out, open(path, "w"), indent=1)
