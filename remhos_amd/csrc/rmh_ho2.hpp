@@ -936,6 +936,41 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    tabp gtb = (tabp)c_tab[P]; // constant memory: compile-time indices become scalar loads
    tabp gt = gtb;
    (void)gt;
+   // One leg of a 1-D change of basis with the D x D table at offset oT, along direction dir, for every element of the batch: a
+   // thread reads a line's D inputs once and forms its D outputs (split workgroups: half of them) with the table row as scalar
+   // operands; in the dof role every output read D inputs and D table entries from LDS (p = 6: 42 instead of 7 LDS reads per
+   // thread and direction; p = 3 +0.5 %, lo 4 +2.3 %).  Same sums in the same order.  The input of the first leg and the output
+   // of the last (direction 2) are in the plain layout; the intermediates are stored with the z-planes JS apart: the lines of
+   // direction 1 -- (ix, iz), inputs D apart -- otherwise start D^2 apart, i.e. in D banks (p = 3: 4-way conflicts, 18 % of the
+   // stage's).  No barrier inside.
+   auto basis_leg = [&](auto oT_, const int dir, const bool first, const int oin, const int oout) {
+      constexpr int oT = decltype(oT_)::value, JS = C::JS;
+      const int zin = first ? D2 : JS, zout = (dir == 2) ? D2 : JS; // plane strides of input and output
+      const int sin_ = (dir == 0) ? 1 : (dir == 1 ? D : zin), sout = (dir == 0) ? 1 : (dir == 1 ? D : zout);
+      for (int k0 = ptid; k0 < NB * D2; k0 += PNT)
+      {
+         const int eb = k0 / D2, k = k0 % D2;
+         // line k: (iy, iz) = (k % D, k / D) along x; (ix, iz) along y; (ix, iy) along z
+         const int bin = (dir == 0) ? D * (k % D) + zin * (k / D) : (dir == 1 ? (k % D) + zin * (k / D) : k);
+         const int bout = (dir == 0) ? D * (k % D) + zout * (k / D) : (dir == 1 ? (k % D) + zout * (k / D) : k);
+         const double *src = RMH_W(eb) + oin + bin;
+         double in[D];
+#pragma unroll
+         for (int j = 0; j < D; j++) { in[j] = src[j * sin_]; }
+         double *dst = RMH_W(eb) + oout + bout;
+         split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
+#pragma unroll
+            for (int kk = klo; kk < khi; kk++)
+            {
+               tabp gt = RMH_TABK();
+               double acc = 0.0;
+#pragma unroll
+               for (int j = 0; j < D; j++) { acc += gt[oT + kk * D + j] * in[j]; }
+               dst[kk * sout] = acc;
+            }
+         });
+      }
+   };
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
    // ("any element still active" flags of the PCG loop: cleared here, in front of the first barrier -- the wavefronts reach
    // the prelude of the mass solve, where the first flag is raised, without a common barrier in between when their element
@@ -1857,52 +1892,20 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int dir = dir0; dir < 3; dir++)
          {
             const int oin = ((dir - dir0) & 1) ? oSB : oSA, oout = ((dir - dir0) & 1) ? oSA : oSB;
-            const int stride = (dir == 0) ? 1 : (dir == 1 ? D : D2);
-            // (one element per workgroup: the directions before the last as pencil tasks, see the back-transform of phase J)
-            if (NB == 1 && dir < 2)
-            {
-               for (int k = ptid; k < D2; k += PNT)
-               {
-                  const int base = (dir == 0) ? k * D : (k % D) + (k / D) * D2;
-                  const double *src = RMH_W(0) + oin + base;
-                  double in[D];
-#pragma unroll
-                  for (int j = 0; j < D; j++) { in[j] = src[j * stride]; }
-                  double *dst = RMH_W(0) + oout + base;
-                  split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
-#pragma unroll
-                     for (int kk = klo; kk < khi; kk++)
-                     {
-                        tabp gt = RMH_TABK();
-                        double acc = 0.0;
-#pragma unroll
-                        for (int j = 0; j < D; j++) { acc += gt[C::oCf + kk * D + j] * in[j]; }
-                        dst[kk * stride] = acc;
-                     }
-                  });
-               }
-            }
-            else
-            {
-#pragma unroll
-            for (int r = 0; r < DR; r++)
-            {
-               const int t = tid + r * NT;
-               if (t < NB * D3)
-               {
-                  const int eb = t / D3, i = t % D3;
-                  const int k = (i / stride) % D;
-                  const double *src = RMH_W(eb) + oin + i - k * stride;
-                  double acc = 0.0;
-#pragma unroll
-                  for (int j = 0; j < D; j++) { acc += stab[C::oCf + k * D + j] * src[j * stride]; }
-                  if (dir == 2) { zb[r] = acc; }
-                  else { RMH_W(eb)[oout + i] = acc; }
-               }
-            }
-            }
+            basis_leg(IntC<C::oCf>{}, dir, dir == dir0, oin, oout);
             __syncthreads();
+            if (dir == 2)
+            {
+#pragma unroll
+               for (int r = 0; r < DR; r++)
+               {
+                  const int t = tid + r * NT;
+                  if (t < NB * D3) { zb[r] = RMH_W(t / D3)[oout + t % D3]; }
+               }
+            }
          }
+         // (the dof threads' reads of the result precede the next stores into these slots: the PCG prelude is a barrier away)
+         if (!WD) { __syncthreads(); }
       }
 #pragma unroll
       for (int r = 0; r < DR; r++)
@@ -2417,39 +2420,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    for (int dir = 0; dir < 3; dir++)
    {
       const int oin = (dir & 1) ? oSB : oSA, oout = (dir & 1) ? oSA : oSB;
-      // The directions as pencil tasks: a thread reads a line's D inputs once and forms its D outputs (split workgroups:
-      // half of them) with the table row as scalar operands; in the dof role every output read D inputs and D table entries
-      // from LDS (p = 6: 42 instead of 7 LDS reads per thread and direction; p = 3 +0.5 %, lo 4 +2.3 %).  Same sums in the
-      // same order.  The dof threads read their outputs behind the barrier of the last direction.
-      // The intermediates of directions 0 and 1 are stored with the z-planes JS apart (the input of direction 0 is plain):
-      // the lines of direction 1 -- (ix, iz), inputs D apart -- otherwise start D^2 apart, i.e. in D banks (p = 3: 4-way
-      // conflicts, 18 % of the stage's)
-      constexpr int JS = C::JS;
-      const int sin_ = (dir == 0) ? 1 : (dir == 1 ? D : JS), zin = (dir == 0) ? D2 : JS; // input: stride along the line, plane stride
-      const int sout = (dir == 0) ? 1 : (dir == 1 ? D : D2), zout = (dir == 2) ? D2 : JS;
-      for (int k0 = ptid; k0 < NB * D2; k0 += PNT)
-      {
-         const int eb = k0 / D2, k = k0 % D2;
-         // line k: (iy, iz) = (k % D, k / D) along x; (ix, iz) along y; (ix, iy) along z
-         const int bin = (dir == 0) ? D * (k % D) + zin * (k / D) : (dir == 1 ? (k % D) + zin * (k / D) : k);
-         const int bout = (dir == 0) ? D * (k % D) + zout * (k / D) : (dir == 1 ? (k % D) + zout * (k / D) : k);
-         const double *src = RMH_W(eb) + oin + bin;
-         double in[D];
-#pragma unroll
-         for (int j = 0; j < D; j++) { in[j] = src[j * sin_]; }
-         double *dst = RMH_W(eb) + oout + bout;
-         split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
-#pragma unroll
-            for (int kk = klo; kk < khi; kk++)
-            {
-               tabp gt = RMH_TABK();
-               double acc = 0.0;
-#pragma unroll
-               for (int j = 0; j < D; j++) { acc += gt[oCi + kk * D + j] * in[j]; }
-               dst[kk * sout] = acc;
-            }
-         });
-      }
+      basis_leg(IntC<oCi>{}, dir, dir == 0, oin, oout);
       if (FUSED && dir == 0)
       {
       // per-dof bounds are box minima / maxima of the 3 x 3 x 3 stencil: a dof sees, per direction, the offsets
