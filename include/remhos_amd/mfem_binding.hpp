@@ -97,7 +97,7 @@ class RMHLocalInverseHOSolver : public HOSolver
    RMHContext &rmh;
 
 public:
-   RMHLocalInverseHOSolver(ParFiniteElementSpace &space, RMHContext &c, bool partial_assembly = true) : HOSolver(space), rmh(c)
+   RMHLocalInverseHOSolver(ParFiniteElementSpace &space, RMHContext &c, bool partial_assembly) : HOSolver(space), rmh(c)
    {
       const int rc = partial_assembly ? (rmh_set_mass_tol(rmh.ctx, 0.0, 1e-8, 100) | rmh_set_mass_completion(rmh.ctx, 1, 1))
                                       : (rmh_set_mass_tol(rmh.ctx, 1e-14, 0.0, 100) | rmh_set_mass_completion(rmh.ctx, 0, 0));

@@ -133,7 +133,7 @@ public:
 class LocalInverseHOSolver : public HOSolver
 {
 public:
-   LocalInverseHOSolver(ParFiniteElementSpace &space, bool partial_assembly = true);
+   LocalInverseHOSolver(ParFiniteElementSpace &space, bool partial_assembly); // (no default: the mass rule is the caller's statement, and it replaces the context's tolerance)
    void CalcHOSolution(const Vector &u, Vector &du) const override;
 };
 
