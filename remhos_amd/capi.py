@@ -360,6 +360,12 @@ class Context:
         self._check(self.lib.rmh_exchange_peer(self.h, int(k), C.byref(r), *[C.byref(x) for x in v]))
         return (r.value,) + tuple(x.value for x in v)
 
+    def comm_count(self):
+        """ranks of the context's RCCL communicator as the communicator reports them (0: none)"""
+        n = C.c_int(-1)
+        self._check(self.lib.rmh_comm_count(self.h, C.byref(n)))
+        return n.value
+
     def allreduce(self, vals, op="sum"):
         arr = (C.c_double * len(vals))(*[float(v) for v in vals])
         self._check(self.lib.rmh_allreduce(self.h, arr, len(vals), {"sum": 0, "min": 1, "max": 2}[op]))

@@ -144,3 +144,57 @@ def test_selfloop_solver_classes_emulated(emulib, kw, monkeypatch):
     u1, us1, r1 = driver_fields(emulib, 2, **kw)
     assert np.array_equal(u0, u1) and np.array_equal(us0, us1)
     assert r0.max_value == r1.max_value and abs(r0.final_mass - r1.final_mass) <= 1e-14 * abs(r0.final_mass)
+
+
+def test_state_checks_of_the_exchange_and_the_split_stage(emulib):
+    """Round-4 state checks (advisor findings): (i) the ranges of one fused stage must name the same u and dt -- a stage
+    that is abandoned or fails leaves no stale extrema behind; (ii) after rmh_exchange_minmax_* the ghost extrema belong to
+    another field: the limiters of u refuse them until u is exchanged again; (iii) rmh_comm_count without a communicator."""
+    import pytest as _pytest
+    import torch
+
+    from remhos_amd.case import Case, make_config
+    from remhos_amd.stepper import Stepper
+
+    case = Case(emulib, make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, self_wrap=1))
+    st = Stepper(emulib, case, device="cpu")
+    c, u, dt = st.ctx, st.x, case.dt
+    assert st.transport == "local" and c.comm_count() == 0
+    y, z = torch.zeros_like(u), torch.zeros_like(u)
+    ne, nh = case.ne_owned, case.ne_halo
+    c.setup(0.1)
+    # reference: the split stage as the stepper runs it
+    c.exchange_begin(u)
+    c.stage_fused_range(u, dt, y, nh, ne, False)
+    c.exchange_end()
+    c.stage_fused_range(u, dt, y, 0, nh, True)
+    # (i) a second range with another input vector (or another dt) is refused, and the stage is forgotten ...
+    u2 = u.clone()
+    u2[0, :] += 0.125
+    c.exchange_begin(u)
+    c.stage_fused_range(u, dt, z, nh, ne, False)
+    c.exchange_end()
+    with _pytest.raises(RuntimeError, match="same u and dt"):
+        c.stage_fused_range(u2, dt, z, 0, nh, True)
+    with _pytest.raises(RuntimeError, match="same u and dt"):
+        c.exchange_begin(u)
+        c.stage_fused_range(u, dt, z, nh, ne, False)
+        c.exchange_end()
+        c.stage_fused_range(u, 0.5 * dt, z, 0, nh, True)
+    # ... so that the next stage starts from scratch (its own extrema) and reproduces the reference
+    c.exchange_begin(u)
+    c.stage_fused_range(u, dt, z, nh, ne, False)
+    c.exchange_end()
+    c.stage_fused_range(u, dt, z, 0, nh, True)
+    assert torch.equal(y, z)
+    # (ii) caller-given extrema in the ghost slots: the limiter of u refuses them, an exchange of u makes them valid again
+    xe_min, xe_max = torch.zeros(ne, dtype=u.dtype), torch.ones(ne, dtype=u.dtype)
+    c.exchange_minmax(xe_min, xe_max)
+    with _pytest.raises(RuntimeError, match="another field"):
+        c.stage_fused_range(u, dt, z, nh, ne, False)
+    c.exchange_begin(u)
+    c.stage_fused_range(u, dt, z, nh, ne, False)
+    c.exchange_end()
+    c.stage_fused_range(u, dt, z, 0, nh, True)
+    assert torch.equal(y, z)
+    st.close()
