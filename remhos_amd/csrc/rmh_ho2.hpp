@@ -989,17 +989,23 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // in front of the first barrier exposed five memory round trips: 18 % of the lo 4 workgroup's cycles)
    constexpr int NLSUB = LO4 ? (NB * 3 * D3 + NT - 1) / NT : 1;
    double gsx[NLSUB], gsv[NLSUB];
-   if (LO4 && a.rd_subcell)
-   {
-#pragma unroll
-      for (int j = 0; j < NLSUB; j++)
+   auto load_submesh = [&]() {
+      if (LO4 && a.rd_subcell)
       {
-         const int k = min(tid + j * NT, NB * 3 * D3 - 1);
-         const size_t g = (size_t)min(e0 + k / (3 * D3), a.e_end - 1) * 3 * D3 + k % (3 * D3);
-         gsx[j] = a.subx0[g];
-         gsv[j] = a.move ? a.subvel[g] : 0.0;
+#pragma unroll
+         for (int j = 0; j < NLSUB; j++)
+         {
+            const int k = min(tid + j * NT, NB * 3 * D3 - 1);
+            const size_t g = (size_t)min(e0 + k / (3 * D3), a.e_end - 1) * 3 * D3 + k % (3 * D3);
+            gsx[j] = a.subx0[g];
+            gsv[j] = a.move ? a.subvel[g] : 0.0;
+         }
       }
-   }
+   };
+   // SUBL (p = 3): the sub-mesh nodes are the youngest loads and go to LDS behind the u pencils (one more barrier) -- the first
+   // barrier then waits for the nodes, u and the tables only: lo 4 +1.2 % at p = 3 (p = 4 +-0, p = 6 -0.8 %: not there)
+   constexpr bool SUBL = LO4 && P == 3;
+   if (!SUBL) { load_submesh(); }
    // ... and the sub-mesh velocities at the subcell midpoints of this thread's subcells (read inside the subcell pass they
    // were a memory round trip in the open)
    constexpr int NSR = LO4 ? (NB * C::NS + NT - 1) / NT : 1;
@@ -1061,6 +1067,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // latency is covered by theirs -- so that a workgroup that does not raise it issues no atomic and waits for nothing
    // (a stale value only costs a redundant atomicMax)
    cg_known = HAS_HO ? *a.cg_iters : 0;
+   if (SUBL) { load_submesh(); }
 #pragma unroll
    for (int j = 0; j < NLX; j++)
    {
@@ -1091,16 +1098,19 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          if (k < NB * 27) { s_sti[k] = sti[j]; }
       }
    }
-   if (LO4 && a.rd_subcell)
-   {
-      // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
-#pragma unroll
-      for (int j = 0; j < NLSUB; j++)
+   auto store_submesh = [&]() {
+      if (LO4 && a.rd_subcell)
       {
-         const int k = tid + j * NT;
-         if (k < NB * 3 * D3) { RMH_W(k / (3 * D3))[C::oXs + k % (3 * D3)] = a.move ? fma(a.t, gsv[j], gsx[j]) : gsx[j]; }
+         // sub-mesh nodes x_sub(t) = x0_sub + t v_sub (remhos.cpp:1262-1274); x0_sub was set up once
+#pragma unroll
+         for (int j = 0; j < NLSUB; j++)
+         {
+            const int k = tid + j * NT;
+            if (k < NB * 3 * D3) { RMH_W(k / (3 * D3))[C::oXs + k % (3 * D3)] = a.move ? fma(a.t, gsv[j], gsx[j]) : gsx[j]; }
+         }
       }
-   }
+   };
+   if (!SUBL) { store_submesh(); }
    __syncthreads();
 
    RMH_STAMP(0);
@@ -1183,6 +1193,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       });
    }
    RMH_STAMP(1);
+   if (SUBL)
+   {
+      store_submesh();
+      __syncthreads();
+   }
    if (LO4)
    {
       // (before the face rows: their Bernstein-tested rows reuse the LDS of the sub-mesh nodes)

@@ -156,7 +156,7 @@ def test_state_checks_of_the_exchange_and_the_split_stage(emulib):
     from remhos_amd.case import Case, make_config
     from remhos_amd.stepper import Stepper
 
-    case = Case(emulib, make_config("periodic-cube", 1, 2, 10, -1.0, 0.5, self_wrap=1))
+    case = Case(emulib, make_config("periodic-cube", 0, 2, 10, -1.0, 0.5, self_wrap=1))
     st = Stepper(emulib, case, device="cpu")
     c, u, dt = st.ctx, st.x, case.dt
     assert st.transport == "local" and c.comm_count() == 0
