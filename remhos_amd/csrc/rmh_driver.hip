@@ -856,9 +856,11 @@ struct Block
 
 // ncclUniqueId rendezvous through a file.  Record = magic, launch tag, id.  The launch tag is what tells this launch's
 // file from a stale one (a path reused by a later run, or left by a crashed one): RMH_COMM_NONCE if the launcher exports
-// it, else the parent process id (ranks started by one shell loop / one torchrun agent share it).  Rank 0 removes a
-// stale file first, writes <path>.tmp and renames it; the others poll until they read a record with their tag that is
-// not older than five minutes.  Rank 0 deletes the file once ncclCommInitRank -- a collective -- has returned.
+// it (bench.py does), else the parent process id (ranks started by one shell loop / one torchrun agent share it; ranks started
+// through per-rank wrappers have different parents and NEED the nonce).  Rank 0 removes a stale file first, writes <path>.tmp
+// and renames it; the others poll until they read a record with their tag that is fresh: not older than five minutes with a
+// nonce, not older than the reader's own start (less 30 s) without.  Rank 0 deletes the file once ncclCommInitRank -- a
+// collective -- has returned.
 struct IdRecord
 {
    char magic[8];
@@ -871,6 +873,9 @@ long long launch_tag()
    if (const char *v = std::getenv("RMH_COMM_NONCE")) { return std::atoll(v); }
    return (long long)getppid();
 }
+// (without a nonce of the launcher the parent pid can repeat across launches of one shell: a reader then also refuses a
+// record that is older than its own start by more than half a minute -- a file left by an earlier, crashed launch)
+const std::time_t g_library_loaded = std::time(nullptr);
 
 bool read_or_write_id(const char *path, bool writer, char id[128])
 {
@@ -895,7 +900,8 @@ bool read_or_write_id(const char *path, bool writer, char id[128])
       {
          const bool ok = std::fread(&rec, sizeof(rec), 1, f) == 1 && fstat(fileno(f), &sb) == 0;
          std::fclose(f);
-         if (ok && std::memcmp(rec.magic, "RMHNCCL1", 8) == 0 && rec.tag == launch_tag() && std::time(nullptr) - sb.st_mtime < 300)
+         const bool fresh = std::getenv("RMH_COMM_NONCE") ? std::time(nullptr) - sb.st_mtime < 300 : sb.st_mtime + 30 >= g_library_loaded;
+         if (ok && std::memcmp(rec.magic, "RMHNCCL1", 8) == 0 && rec.tag == launch_tag() && fresh)
          {
             std::memcpy(id, rec.id, 128);
             return true;
