@@ -100,7 +100,7 @@ int create_tables(rmh_ctx *c)
    return upload(&c->d_tab, tab.data(), tab.size());
 }
 
-// face speed table of the kernels that read one (FaceGeo<P>::used): made on the context's stream the first time such
+// face speed table (every ho_kernel2 reads it): made on the context's stream the first time such
 // a kernel is launched
 template <int P>
 int ensure_face_table(rmh_ctx *c)
@@ -122,8 +122,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.gh_ustride = c->gh_ustride;
    a.gh_mstride = c->gh_mstride;
    a.gh_compact = c->gh_compact;
-   a.x0 = c->d_x0;
-   a.vel = c->d_vel;
+   a.x0 = c->d_x0h; // (ho_kernel2 takes the nodes in hierarchical form, see RMH_HIER in rmh_ho2.hpp)
+   a.vel = c->d_velh;
    a.face_nbr = c->d_nbr;
    a.tab = c->d_tab;
    a.subvel = c->d_subvel;
@@ -165,7 +165,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    {
       constexpr int P2 = P >= 2 ? P : 2; // subcell schemes need order >= 2 (checked by the callers)
       constexpr int NB = K2Cfg<P2, true>::NB;
-      if (FaceGeo<P2>::used(2))
+      // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P2>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
@@ -175,7 +175,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    else
    {
       constexpr int NB = K2Cfg<P>::NB;
-      if (FaceGeo<P>::used(0))
+      // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
@@ -196,8 +196,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.gh_ustride = c->gh_ustride;
    a.gh_mstride = c->gh_mstride;
    a.gh_compact = c->gh_compact;
-   a.x0 = c->d_x0;
-   a.vel = c->d_vel;
+   a.x0 = c->d_x0h; // (ho_kernel2 takes the nodes in hierarchical form, see RMH_HIER in rmh_ho2.hpp)
+   a.vel = c->d_velh;
    a.face_nbr = c->d_nbr;
    a.tab = c->d_tab;
    a.subvel = c->d_subvel;
@@ -242,7 +242,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P4, true, true>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
-      if (FaceGeo<P4>::used(3))
+      // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P4>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
@@ -254,7 +254,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
-      if (FaceGeo<P>::used(1))
+      // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
@@ -284,6 +284,29 @@ int create_device_state(rmh_ctx *c, const rmh_layout *L)
    int rc = 0;
    if ((rc = upload(&c->d_x0, L->x0, ne * 81))) { return rc; }
    if ((rc = upload(&c->d_vel, L->vel, ne * 81))) { return rc; }
+   {
+      // the same nodes in the hierarchical form of the quadratic Lagrange basis along the directions of the mask RMH_HIER, for
+      // ho_kernel2: (n0, n1 - n0, n2 - n0).  The set-up kernels (face table, sub-mesh, lumped mass) keep the nodal arrays.
+      std::vector<double> h(ne * 81);
+      for (const double *src : {L->x0, L->vel})
+      {
+         std::copy(src, src + ne * 81, h.begin());
+         for (size_t b = 0; b < ne * 3; b++) // (element, component) blocks of 27 nodes, index a + 3 b + 9 c
+         {
+            double *n = h.data() + b * 27;
+            for (int dir = 0; dir < 3; dir++)
+            {
+               if (!((RMH_HIER >> dir) & 1)) { continue; }
+               const int st = dir == 0 ? 1 : (dir == 1 ? 3 : 9);
+               for (int k = 0; k < 27; k++)
+               {
+                  if ((k / st) % 3 == 0) { n[k + st] -= n[k]; n[k + 2 * st] -= n[k]; }
+               }
+            }
+         }
+         if ((rc = upload(src == L->x0 ? &c->d_x0h : &c->d_velh, h.data(), ne * 81))) { return rc; }
+      }
+   }
    if ((rc = upload(&c->d_nbr, L->face_nbr, ne * 6))) { return rc; }
    if ((rc = upload(&c->d_st27, L->stencil27, ne * 27))) { return rc; }
    if (L->subcell_vel)
@@ -393,7 +416,7 @@ void rmh_destroy(rmh_ctx *c)
    if (!c) { return; }
    (void)hipSetDevice(c->device);
    exchange_free(c);
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {

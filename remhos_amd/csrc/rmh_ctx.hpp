@@ -40,6 +40,7 @@ struct rmh_ctx
    hipStream_t stream = nullptr;
    double t = 0.0;
    double *d_x0 = nullptr, *d_vel = nullptr, *d_tab = nullptr, *d_subvel = nullptr;
+   double *d_x0h = nullptr, *d_velh = nullptr; // x0, vel in the hierarchical node basis (what ho_kernel2 reads)
    double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
    double *d_fgeo = nullptr;                        // face speed coefficients (face_geom_kernel)
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;

@@ -266,6 +266,18 @@ __device__ inline double wave_bcast(double v)
 #ifndef RMH_FACE_MAJOR
 #define RMH_FACE_MAJOR (P == 3)
 #endif
+// The Q2 mesh nodes (and node velocities) reach the stage kernel in the HIERARCHICAL form of the quadratic Lagrange basis on
+// {0, 1/2, 1} along the directions of the bit mask RMH_HIER (1: x, 2: y, 4: z): (n0, n1 - n0, n2 - n0) -- a linear map,
+// applied once on the host when the context is made (rmh_api.hip), so x0 + t v stays what the kernel forms.  Along such a
+// direction the basis reads (1, L1, L2), its derivative (0, dL1, dL2) (the L sum to one, the dL to zero): a 1-D interpolation
+// of the geometry costs two FMAs instead of three.  x and z: 153 of the 958 FP64 instructions of a p = 3 quadrature column
+// (-16 % of the column pass, -7 % of the stage kernel's FP64 work; the same absolute saving per column and point at every
+// order).  y as well would save 36 more, but that form of the y-leg makes the compiler spill at every order but 4 (p = 6: 44
+// -> 484 B/lane of scratch, 20.7 k -> 12.7 k MDOFs*stage/s).  Same polynomial, evaluated from differences: results differ from
+// the nodal evaluation by round-off.
+#ifndef RMH_HIER
+#define RMH_HIER 5
+#endif
 #ifndef RMH_WAVE_DOT
 #define RMH_WAVE_DOT 1
 #endif
@@ -315,14 +327,12 @@ __device__ inline tabp_t<P> tab_view()
 #define RMH_TAB() tab_view<P>()
 #define RMH_TABK() (P >= RMH_VIEW_MINP ? tab_view<P>() : gtb)
 
-// The upwind face speeds can come from a table made once per context (face_geom_kernel): w_q v.n_out(q, t) is a quadratic
-// in the pseudo-time t (the mesh moves linearly), three coefficients per face quadrature point.
-//   0: never; 1: in every kernel; 2: where it pays -- everywhere but the p = 3 HO / lo 5 kernels, which run at the
-//   board's power limit: there the FP64 work saved and the HBM bytes added cancel (tools/power_probe.py: same
-//   throughput at 130 MHz lower clocks), and the table would more than double the stage's HBM traffic.
-#ifndef RMH_FACE_COEF
-#define RMH_FACE_COEF 2
-#endif
+// The upwind face speeds come from a table made once per context (face_geom_kernel): w_q v.n_out(q, t) is a quadratic in the
+// pseudo-time t (the mesh moves linearly), three coefficients per face quadrature point.  Rounds 2-3 kept the p = 3 HO / lo 5
+// kernels on the node-based face rows (~315 FMAs per row): at the board's power limit the FP64 work saved and the HBM bytes
+// added cancelled (tools/power_probe.py).  With the hierarchical nodes of the column pass (RMH_HIER) the table wins there too --
+// +2.0 ... +2.5 % over 100 steps, +4.6 % at -rs 4, +5.2 % with the converged mass solve -- and the node-based path is gone
+// (tools/experiments/r04_node_face_rows.patch).
 // x-leg basis rows of a thread's dofs in registers through the PCG loop (see ho_kernel2, phase G)
 #ifndef RMH_CBG_REG
 #define RMH_CBG_REG (DR * Q <= 12)
@@ -762,8 +772,6 @@ template <int P>
 struct FaceGeo
 {
    static constexpr int Q = K2Cfg<P>::Q, R = 6 * Q, PER_ELEM = 3 * Q * R;
-   // does ho_kernel2<P, MODE> read the table?
-   static constexpr bool used(int mode) { return RMH_FACE_COEF == 1 || (RMH_FACE_COEF == 2 && !(P == 3 && mode <= 1)); }
 };
 
 template <int P>
@@ -1043,15 +1051,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       }
    }
    // face speed coefficients of this thread's face rows (youngest loads: first used after the second barrier)
-   constexpr bool FC = FaceGeo<P>::used(MODE);
    // face-major order of the face rows of a multi-element workgroup: row index = (face, element, q1).  The lanes of an LDS
    // access group then work on ONE face of several elements -- the same node and trace offsets, element blocks apart (EL == 2
    // mod 32: different banks) -- instead of on several faces of one element, whose trace blocks (D^2 doubles apart) and face
    // nodes share banks (tools/pmc_variants.sh: the face rows were 30 % of the p = 3 stage's bank conflicts)
    constexpr bool FMJ = RMH_FACE_MAJOR && NB > 1;
+   constexpr bool HX = (RMH_HIER & 1) != 0, HY = (RMH_HIER & 2) != 0, HZ = (RMH_HIER & 4) != 0; // hierarchical directions of the mesh nodes
    constexpr int NFR = (NB * 6 * Q + NT - 1) / NT;
    double fgc[NFR][3 * Q];
-   if constexpr (FC)
    {
 #pragma unroll
       for (int jp = 0; jp < NFR; jp++)
@@ -1302,39 +1309,6 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       if (fr >= NB * 6 * Q) { break; }
       const int eb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q);
       const int f = FMJ ? fr / (NB * Q) : (fr % (6 * Q)) / Q, q1 = fr % Q;
-      const int c = f >> 1, side = f & 1;
-      const int c1 = axis_next(c), c2 = axis_next2(c);
-      double xd[3][3], xl[3][3], vl[3][3]; // [comp][a2]
-      double w1 = 0.0;
-      if constexpr (!FC)
-      {
-         // geometry of the face from the nodes: contraction along a1 for the three node rows a2
-         const int nc = axis_stride<3>(c), n1 = axis_stride<3>(c1), n2s = axis_stride<3>(c2);
-         const double *X = RMH_W(eb) + oXV + (side ? 2 * nc : 0);
-         const double *V = X + 81;
-         double L1[3], dL1[3];
-#pragma unroll
-         for (int k = 0; k < 3; k++) { L1[k] = stab[oL + q1 * 3 + k]; dL1[k] = stab[odL + q1 * 3 + k]; }
-#pragma unroll
-         for (int comp = 0; comp < 3; comp++)
-         {
-#pragma unroll
-            for (int a2 = 0; a2 < 3; a2++)
-            {
-               double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-               for (int a1 = 0; a1 < 3; a1++)
-               {
-                  const double x = X[comp * 27 + a1 * n1 + a2 * n2s];
-                  s0 += dL1[a1] * x;
-                  s1 += L1[a1] * x;
-                  s2 += L1[a1] * V[comp * 27 + a1 * n1 + a2 * n2s];
-               }
-               xd[comp][a2] = s0; xl[comp][a2] = s1; vl[comp][a2] = s2;
-            }
-         }
-         w1 = stab[oW + q1];
-      }
       // traces: contraction of the jumps u_nbr - u_own along i1
       const double *un = RMH_W(eb) + oNb + f * D2;
       double jr[D];
@@ -1353,35 +1327,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int q2 = 0; q2 < Q; q2++)
       {
          tabp gt = RMH_TABK();
-         double sq; // w_q1 w_q2 max(0, upw * v.n_out) at time t
-         if constexpr (FC)
-         {
-            sq = fmax(0.0, a.upw * (fgc[jp][3 * q2] + a.t * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
-         }
-         else
-         {
-            double t1[3], t2[3], vf[3];
-#pragma unroll
-            for (int comp = 0; comp < 3; comp++)
-            {
-               double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-               for (int a2 = 0; a2 < 3; a2++)
-               {
-                  const double L2 = gt[oL + q2 * 3 + a2], dL2 = gt[odL + q2 * 3 + a2];
-                  s0 += L2 * xd[comp][a2];
-                  s1 += dL2 * xl[comp][a2];
-                  s2 += L2 * vl[comp][a2];
-               }
-               t1[comp] = s0; t2[comp] = s1; vf[comp] = s2;
-            }
-            const double nx = t1[1] * t2[2] - t1[2] * t2[1];
-            const double ny = t1[2] * t2[0] - t1[0] * t2[2];
-            const double nz = t1[0] * t2[1] - t1[1] * t2[0];
-            double vn = vf[0] * nx + vf[1] * ny + vf[2] * nz;
-            if (!side) { vn = -vn; }
-            sq = fmax(0.0, a.upw * vn) * w1 * gt[oW + q2];
-         }
+         // w_q1 w_q2 max(0, upw * v.n_out) at time t: the face speed is a quadratic in t (face_geom_kernel)
+         const double sq = fmax(0.0, a.upw * (fgc[jp][3 * q2] + a.t * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
          double jump = 0.0;
 #pragma unroll
          for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
@@ -1519,13 +1466,18 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                   const double *xr = XN + comp * 27 + 3 * (ay + 3 * az);
                   const double x0n = xr[0], x1n = xr[1], x2n = xr[2];
                   const double v0n = xr[81], v1n = xr[82], v2n = xr[83];
-                  const double xl = Lx[0] * x0n + Lx[1] * x1n + Lx[2] * x2n;
-                  const double xd = dLx[0] * x0n + dLx[1] * x1n + dLx[2] * x2n;
-                  const double vl = Lx[0] * v0n + Lx[1] * v1n + Lx[2] * v2n;
-                  a0 += Ly[ay] * xd;
-                  a1 += dLy[ay] * xl;
-                  a2 += Ly[ay] * xl;
-                  a3 += Ly[ay] * vl;
+                  // (hierarchical nodes, RMH_HIER: basis (1, L1, L2), derivative (0, dL1, dL2), along x and along y)
+                  const double xl = HX ? x0n + Lx[1] * x1n + Lx[2] * x2n : Lx[0] * x0n + Lx[1] * x1n + Lx[2] * x2n;
+                  const double xd = HX ? dLx[1] * x1n + dLx[2] * x2n : dLx[0] * x0n + dLx[1] * x1n + dLx[2] * x2n;
+                  const double vl = HX ? v0n + Lx[1] * v1n + Lx[2] * v2n : Lx[0] * v0n + Lx[1] * v1n + Lx[2] * v2n;
+                  if (HY && ay == 0) { a0 = xd; a2 = xl; a3 = vl; }
+                  else
+                  {
+                     a0 += Ly[ay] * xd;
+                     a1 += dLy[ay] * xl;
+                     a2 += Ly[ay] * xl;
+                     a3 += Ly[ay] * vl;
+                  }
                }
                A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2; A[comp][3][az] = a3;
             }
@@ -1540,8 +1492,9 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             for (int comp = 0; comp < 3; comp++)
             {
                double j0 = 0, j1 = 0, j2 = 0, vv = 0;
+               if (HZ) { j0 = A[comp][0][0]; j1 = A[comp][1][0]; vv = A[comp][3][0]; }
 #pragma unroll
-               for (int az = 0; az < 3; az++)
+               for (int az = HZ ? 1 : 0; az < 3; az++)
                {
                   const double Lz = T3(gt, oL, qz, az), dLz = T3(gt, odL, qz, az);
                   j0 += Lz * A[comp][0][az];

@@ -113,8 +113,9 @@ def test_stage_parity(gpu, mesh, rs, p, prob, t):
         ctypes.c_void_p(m2.data_ptr()), ctypes.c_void_p(mptr), ctypes.c_size_t(m.numel() * 8), 3
     )
     torch.cuda.synchronize()
-    # (two kernels with their own operation order: the stage kernel's by-product and lumped_mass_kernel)
-    assert _relerr(m2.cpu().numpy(), m.cpu().numpy()) < 1e-14
+    # (two kernels with their own operation order: the stage kernel's by-product -- geometry from the hierarchical form of the
+    # nodes since round 4 -- and lumped_mass_kernel, nodal; measured 1.7e-14, both are held to 1e-13 against the oracle above)
+    assert _relerr(m2.cpu().numpy(), m.cpu().numpy()) < 1e-13
     ctx.close()
 
 
