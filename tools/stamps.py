@@ -15,9 +15,9 @@ rs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 maxit = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 lo = int(sys.argv[4]) if len(sys.argv) > 4 else 5
-nb = {1: 16, 2: 10, 3: 7, 4: 1, 5: 1, 6: 1}[order]
+nb = {1: 16, 2: 9, 3: 7, 4: 1, 5: 1, 6: 1}[order]
 if lo != 5:
-    nb = {2: 9, 3: 6, 4: 1, 5: 1, 6: 1}[order]
+    nb = {2: 9, 3: 7, 4: 1, 5: 1, 6: 1}[order]
 st = Stepper(lib, Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5, lo_type=lo)), device="cuda:0")
 if maxit > 0:
     st.ctx.set_mass_tol(1e-14, 0.0, maxit)  # converged (or capped) solve
