@@ -32,10 +32,11 @@ namespace rmh
 // traces stored as values, per-dof back-transform and x-leg, whole second wavefront for the 17 extra columns of p = 6, ...)
 // are kept as patches with their numbers under tools/experiments/, not as dead branches of the product kernel.
 //
-// adj(J) v and det J through two cross products in the column phase: a small measured gain at p = 3 only (at p = 6 the
-// different register lifetimes cost 8 %)
+// adj(J) v and det J through two cross products in the column phase (24 instead of 30 operations per quadrature point).  Round 3:
+// a gain at p = 3 only (at p = 6 the different register lifetimes cost 8 %); re-measured with the hierarchical nodes of round 4:
+// p = 4, 5 +1.0 %, p = 6 +0.2 %, p = 2 -0.5 %
 #ifndef RMH_ADJ_CROSS
-#define RMH_ADJ_CROSS (P == 3)
+#define RMH_ADJ_CROSS (P >= 3)
 #endif
 // fresh views of the constant table per unrolled quadrature plane from this order on (see tab_view)
 #ifndef RMH_VIEW_MINP
