@@ -21,6 +21,7 @@ ap.add_argument("--rs", type=int, default=5)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--lo", type=int, default=5)
 ap.add_argument("--mesh", default="periodic-cube")
+ap.add_argument("--problem", type=int, default=10, help="10: remap (default); 0: transport on a static mesh")
 ap.add_argument("--exact", action="store_true", help="converged local mass solve instead of the -pa rule")
 ap.add_argument("names", nargs="+")
 args = ap.parse_args()
@@ -29,7 +30,7 @@ ref = None
 for name in args.names:
     path = os.path.join(root, "remhos_amd", f"librmh_{name}.so" if name not in ("", "main") else "librmh.so")
     lib = bind_driver(load_library(path))
-    case = Case(lib, make_config(args.mesh, args.rs, args.order, 10, -1.0, 0.5, lo_type=args.lo, pa=0 if args.exact else 1))
+    case = Case(lib, make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, lo_type=args.lo, pa=0 if args.exact else 1))
     st = Stepper(lib, case, device="cuda:0")
     for _ in range(2):
         st.step(case.dt)
