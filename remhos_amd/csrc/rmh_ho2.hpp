@@ -1067,8 +1067,12 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          const int fr = min(frt + jp * NT, NB * 6 * Q - 1);
          const int feb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q), frow = FMJ ? (fr / (NB * Q)) * Q + fr % Q : fr % (6 * Q);
          const double *fg = a.fgeo + (size_t)min(e0 + feb, a.e_end - 1) * FaceGeo<P>::PER_ELEM + frow;
+         // (a static mesh -- transport -- has c1 = c2 = 0: their loads are pointed at the c0 row, which is in the cache anyway, and
+         // the face rows multiply them by zero; straight-line loads either way: a.move is uniform over the launch)
+         // (+3.8 % for transport at p = 3, remap +-0; not at p >= 4, where the extra scalar arithmetic of the 21-27 loads costs remap 0.4-0.7 %)
+         const int mv = (a.move || P >= 4) ? 1 : 0;
 #pragma unroll
-         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[k * 6 * Q]; }
+         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[(k - (1 - mv) * (k % 3)) * 6 * Q]; }
       }
    }
    // diagnostic: the largest iteration count so far, read here -- behind the element loads, a uniform load whose
@@ -1300,6 +1304,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    }
    __syncthreads();
    RMH_STAMP(25);
+   const double t_move = (a.move || P >= 4) ? a.t : 0.0; // (static mesh: the face speed is its value at t = 0; p >= 4 reads the zero coefficients)
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
    //   val(q) = w_q max(0, upw * v.n_out) (u_nbr - u_own)(q)      
    // and tests it along q2 with the GL nodal basis -> sFq[eb][(f*Q + q1)*D + k2]
@@ -1329,7 +1334,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       {
          tabp gt = RMH_TABK();
          // w_q1 w_q2 max(0, upw * v.n_out) at time t: the face speed is a quadratic in t (face_geom_kernel)
-         const double sq = fmax(0.0, a.upw * (fgc[jp][3 * q2] + a.t * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
+         const double sq = fmax(0.0, a.upw * (fgc[jp][3 * q2] + t_move * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
          double jump = 0.0;
 #pragma unroll
          for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
