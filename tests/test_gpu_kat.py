@@ -51,7 +51,11 @@ def test_reference_final_mass(lib, name, kw, mass_ref, rtol, fused, pa):
 
 
 @pytest.mark.parametrize("mesh,rs,p,prob,steps", [("periodic-cube", 1, 3, 10, 4), ("cube01_hex", 2, 2, 10, 3),
-                                                  ("periodic-cube", 1, 2, 0, 6), ("cube01_hex", 1, 4, 10, 2)])
+                                                  ("periodic-cube", 1, 2, 0, 6), ("cube01_hex", 1, 4, 10, 2),
+                                                  # transport at p = 3 (round 4: the face speed table serves this kernel too); 6
+                                                  # steps -- at the reference's step this case also amplifies rounding differences
+                                                  # (5e-11 after 7 steps at -rs 1, 2e-8 after 12 at -rs 2, for every kernel variant)
+                                                  ("periodic-cube", 1, 3, 0, 6)])
 def test_run_vs_oracle(lib, mesh, rs, p, prob, steps):
     """final mass, max and the field itself after several RK3 steps: GPU path vs CPU oracle.
     Tolerances: mass 1e-12 relative (BASELINE target), field 1e-10 in max norm (the error of
