@@ -55,6 +55,8 @@ def test_rccl_selfloop_cpp_driver(lib, tmp_path):
         assert not (tmp_path / "rmh.id").exists()
         assert (loop.steps, loop.stages, loop.global_dofs) == (one.steps, one.stages, one.global_dofs)
         assert loop.timed_stages == 3 * (5 - 2) and loop.transport == 1 and loop.n_peers == 1
+        assert loop.comm_ranks == 1  # ncclCommCount of the library's communicator (rmh_comm_count)
+        assert loop.t_rhs > 0 and loop.fom_rhs > 0  # sampled TimingData events, scaled to all timed steps
         assert loop.send_bytes_per_stage == loop.recv_bytes_per_stage > 0
         assert loop.max_value == one.max_value
         assert abs(loop.final_mass - one.final_mass) < 1e-13 and abs(loop.mass0 - one.mass0) < 1e-13  # (host sums in different element orders)
