@@ -159,6 +159,7 @@ struct K2Cfg : TabLayout<P>
 #ifndef RMH_WAVES5
 #define RMH_WAVES5 3
 #endif
+   // (p = 4, round 4: four wavefronts per SIMD -- 128 VGPRs, 140 B/lane of scratch -- 20.8 k -> 17.4 k MDOFs*stage/s on cube01_hex -rs 5)
    // (lo 4 at p = 6, round 4: with the slim layout below the kernel's LDS admits a fifth workgroup per CU, i.e. 2.5 wavefronts per
    // SIMD; asking for 3 gives 168 VGPRs + 76 B/lane of scratch and 10.0 k instead of 11.7 k MDOFs*stage/s -- it stays at 2)
    static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0));
