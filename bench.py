@@ -443,6 +443,78 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     return res
 
 
+def granular_block(args, lib, world, rank, dev, dist, backend):
+    """The reference's own call sequence at the plug-in boundary (remhos.cpp:1692, 1815-1831): CalcHOSolution, CalcLOSolution,
+    ComputeElementsMinMax + ComputeBounds, CalcFCTSolution as separate kernels, the RK vector updates by the caller (torch) --
+    what a binding that only replaces the three solver classes gets -- and the HO kernel + fused limiter.
+    The limiter-side kernels stream every E-vector once: each is priced against its algorithmic HBM bytes (8 B x dofs x
+    vectors read and written, + the stencil table), timed alone with HIP events on the context's stream."""
+    import copy
+
+    import torch
+
+    from remhos_amd.stepper import Stepper
+
+    a2 = copy.copy(args)
+    a2.unfused = True
+    seq = measure(a2, lib, args.order, args.rs, world, rank, dev, dist, backend, with_counters=False)
+    a3 = copy.copy(args)
+    a3.two_kernels = True
+    two = measure(a3, lib, args.order, args.rs, world, rank, dev, dist, backend, with_counters=False)
+    case = next(iter(_CASES.values()))
+    st = Stepper(lib, case, device=dev, fused=False)
+    (rel, ab, mit, jac, fix), _ = MASS_SOLVE[args.mass_solve]
+    st.ctx.set_mass_tol(rel, ab, mit)
+    st.ctx.set_mass_completion(jac, fix)
+    for _ in range(2):
+        st.step(case.dt)
+    ctx, u, dt = st.ctx, st.x, case.dt
+    n, ne = case.ne_owned * case.ndof, case.ne_owned
+    f64 = dict(dtype=torch.float64, device=u.device)
+    du_ho, du_lo, du, umin, umax, y = (torch.empty(n, **f64) for _ in range(6))
+    xe_min, xe_max = torch.empty(ne, **f64), torch.empty(ne, **f64)
+    ctx.setup(st.t)
+    ctx.ho_apply(u, du_ho)
+    m_ptr = ctx.lumped_mass_ptr()
+    vec, sten = 8.0 * n, 4.0 * 27 * ne
+    rows = [
+        ("elem_minmax_kernel", "ComputeElementsMinMax (remhos_tools.cpp:497-523)", lambda: ctx.elem_minmax(u, xe_min, xe_max), vec + 16.0 * ne),
+        ("bounds_kernel", "ComputeBounds (remhos_tools.cpp:432-495)", lambda: ctx.bounds(xe_min, xe_max, umin, umax), 2 * vec + sten + 16.0 * ne),
+        ("lo_massavg_kernel", "MassBasedAvg::CalcLOSolution (remhos_lo.cpp:247-324)", lambda: ctx.lo_massavg(u, du_ho, dt, du_lo), 4 * vec),
+        ("fct_clipscale_kernel", "ClipScaleSolver::CalcFCTSolution (remhos_fct.cpp:449-541)",
+         lambda: ctx.fct_clipscale(u, m_ptr, du_ho, du_lo, umin, umax, dt, du), 7 * vec),
+        ("limit_fused_kernel", "LimitMult + RK update in one pass (remhos.cpp:1798-1845)",
+         lambda: ctx.limit_fused(u, du_ho, dt, x_base=u, a=0.75, b=0.25, dt_rk=dt, y_out=y), 5 * vec + sten),
+    ]
+    kern = {}
+    reps = 20
+    for name, what, fn, nbytes in rows:
+        for _ in range(3):
+            fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / reps
+        kern[name] = {"replaces": what, "avg_launch_ms": ms, "alg_bytes_per_launch": nbytes, "bound": "hbm",
+                      "achieved": nbytes / (1e9 * ms) * 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (1e6 * ms) / HBM_PEAK_GBS}
+    st.close()
+    del st
+    torch.cuda.empty_cache()
+    keep = ("value", "ms_per_step", "buckets_s", "fom_reference_style")
+    return {"what": "the same workload through the GRANULAR entry points of the C ABI: the reference's call sequence "
+                    "(rmh_ho_apply, rmh_lo_massavg, rmh_elem_minmax, rmh_bounds, rmh_fct_clipscale; RK updates by the caller) "
+                    "and HO kernel + fused limiter (rmh_ho_apply, rmh_limit_fused)",
+            "unit": "MDOFs*RK-stage/s", "steps": args.steps, "warmup": args.warmup,
+            "reference_call_sequence": {k: seq[k] for k in keep},
+            "ho_plus_fused_limiter": {k: two[k] for k in keep},
+            "ho_kernel": {"kernel": f"rmh::ho_kernel2<{args.order}, 0>", "avg_launch_ms": 1e3 * two["buckets_s"]["ho_rhs_plus_inv_or_stage"] / (3 * args.steps)},
+            "streaming_kernels": kern,
+            "timing": f"each streaming kernel alone, {reps} launches between two HIP events on the context's stream, after 2 RK steps"}
+
+
 def measure_cpp_loop(args, lib, world, rank, device, comm_file):
     """N > 1: the C++ stage loop (rmhd_run_partitioned, remhos_amd/csrc/rmh_driver.hip) -- one process per GPU, the
     halo exchange as grouped RCCL send/recv inside the library, no Python between the launches (at N = 8 strong
@@ -709,6 +781,10 @@ def main():
                      "note": "the mesh keeps moving: later stages of the remap need the same work per element; a clock or power limit "
                              "would show as step times rising with the sample's power at the cap and sclk falling"}
 
+    granular = None
+    if extras and default_case and args.lo == 5 and world == 1 and not args.unfused and not args.two_kernels:
+        granular = granular_block(args, lib, world, rank, dev, dist, backend)
+
     lo4 = None
     if extras and default_case and args.lo == 5:
         # the LO solver BASELINE.json's north_star names: subcell residual distribution (-lo 4) in the one-kernel stage
@@ -758,6 +834,8 @@ def main():
             out["sustained"] = sustained
         if lo4 is not None:
             out["lo4"] = lo4
+        if granular is not None:
+            out["granular"] = granular
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, args.order, args.rs, args.mass_solve)
         print(json.dumps(out), flush=True)

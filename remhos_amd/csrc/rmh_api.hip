@@ -3,6 +3,7 @@
 #include "rmh_ctx.hpp"
 #include "rmh_kernels.hpp"
 #include "rmh_ho2.hpp"
+#include "rmh_stream.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -556,8 +557,8 @@ int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)
 {
    if (!c || !u || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
-   RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
-                                      xe_min, xe_max));
+   RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::U8)), dim3(SCfg<P>::NT), 0,
+                                      c->stream, u, xe_min, xe_max, c->ne));
    RMH_HIP(hipGetLastError());
    return RMH_OK;
 }
@@ -568,9 +569,10 @@ int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u
    RMH_ENTER(c);
    extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
-   RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
+   const int wide = (((uintptr_t)u_min | (uintptr_t)u_max) & 15) == 0; // 16-byte stores
+   RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::UB)), dim3(SCfg<P>::NT), 0, c->stream,
                                       c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
-                                      u_max));
+                                      u_max, wide));
    RMH_HIP(hipGetLastError());
    return RMH_OK;
 }
@@ -669,7 +671,7 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    EventPair ep;
    int rc = timer_begin(c, 3, ep);
    if (rc) { return rc; }
-   RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, la));
+   RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::U4)), dim3(SCfg<P>::NT), 0, c->stream, la));
    RMH_HIP(hipGetLastError());
    return timer_end(c, 3, ep);
 }

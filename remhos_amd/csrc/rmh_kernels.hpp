@@ -77,6 +77,21 @@ struct HoArgs
    double *dt_est;                  // null, or the running minimum of UpdateTimeStepEstimate
 };
 
+// Stores of E-vectors that are not read again before they have left the caches -- every output of the streaming kernels:
+// nontemporal.  Measured (tools/gbench.py, -rs 5, p = 3): the write-only bounds kernel 275 -> 163 us (3.7 -> 6.2 TB/s),
+// ClipScale 554 -> 527 us, the fused limiter 392 -> 385 us; p = 4, 5 alike, the mass-based average +-3 %.
+#ifndef RMH_NT_STORES
+#define RMH_NT_STORES 1
+#endif
+__device__ inline void store_stream(double *p, double x) // an output that is not read again soon
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RMH_NT_STORES
+   __builtin_nontemporal_store(x, p);
+#else
+   *p = x;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // block-wide reductions (one or two wavefronts)
 // ---------------------------------------------------------------------------------------
@@ -239,73 +254,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) lumped_mass_kernel(const double *
    }
 }
 
-// ---------------------------------------------------------------------------------------
-// Element extrema: DofInfo::ComputeElementsMinMax (remhos_tools.cpp:497-523)
-// ---------------------------------------------------------------------------------------
-template <int P>
-__global__ void __launch_bounds__(KCfg<P>::NT) elem_minmax_kernel(const double *u, double *xe_min, double *xe_max)
-{
-   using C = KCfg<P>;
-   __shared__ double s_red[4];
-   const int e = blockIdx.x;
-   double lmin = INFINITY, lmax = -INFINITY;
-   for (int i = threadIdx.x; i < C::D3; i += C::NT)
-   {
-      const double v = u[(size_t)e * C::D3 + i];
-      lmin = fmin(lmin, v);
-      lmax = fmax(lmax, v);
-   }
-   lmin = block_min<C::NW>(lmin, s_red);
-   lmax = block_max<C::NW>(lmax, s_red);
-   if (threadIdx.x == 0) { xe_min[e] = lmin; xe_max[e] = lmax; }
-}
-
-// per-dof overlap bounds from the 27-element stencil held in LDS (smin/smax[27]):
-// a dof on the low/high face layer of direction c also sees the -1/+1 neighbours in c
-template <int P>
-__device__ inline void dof_bounds(int i, const double *smin, const double *smax, double &lo, double &hi)
-{
-   constexpr int D = P + 1;
-   const int idx[3] = {i % D, (i / D) % D, i / (D * D)};
-   int olo[3], ohi[3];
-#pragma unroll
-   for (int c = 0; c < 3; c++)
-   {
-      olo[c] = (idx[c] == 0) ? -1 : 0;
-      ohi[c] = (idx[c] == P) ? 1 : 0;
-   }
-   lo = INFINITY;
-   hi = -INFINITY;
-   for (int oz = olo[2]; oz <= ohi[2]; oz++)
-   {
-      for (int oy = olo[1]; oy <= ohi[1]; oy++)
-      {
-         for (int ox = olo[0]; ox <= ohi[0]; ox++)
-         {
-            const int s = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1);
-            lo = fmin(lo, smin[s]);
-            hi = fmax(hi, smax[s]);
-         }
-      }
-   }
-}
-
-// DofInfo::ComputeBounds (remhos_tools.hpp:168-182): bounds type 0 = overlap bounds above, 1 = the element
-// and its face neighbours (ComputeMatrixSparsityBounds, remhos_tools.cpp:381-430), one interval per element
-template <int P>
-__device__ inline void dof_bounds_bt(int bt, int i, const double *smin, const double *smax, double &lo, double &hi)
-{
-   if (bt == 0) { dof_bounds<P>(i, smin, smax, lo, hi); return; }
-   constexpr int fs[7] = {13, 12, 14, 10, 16, 4, 22};
-   lo = INFINITY;
-   hi = -INFINITY;
-#pragma unroll
-   for (int k = 0; k < 7; k++)
-   {
-      lo = fmin(lo, smin[fs[k]]);
-      hi = fmax(hi, smax[fs[k]]);
-   }
-}
+// (ComputeElementsMinMax, ComputeBounds and the fused LimitMult are wavefront-per-element streaming kernels: rmh_stream.hpp)
 
 // AdvectionOperator::UpdateTimeStepEstimate (remhos.cpp:1968-1998) for one dof: the largest dt with
 // x_min <= x + dt*dx <= x_max (+inf when |dx| <= 1e-12)
@@ -325,45 +274,6 @@ __device__ inline void atomic_min_nonneg(double *p, double v)
    if (v < __builtin_nontemporal_load(p))
    {
       atomicMin((unsigned long long *)p, (unsigned long long)__double_as_longlong(v));
-   }
-}
-
-__device__ inline void load_stencil(int e, int ne_owned, const int *stencil27, const double *xe_min,
-                                    const double *xe_max, const double *gh_min, const double *gh_max, int gh_mstride,
-                                    double *smin, double *smax)
-{
-   const int tid = threadIdx.x;
-   if (tid < 27)
-   {
-      const int nb = stencil27[(size_t)e * 27 + tid];
-      double lo = INFINITY, hi = -INFINITY;
-      if (nb >= 0)
-      {
-         if (nb < ne_owned) { lo = xe_min[nb]; hi = xe_max[nb]; }
-         else { lo = gh_min[(size_t)(nb - ne_owned) * gh_mstride]; hi = gh_max[(size_t)(nb - ne_owned) * gh_mstride]; }
-      }
-      smin[tid] = lo;
-      smax[tid] = hi;
-   }
-}
-
-// DofInfo::ComputeBounds -> ComputeOverlapBounds (remhos_tools.cpp:432-495)
-template <int P>
-__global__ void __launch_bounds__(KCfg<P>::NT) bounds_kernel(int bt, const int *stencil27, int ne_owned, const double *xe_min,
-                                                             const double *xe_max, const double *gh_min,
-                                                             const double *gh_max, int gh_mstride, double *u_min, double *u_max)
-{
-   using C = KCfg<P>;
-   __shared__ double smin[27], smax[27];
-   const int e = blockIdx.x;
-   load_stencil(e, ne_owned, stencil27, xe_min, xe_max, gh_min, gh_max, gh_mstride, smin, smax);
-   __syncthreads();
-   for (int i = threadIdx.x; i < C::D3; i += C::NT)
-   {
-      double lo, hi;
-      dof_bounds_bt<P>(bt, i, smin, smax, lo, hi);
-      u_min[(size_t)e * C::D3 + i] = lo;
-      u_max[(size_t)e * C::D3 + i] = hi;
    }
 }
 
@@ -466,7 +376,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) lo_massavg_kernel(const double *u
    for (int k = 0; k < C::DPT; k++)
    {
       const int i = threadIdx.x + k * C::NT;
-      if (i < C::D3) { du_lo[(size_t)e * C::D3 + i] = (ubar - uu[k]) / dt; }
+      if (i < C::D3) { store_stream(du_lo + (size_t)e * C::D3 + i, (ubar - uu[k]) / dt); }
    }
 }
 
@@ -516,7 +426,7 @@ __global__ void __launch_bounds__(KCfg<P>::NT) fct_clipscale_kernel(const double
          double fc = f[k];
          if (new_mass > eps) { fc = fmin(0.0, fc) - fmax(0.0, fc) * sumNeg / sumPos; }
          if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos / sumNeg; }
-         du[(size_t)e * C::D3 + i] = dl[k] + fc / mm[k];
+         store_stream(du + (size_t)e * C::D3 + i, dl[k] + fc / mm[k]);
       }
    }
 }
@@ -723,86 +633,5 @@ __global__ void __launch_bounds__(256) dt_estimate_kernel(const double *x, const
    if (threadIdx.x == 0) { atomic_min_nonneg(dt_est, c); }
 }
 
-template <int P>
-__global__ void __launch_bounds__(KCfg<P>::NT) limit_fused_kernel(LimitArgs a)
-{
-   using C = KCfg<P>;
-   __shared__ double s_red[4];
-   __shared__ double smin[27], smax[27];
-   const int e = blockIdx.x;
-   constexpr double eps = 1.0e-15;
-   load_stencil(e, a.ne_owned, a.stencil27, a.xe_min, a.xe_max, a.gh_min, a.gh_max, a.gh_mstride, smin, smax);
-   double uu[C::DPT], mm[C::DPT], dh[C::DPT];
-   double mass = 0.0, vol = 0.0;
-#pragma unroll
-   for (int k = 0; k < C::DPT; k++)
-   {
-      const int i = threadIdx.x + k * C::NT;
-      uu[k] = 0.0; mm[k] = 1.0; dh[k] = 0.0;
-      if (i < C::D3)
-      {
-         const size_t g = (size_t)e * C::D3 + i;
-         uu[k] = a.u[g];
-         mm[k] = a.m[g];
-         dh[k] = a.du_ho[g];
-         mass += mm[k] * (uu[k] + a.dt * dh[k]);
-         vol += mm[k];
-      }
-   }
-   __syncthreads(); // stencil in LDS
-   mass = block_sum<C::NW>(mass, s_red);
-   vol = block_sum<C::NW>(vol, s_red);
-   const double ubar = mass / vol;
-   double f[C::DPT], dl[C::DPT];
-   double sumPos = 0.0, sumNeg = 0.0, dtc = INFINITY;
-#pragma unroll
-   for (int k = 0; k < C::DPT; k++)
-   {
-      const int i = threadIdx.x + k * C::NT;
-      f[k] = 0.0; dl[k] = 0.0;
-      if (i < C::D3)
-      {
-         double lo, hi;
-         dof_bounds_bt<P>(a.bounds_type, i, smin, smax, lo, hi);
-         dl[k] = a.du_lo ? a.du_lo[(size_t)e * C::D3 + i] : (ubar - uu[k]) / a.dt;
-         dtc = fmin(dtc, dt_candidate(uu[k], dl[k], lo, hi));
-         const double u_new_lo = uu[k] + a.dt * dl[k];
-         const double f_clip_min = mm[k] / a.dt * (lo - u_new_lo);
-         const double f_clip_max = mm[k] / a.dt * (hi - u_new_lo);
-         double fc = mm[k] * (dh[k] - dl[k]);
-         fc = fmin(f_clip_max, fmax(f_clip_min, fc));
-         f[k] = fc;
-         sumNeg += fmin(fc, 0.0);
-         sumPos += fmax(fc, 0.0);
-      }
-   }
-   sumNeg = block_sum<C::NW>(sumNeg, s_red);
-   sumPos = block_sum<C::NW>(sumPos, s_red);
-   if (a.dt_est)
-   {
-      dtc = block_min<C::NW>(dtc, s_red);
-      if (threadIdx.x == 0) { atomic_min_nonneg(a.dt_est, dtc); }
-   }
-   const double new_mass = sumNeg + sumPos;
-#pragma unroll
-   for (int k = 0; k < C::DPT; k++)
-   {
-      const int i = threadIdx.x + k * C::NT;
-      if (i < C::D3)
-      {
-         const size_t g = (size_t)e * C::D3 + i;
-         double fc = f[k];
-         if (new_mass > eps) { fc = fmin(0.0, fc) - fmax(0.0, fc) * sumNeg / sumPos; }
-         if (new_mass < -eps) { fc = fmax(0.0, fc) - fmin(0.0, fc) * sumPos / sumNeg; }
-         const double dui = dl[k] + fc / mm[k];
-         if (a.du) { a.du[g] = dui; }
-         if (a.y_out)
-         {
-            const double y = uu[k] + a.dt_rk * dui;
-            a.y_out[g] = (a.x_base ? a.a * a.x_base[g] : 0.0) + a.b * y;
-         }
-      }
-   }
-}
 
 } // namespace rmh
