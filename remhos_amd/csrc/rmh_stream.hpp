@@ -265,14 +265,20 @@ __global__ void __launch_bounds__(SCfg<P>::NT) elem_minmax_kernel(const double *
       }
       wave_reduce_multi<OpMin, U>(lo);
       wave_reduce_multi<OpMax, U>(hi);
-      // element j's results sit in row red_row(j) of vector red_vec(j): the first lane of that row stores them
+      // element j's results sit in row red_row(j) of vector red_vec(j): the first lanes of the rows of a vector store
+      // together (one store instruction per vector and array, not one per element)
+      constexpr int NV = U == 8 ? 2 : 1;        // vectors
+      constexpr int RS = U >= 4 ? 16 : (U == 2 ? 32 : 64); // lanes per element in a vector
+      const int grp = lane / RS;
+      const int jv = U >= 4 ? ((grp == 1) ? 2 : ((grp == 2) ? 1 : grp)) : grp; // the element of this lane's rows within its vector
 #pragma unroll
-      for (int j = 0; j < U; j++)
+      for (int v4 = 0; v4 < NV; v4++)
       {
-         if (lane == 16 * red_row<U>(j) && e0 + j < ne)
+         const int e = e0 + 4 * v4 + jv;
+         if ((lane & (RS - 1)) == 0 && e < ne)
          {
-            xe_min[e0 + j] = lo[red_vec<U>(j)];
-            xe_max[e0 + j] = hi[red_vec<U>(j)];
+            xe_min[e] = lo[v4];
+            xe_max[e] = hi[v4];
          }
       }
    }

@@ -67,6 +67,7 @@ class Stepper:
             self.xe_min = torch.empty(ne, **f64)
             self.xe_max = torch.empty(ne, **f64)
             self.m = torch.empty_like(self.x)
+            self.du = torch.empty_like(self.x)
         self.t = 0.0
         self.dt = case.dt
         self.tok_x = 0  # token of the element extrema of self.x (rmh_stage_fused_chain); 0: none
@@ -220,14 +221,20 @@ class Stepper:
             c.lo_massavg(u, self.k, dt, self.du_lo)
         c.elem_minmax(u, self.xe_min, self.xe_max)
         c.bounds(self.xe_min, self.xe_max, self.umin, self.umax)
-        du = torch.empty_like(u)
+        du = self.du
         c.fct_clipscale(u, m, self.k, self.du_lo, self.umin, self.umax, dt, du)
         c.dt_estimate_update(u, self.du_lo, self.umin, self.umax)  # remhos.cpp:1839-1842 (no-op with a fixed dt)
-        y = u + dt * du
-        if x_base is None:
-            out.copy_(b * y)
+        # the RK vector update is the caller's (MFEM's RK3SSPSolver: add / Add on Vectors): out = a x_base + b (u + dt du),
+        # in place in du -- no temporaries
+        if x_base is None and b == 1.0:
+            torch.add(u, du, alpha=dt, out=out)
         else:
-            out.copy_(a * x_base + b * y)
+            torch.add(u, du, alpha=dt, out=du)
+            du.mul_(b)
+            if x_base is None:
+                out.copy_(du)
+            else:
+                torch.add(du, x_base, alpha=a, out=out)
         return 0
 
     def step(self, dt):

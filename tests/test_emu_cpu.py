@@ -58,6 +58,52 @@ def test_kernels_vs_oracle(lib, mesh, rs, p, prob, t):
     ctx.close()
 
 
+@pytest.mark.parametrize("p,bt", [(1, 1), (2, 0), (3, 1), (4, 0), (4, 1), (5, 0), (6, 0)])
+def test_streaming_kernels_every_order(lib, p, bt):
+    """The wavefront-per-element streaming kernels (rmh_stream.hpp: element extrema, bounds, fused limiter) at every order --
+    one to six dof rounds per wavefront, 1 ... 8 elements per pass, a last pass that is not full (27 elements), both bounds
+    types, the limiter with its own mass-based average and with a given LO rate -- against the oracle's bounds (bit for bit)
+    and against the granular ClipScale kernel on the same inputs.  No HO kernel: du_HO is synthetic."""
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh="periodic-cube", rs=0, order=p, problem=0, dt=0.02, t_final=0.7, lo=5, bounds_type=bt)
+    r = Remhos(cfg)
+    x0, vel, nbr, st = layout_from_oracle(r)
+    ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+    ctx.set_bounds_type(bt)
+    rng = np.random.default_rng(7 + p)
+    u = perturbed(r.u)
+    ne, nd = u.shape
+    xmn, xmx = np.zeros(ne), np.zeros(ne)
+    ctx.elem_minmax(u, xmn, xmx)
+    assert np.array_equal(xmn, u.min(axis=1)) and np.array_equal(xmx, u.max(axis=1))
+    umin, umax = np.zeros_like(u), np.zeros_like(u)
+    ctx.bounds(xmn, xmx, umin, umax)
+    omin, omax = r.bounds_from_extrema(xmn, xmx)
+    assert np.array_equal(umin, omin.reshape(u.shape)) and np.array_equal(umax, omax.reshape(u.shape))
+    # limiter: HO rate = anything; the lumped mass and the state flag come from rmh_ho_apply
+    ctx.setup(0.0)
+    du_ho = np.zeros_like(u)
+    ctx.ho_apply(u, du_ho)
+    du_ho += 0.5 * rng.standard_normal(u.shape)
+    m = np.zeros_like(u)
+    ctx.compute_lumped_mass(0.0, m)
+    dulo, du_ref, du, y = (np.zeros_like(u) for _ in range(4))
+    ctx.lo_massavg(u, du_ho, cfg.dt, dulo)
+    ctx.fct_clipscale(u, m, du_ho, dulo, umin, umax, cfg.dt, du_ref)
+    ctx.limit_fused(u, du_ho, cfg.dt, du=du)
+    assert _rel(du, du_ref) < 1e-12
+    xb = rng.standard_normal(u.shape)
+    ctx.limit_fused(u, du_ho, cfg.dt, x_base=xb, a=0.75, b=0.25, dt_rk=0.5 * cfg.dt, y_out=y)
+    assert _rel(y, 0.75 * xb + 0.25 * (u + 0.5 * cfg.dt * du_ref)) < 1e-12
+    # a given LO rate (lo 3 / 4 path of the fused limiter)
+    dulo2 = dulo * (1.0 + 0.1 * rng.random(u.shape))
+    ctx.fct_clipscale(u, m, du_ho, dulo2, umin, umax, cfg.dt, du_ref)
+    ctx.limit_fused_lo(u, du_ho, dulo2, cfg.dt, du=du)
+    assert _rel(du, du_ref) < 1e-12
+    ctx.close()
+
+
 def test_split_columns_p6_emulated(lib):
     """p = 6: two wavefronts per element; the second one runs the face rows and the 17 quadrature columns beyond the first 64
     with three lanes per column (a third of the qz range each, DPP row-shift sums, w detJ of those columns in LDS).  HO kernel
