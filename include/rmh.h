@@ -44,7 +44,8 @@ typedef enum {
  * [ne_owned, ne_owned + ne_ghost) are ghosts owned by neighbour ranks (MFEM's face-neighbour
  * elements, plus edge/vertex neighbours for the bounds stencil). */
 typedef struct {
-   int dim;          /* 3                                                                  */
+   int dim;          /* 3: hexahedra (the whole API).  2: quadrilaterals -- HO solver + granular limiter sequence *
+                      *    (see "dim = 2" below)                                                */
    int order;        /* polynomial order p of the Bernstein DG space (-o, remhos.cpp:261)   */
    int mesh_order;   /* order of the nodal mesh (-mo, remhos.cpp:222); 2                    */
    int exec_mode;    /* 0 transport, 1 remap (remhos.cpp:437-440)                           */
@@ -71,6 +72,15 @@ typedef struct {
    const double *subcell_vel;
    int device;       /* HIP device ordinal */
 } rmh_layout;
+
+/* dim = 2 (quadrilateral tensor lattices; remhos_amd/csrc/rmh_2d.hpp): the reference's 2-D runs -- its ctest table
+ * (remhos_tests.cpp:38-107: inline-quad, -ho 3 -lo 5 -fct 2, incl. the -pa entries and its CUDA-device entry #10) and
+ * BASELINE configs[0]'s mesh family.  Layout: x0 / vel [ne][2][9] (node a = ax + 3*ay), face_nbr [ne][4] (f = 2*c + side),
+ * `stencil27` = the 3 x 3 element stencil [ne][9] (entry (ox+1) + 3*(oy+1)), ne_ghost = 0, subcell_vel = NULL; E-vectors
+ * carry (p+1)^2 doubles per element; Q = p + 2 quadrature points per direction.  Entry points: rmh_setup,
+ * rmh_ho_apply, rmh_lumped_mass, rmh_compute_lumped_mass, rmh_lo_massavg, rmh_elem_minmax, rmh_bounds, rmh_fct_clipscale,
+ * rmh_limit_fused, rmh_limit_fused_lo, the mass-rule / bounds-type / dt-control setters and getters, timers.  Everything else
+ * (one-kernel stage, lo 3 / 4, product fields, exchange) returns RMH_ERR_INVALID for a 2-D context. */
 
 /* Neighbour tables from mesh topology (host, no GPU): face_nbr and stencil27 of rmh_layout for ANY element numbering,
  * from the vertex ids of the elements -- what a binding has at hand (Mesh::GetElementVertices; periodic meshes: the

@@ -161,10 +161,11 @@ class Context:
         vel = np.ascontiguousarray(vel, dtype=np.float64)
         face_nbr = np.ascontiguousarray(face_nbr, dtype=np.int32)
         stencil27 = np.ascontiguousarray(stencil27, dtype=np.int32)
-        assert x0.shape == (ne, 3, 27) and vel.shape == (ne, 3, 27)
-        assert face_nbr.shape == (ne, 6) and stencil27.shape == (ne, 27)
+        dim = x0.shape[1]  # 3: hexahedra; 2: quadrilaterals (nodes [ne][2][9], 4 faces, 3 x 3 stencil -- include/rmh.h)
+        assert dim in (2, 3) and x0.shape == (ne, dim, 3**dim) and vel.shape == (ne, dim, 3**dim)
+        assert face_nbr.shape == (ne, 2 * dim) and stencil27.shape == (ne, 3**dim)
         L = RmhLayout()
-        L.dim, L.order, L.mesh_order, L.exec_mode = 3, order, mesh_order, exec_mode
+        L.dim, L.order, L.mesh_order, L.exec_mode = dim, order, mesh_order, exec_mode
         L.ne_owned, L.ne_ghost = ne, ne_ghost
         L.x0, L.vel = x0.ctypes.data, vel.ctypes.data
         L.face_nbr, L.stencil27 = face_nbr.ctypes.data, stencil27.ctypes.data
@@ -173,7 +174,7 @@ class Context:
             assert subcell_vel.shape == (ne, 3, (order + 1) ** 3)
             L.subcell_vel = subcell_vel.ctypes.data
         L.device = device
-        self.ne, self.order, self.ndof = ne, order, (order + 1) ** 3
+        self.ne, self.order, self.ndof, self.dim = ne, order, (order + 1) ** dim, dim
         h = C.c_void_p()
         self._check(lib.rmh_create(C.byref(L), C.byref(h)))
         self.h = h

@@ -4,6 +4,7 @@
 #include "rmh_kernels.hpp"
 #include "rmh_ho2.hpp"
 #include "rmh_stream.hpp"
+#include "rmh_2d.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -278,6 +279,70 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       default: return fail(RMH_ERR_INVALID, "unsupported order");                              \
    }
 
+// entry points that exist for hexahedra only
+#define RMH_3D_ONLY(c, name)                                                                                              \
+   if ((c)->dim != 3) { return fail(RMH_ERR_INVALID, name ": not available for dim = 2 (HO solver and granular limiter sequence only)"); }
+
+// dim = 2: nodes [ne][2][9], face_nbr [ne][4]; the caller's 3 x 3 element stencil [ne][9] becomes the middle layer of the
+// 27-entry table that the bounds kernels read (no neighbours along z)
+template <int P>
+int create_tables_2d(rmh_ctx *c)
+{
+   std::vector<double> tab = make_tables_q<P, P + 2>();
+   return upload(&c->d_tab, tab.data(), tab.size());
+}
+
+int create_device_state_2d(rmh_ctx *c, const rmh_layout *L)
+{
+   const size_t ne = c->ne;
+   int rc = 0;
+   if ((rc = upload(&c->d_x0, L->x0, ne * 18))) { return rc; }
+   if ((rc = upload(&c->d_vel, L->vel, ne * 18))) { return rc; }
+   if ((rc = upload(&c->d_nbr, L->face_nbr, ne * 4))) { return rc; }
+   std::vector<int> st(ne * 27, -1);
+   for (size_t e = 0; e < ne; e++)
+   {
+      for (int k = 0; k < 9; k++) { st[e * 27 + 9 + k] = L->stencil27[e * 9 + k]; }
+   }
+   if ((rc = upload(&c->d_st27, st.data(), ne * 27))) { return rc; }
+   RMH_DISPATCH(c, rc = create_tables_2d<P>(c));
+   if (rc) { return rc; }
+   RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_cg, sizeof(int)));
+   RMH_HIP(hipMemset(c->d_cg, 0, sizeof(int)));
+   return 0;
+}
+
+template <int P, int MODE>
+int launch_ho_2d(rmh_ctx *c, const double *u, double *du, double *m, double t)
+{
+   Ho2Args a;
+   a.u = u;
+   a.x0 = c->d_x0;
+   a.vel = c->d_vel;
+   a.face_nbr = c->d_nbr;
+   a.tab = c->d_tab;
+   a.du = du;
+   a.m = m;
+   a.xe_min = MODE == 0 ? c->d_xe_min : nullptr;
+   a.xe_max = MODE == 0 ? c->d_xe_max : nullptr;
+   a.cg_iters = c->d_cg;
+   a.t = t;
+   a.move = c->exec_mode == 1 ? 1 : 0;
+   a.alpha = c->exec_mode == 1 ? 1.0 : -1.0; // remhos.cpp:648-657
+   a.upw = c->exec_mode == 1 ? 1.0 : -1.0;
+   a.rel2 = c->rel_tol * c->rel_tol;
+   a.abs2 = c->abs_tol * c->abs_tol;
+   a.max_iter = c->max_iter;
+   a.jacobi_step = c->jacobi_step;
+   a.mass_fix = c->mass_fix;
+   hipLaunchKernelGGL((ho2d_kernel<P, MODE>), dim3(c->ne), dim3(64), 0, c->stream, a);
+   RMH_HIP(hipGetLastError());
+   return 0;
+}
+
 // device buffers, tables and lo 4 set-up data of a new context (rmh_create releases the context when this fails)
 int create_device_state(rmh_ctx *c, const rmh_layout *L)
 {
@@ -367,7 +432,9 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
 {
    if (!L || !out) { return fail(RMH_ERR_INVALID, "null argument"); }
    *out = nullptr;
-   if (L->dim != 3) { return fail(RMH_ERR_INVALID, "only dim = 3 is implemented on the device"); }
+   if (L->dim != 3 && L->dim != 2) { return fail(RMH_ERR_INVALID, "dim must be 3 (or 2: HO solver and granular limiter sequence)"); }
+   const int nf = 2 * L->dim, nst = L->dim == 3 ? 27 : 9;
+   if (L->dim == 2 && (L->ne_ghost != 0 || L->subcell_vel)) { return fail(RMH_ERR_INVALID, "dim = 2: single rank, no subcell data"); }
    if (L->order < 1 || L->order > 6) { return fail(RMH_ERR_INVALID, "order must be in 1..6"); }
    if (L->mesh_order != 2) { return fail(RMH_ERR_INVALID, "mesh_order must be 2"); }
    if (L->ne_owned <= 0 || L->ne_ghost < 0) { return fail(RMH_ERR_INVALID, "bad element counts"); }
@@ -377,17 +444,17 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
       const long long ntot = (long long)L->ne_owned + L->ne_ghost;
       for (long long e = 0; e < L->ne_owned; e++)
       {
-         for (int f = 0; f < 6; f++)
+         for (int f = 0; f < nf; f++)
          {
-            const int nb = L->face_nbr[e * 6 + f];
+            const int nb = L->face_nbr[e * nf + f];
             if (nb < -1 || nb >= ntot) { return fail(RMH_ERR_INVALID, "face_nbr entry out of range"); }
          }
-         for (int k = 0; k < 27; k++)
+         for (int k = 0; k < nst; k++)
          {
-            const int nb = L->stencil27[e * 27 + k];
+            const int nb = L->stencil27[e * nst + k];
             if (nb < -1 || nb >= ntot) { return fail(RMH_ERR_INVALID, "stencil27 entry out of range"); }
          }
-         if (L->stencil27[e * 27 + 13] != e) { return fail(RMH_ERR_INVALID, "stencil27[e][13] must be the element itself"); }
+         if (L->stencil27[e * nst + nst / 2] != e) { return fail(RMH_ERR_INVALID, "the centre entry of an element's stencil must be the element itself"); }
       }
    }
    int ndev = 0;
@@ -403,10 +470,11 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->ng = L->ne_ghost;
    c->exec_mode = L->exec_mode;
    c->device = L->device;
-   c->ndof = (c->p + 1) * (c->p + 1) * (c->p + 1);
+   c->dim = L->dim;
+   c->ndof = (c->p + 1) * (c->p + 1) * (c->dim == 3 ? c->p + 1 : 1);
    c->gh_ustride = c->ndof;
    // every failure past this point releases the context and whatever it already owns
-   const int rc = create_device_state(c, L);
+   const int rc = c->dim == 3 ? create_device_state(c, L) : create_device_state_2d(c, L);
    if (rc) { rmh_destroy(c); return rc; }
    *out = c;
    return RMH_OK;
@@ -480,7 +548,8 @@ int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
    EventPair ep;
    int rc = timer_begin(c, 0, ep);
    if (rc) { return rc; }
-   RMH_DISPATCH(c, rc = (launch_ho<P, 0>(c, u, du, c->d_m, c->t)));
+   if (c->dim == 2) { RMH_DISPATCH(c, rc = (launch_ho_2d<P, 0>(c, u, du, c->d_m, c->t))); }
+   else { RMH_DISPATCH(c, rc = (launch_ho<P, 0>(c, u, du, c->d_m, c->t))); }
    if (rc) { return rc; }
    rc = timer_end(c, 0, ep);
    c->ho_done = true;
@@ -495,6 +564,11 @@ int rmh_compute_lumped_mass(rmh_ctx *c, double t, double *m)
    if (!c || !m) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
    int rc = 0;
+   if (c->dim == 2)
+   {
+      RMH_DISPATCH(c, rc = (launch_ho_2d<P, 4>(c, nullptr, nullptr, m, t)));
+      return rc;
+   }
    RMH_DISPATCH(c, hipLaunchKernelGGL((lumped_mass_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream,
                                       (const double *)c->d_x0, (const double *)c->d_vel, (const double *)c->d_tab, t,
                                       c->exec_mode == 1 ? 1 : 0, m));
@@ -511,8 +585,16 @@ int rmh_lo_massavg(rmh_ctx *c, const double *u, const double *du_ho, double dt, 
    EventPair ep;
    int rc = timer_begin(c, 2, ep);
    if (rc) { return rc; }
-   RMH_DISPATCH(c, hipLaunchKernelGGL((lo_massavg_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
-                                      du_ho, (const double *)c->d_m, dt, du_lo));
+   if (c->dim == 2)
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((lo_massavg_kernel<P, 2>), dim3(c->ne), dim3(KCfg<P, 2>::NT), 0, c->stream, u,
+                                         du_ho, (const double *)c->d_m, dt, du_lo));
+   }
+   else
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((lo_massavg_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
+                                         du_ho, (const double *)c->d_m, dt, du_lo));
+   }
    RMH_HIP(hipGetLastError());
    return timer_end(c, 2, ep);
 }
@@ -539,6 +621,7 @@ int lo_rd(rmh_ctx *c, const double *u, double *du_lo, int lo_type)
 int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 {
    if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_lo_rdsubcell");
    if (c->p < 2) { return fail(RMH_ERR_INVALID, "Subcell schemes require FE order > 2."); } // remhos.cpp:612-616
    if (!c->d_subvel) { return fail(RMH_ERR_STATE, "rmh_lo_rdsubcell needs rmh_layout.subcell_vel"); }
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
@@ -548,6 +631,7 @@ int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 int rmh_lo_rd(rmh_ctx *c, const double *u, double *du_lo)
 {
    if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_lo_rd");
    if (c->p < 2) { return fail(RMH_ERR_INVALID, "rmh_lo_rd: the RD kernel is built for orders >= 2"); }
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
    return lo_rd(c, u, du_lo, 3);
@@ -557,8 +641,16 @@ int rmh_elem_minmax(rmh_ctx *c, const double *u, double *xe_min, double *xe_max)
 {
    if (!c || !u || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
-   RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::U8)), dim3(SCfg<P>::NT), 0,
-                                      c->stream, u, xe_min, xe_max, c->ne));
+   if (c->dim == 2)
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P, 2>), dim3(SCfg<P, 2>::grid(c->ne, SCfg<P, 2>::U8)),
+                                         dim3(SCfg<P, 2>::NT), 0, c->stream, u, xe_min, xe_max, c->ne));
+   }
+   else
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::U8)), dim3(SCfg<P>::NT), 0,
+                                         c->stream, u, xe_min, xe_max, c->ne));
+   }
    RMH_HIP(hipGetLastError());
    return RMH_OK;
 }
@@ -570,9 +662,18 @@ int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u
    extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
    const int wide = (((uintptr_t)u_min | (uintptr_t)u_max) & 15) == 0; // 16-byte stores
-   RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::UB)), dim3(SCfg<P>::NT), 0, c->stream,
-                                      c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
-                                      u_max, wide));
+   if (c->dim == 2)
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P, 2>), dim3(SCfg<P, 2>::grid(c->ne, SCfg<P, 2>::UB)), dim3(SCfg<P, 2>::NT), 0, c->stream,
+                                         c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
+                                         u_max, wide));
+   }
+   else
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((bounds_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::UB)), dim3(SCfg<P>::NT), 0, c->stream,
+                                         c->bounds_type, (const int *)c->d_st27, c->ne, xe_min, xe_max, c->gh_min, c->gh_max, c->gh_mstride, u_min,
+                                         u_max, wide));
+   }
    RMH_HIP(hipGetLastError());
    return RMH_OK;
 }
@@ -589,8 +690,16 @@ int rmh_fct_clipscale(rmh_ctx *c, const double *u, const double *m, const double
    EventPair ep;
    int rc = timer_begin(c, 3, ep);
    if (rc) { return rc; }
-   RMH_DISPATCH(c, hipLaunchKernelGGL((fct_clipscale_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u, m,
-                                      du_ho, du_lo, u_min, u_max, dt, du));
+   if (c->dim == 2)
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((fct_clipscale_kernel<P, 2>), dim3(c->ne), dim3(KCfg<P, 2>::NT), 0, c->stream, u, m,
+                                         du_ho, du_lo, u_min, u_max, dt, du));
+   }
+   else
+   {
+      RMH_DISPATCH(c, hipLaunchKernelGGL((fct_clipscale_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u, m,
+                                         du_ho, du_lo, u_min, u_max, dt, du));
+   }
    RMH_HIP(hipGetLastError());
    return timer_end(c, 3, ep);
 }
@@ -599,6 +708,7 @@ int rmh_product_ratio(rmh_ctx *c, const double *us, const double *u, double *s, 
                       unsigned char *active_dofs)
 {
    if (!c || !u || !active_el || !active_dofs || ((us != nullptr) != (s != nullptr))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_product_ratio");
    RMH_ENTER(c);
    extrema_dropped(c);
    RMH_DISPATCH(c, hipLaunchKernelGGL((product_ratio_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, us, u, s,
@@ -611,6 +721,7 @@ int rmh_elem_minmax_masked(rmh_ctx *c, const double *u, const unsigned char *act
                            double *xe_min, double *xe_max)
 {
    if (!c || !u || !active_el || !active_dofs || !xe_min || !xe_max) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_elem_minmax_masked");
    RMH_ENTER(c);
    RMH_DISPATCH(c, hipLaunchKernelGGL((elem_minmax_masked_kernel<P>), dim3(c->ne), dim3(KCfg<P>::NT), 0, c->stream, u,
                                       active_el, active_dofs, xe_min, xe_max));
@@ -626,6 +737,7 @@ int rmh_fct_product(rmh_ctx *c, const double *us, const double *m, const double 
    {
       return fail(RMH_ERR_INVALID, "null argument");
    }
+   RMH_3D_ONLY(c, "rmh_fct_product");
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    RMH_ENTER(c);
    extrema_dropped(c);
@@ -671,7 +783,8 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    EventPair ep;
    int rc = timer_begin(c, 3, ep);
    if (rc) { return rc; }
-   RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::U4)), dim3(SCfg<P>::NT), 0, c->stream, la));
+   if (c->dim == 2) {   RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P, 2>), dim3(SCfg<P, 2>::grid(c->ne, SCfg<P, 2>::U4)), dim3(SCfg<P, 2>::NT), 0, c->stream, la)); }
+   else {   RMH_DISPATCH(c, hipLaunchKernelGGL((limit_fused_kernel<P>), dim3(SCfg<P>::grid(c->ne, SCfg<P>::U4)), dim3(SCfg<P>::NT), 0, c->stream, la)); }
    RMH_HIP(hipGetLastError());
    return timer_end(c, 3, ep);
 }
@@ -695,6 +808,7 @@ int rmh_stage_fused_chain(rmh_ctx *c, const double *u, double dt, const double *
 {
    if (out_token) { *out_token = 0; }
    if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_stage_fused_chain");
    RMH_ENTER(c);
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    if (y_out == u || du == u) { return fail(RMH_ERR_INVALID, "rmh_stage_fused: the output must not alias u"); }
@@ -770,6 +884,7 @@ int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend,
                   double *out_max)
 {
    if (!c || !u || (nsend > 0 && (!send_elems || !rows || !out_min || !out_max))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_halo_pack");
    RMH_ENTER(c);
    if (nsend <= 0) { return RMH_OK; }
    RMH_DISPATCH(c, hipLaunchKernelGGL((halo_pack_kernel<P>), dim3(nsend), dim3(KCfg<P>::NT), 0, c->stream, u, send_elems,
@@ -781,6 +896,7 @@ int rmh_halo_pack(rmh_ctx *c, const double *u, const int *send_elems, int nsend,
 int rmh_halo_pack_records(rmh_ctx *c, const double *u, const int *send_elems, int nsend, double *rec)
 {
    if (!c || !u || (nsend > 0 && (!send_elems || !rec))) { return fail(RMH_ERR_INVALID, "null argument"); }
+   RMH_3D_ONLY(c, "rmh_halo_pack_records");
    RMH_ENTER(c);
    if (nsend <= 0) { return RMH_OK; }
    const int w = c->ndof + 2;

@@ -223,6 +223,7 @@ extern "C" {
 int rmh_exchange_setup(rmh_ctx *c, const rmh_exchange_desc *d, int compact)
 {
    if (!c || !d || d->n_peers < 0) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (c->dim != 3) { return fail(RMH_ERR_INVALID, "rmh_exchange_setup: not available for dim = 2 (single rank)"); }
    if (c->xch) { return fail(RMH_ERR_STATE, "rmh_exchange_setup: the exchange of this context is already set up"); }
    RMH_ENTER(c);
    bool rewritten = false;

@@ -35,6 +35,7 @@ struct Exchange; // rmh_comm.hpp
 
 struct rmh_ctx
 {
+   int dim = 3; // 3: hexahedra (the whole API); 2: quadrilaterals (HO solver + the granular limiter sequence, rmh_2d.hpp)
    int p = 0, ne = 0, ng = 0, exec_mode = 0, device = 0;
    int ndof = 0;
    hipStream_t stream = nullptr;

@@ -19,12 +19,12 @@
 namespace rmh
 {
 
-template <int P>
+template <int P, int DIM = 3> // (DIM = 2: D3 is the dof count D^2 of a quadrilateral element -- the streaming kernels only)
 struct KCfg : TabLayout<P>
 {
    using T = TabLayout<P>;
    static constexpr int D = T::D, Q = T::Q;
-   static constexpr int D2 = D * D, D3 = D * D * D, Q2 = Q * Q, Q3 = Q * Q * Q;
+   static constexpr int D2 = D * D, D3 = DIM == 3 ? D * D * D : D * D, Q2 = Q * Q, Q3 = Q * Q * Q;
    static constexpr int NT = (Q2 <= 64) ? 64 : 128;
    static constexpr int NW = NT / 64;
    static constexpr int DPT = (D3 + NT - 1) / NT; // dofs per thread
@@ -346,11 +346,11 @@ __global__ void __launch_bounds__(KCfg<P>::NT) halo_pack_kernel(const double *u,
 // MassBasedAvg::CalcLOSolution (remhos_lo.cpp:247-324): du_lo = (ubar - u)/dt with
 // ubar = int (u + dt du_ho) / int 1 over the element at the current mesh position.
 // int u_h = sum_i m_i u_i with the lumped mass (Bernstein partition of unity).
-template <int P>
-__global__ void __launch_bounds__(KCfg<P>::NT) lo_massavg_kernel(const double *u, const double *du_ho, const double *m,
+template <int P, int DIM = 3>
+__global__ void __launch_bounds__((KCfg<P, DIM>::NT)) lo_massavg_kernel(const double *u, const double *du_ho, const double *m,
                                                                  double dt, double *du_lo)
 {
-   using C = KCfg<P>;
+   using C = KCfg<P, DIM>;
    __shared__ double s_red[4];
    const int e = blockIdx.x;
    double uu[C::DPT];
@@ -382,12 +382,12 @@ __global__ void __launch_bounds__(KCfg<P>::NT) lo_massavg_kernel(const double *u
 
 // ClipScaleSolver::CalcFCTSolution (remhos_fct.cpp:449-541), one element per workgroup,
 // wave-reduced sumPos / sumNeg, the f_clip scratch stays in registers.
-template <int P>
-__global__ void __launch_bounds__(KCfg<P>::NT) fct_clipscale_kernel(const double *u, const double *m, const double *du_ho,
+template <int P, int DIM = 3>
+__global__ void __launch_bounds__((KCfg<P, DIM>::NT)) fct_clipscale_kernel(const double *u, const double *m, const double *du_ho,
                                                                     const double *du_lo, const double *u_min,
                                                                     const double *u_max, double dt, double *du)
 {
-   using C = KCfg<P>;
+   using C = KCfg<P, DIM>;
    __shared__ double s_red[4];
    const int e = blockIdx.x;
    constexpr double eps = 1.0e-15;

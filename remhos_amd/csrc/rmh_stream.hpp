@@ -39,10 +39,10 @@ __device__ inline void wave_lds_fence()
 // every kernel here.)
 #define RMH_PASS_LOOP(wave) for (int e0 = (wave) * U; e0 < ne; e0 += nwaves * U)
 
-template <int P>
-struct SCfg
+template <int P, int DIM = 3> // (DIM = 2: D3 is the dof count D^2 of a quadrilateral element; its 3 x 3 element stencil sits
+struct SCfg                  //  in the middle layer of the 27-entry table, every dof is "interior" along z)
 {
-   static constexpr int D = P + 1, D2 = D * D, D3 = D * D * D;
+   static constexpr int D = P + 1, D2 = D * D, D3 = DIM == 3 ? D * D * D : D * D;
    static constexpr int NT = 256, NW = NT / 64;
    static constexpr int DPT = (D3 + 63) / 64; // dof rounds of a wavefront per element
    // elements a wavefront has in flight per pass: ~8 loads per lane and array for the kernels that read one or two
@@ -66,7 +66,7 @@ struct SCfg
       const int ix = i % D, iy = (i / D) % D, iz = i / D2;
       const int cx = (ix == 0) ? 0 : ((ix == P) ? 2 : 1);
       const int cy = (iy == 0) ? 0 : ((iy == P) ? 2 : 1);
-      const int cz = (iz == 0) ? 0 : ((iz == P) ? 2 : 1);
+      const int cz = DIM == 2 ? 1 : ((iz == 0) ? 0 : ((iz == P) ? 2 : 1));
       return cx + 3 * cy + 9 * cz;
    }
 };
@@ -233,10 +233,10 @@ __device__ inline void class_tables(int bt, int lane, const MinMax (&raw)[U], Mi
 // ---------------------------------------------------------------------------------------
 // Element extrema: DofInfo::ComputeElementsMinMax (remhos_tools.cpp:497-523)
 // ---------------------------------------------------------------------------------------
-template <int P>
-__global__ void __launch_bounds__(SCfg<P>::NT) elem_minmax_kernel(const double *u, double *xe_min, double *xe_max, int ne)
+template <int P, int DIM = 3>
+__global__ void __launch_bounds__((SCfg<P, DIM>::NT)) elem_minmax_kernel(const double *u, double *xe_min, double *xe_max, int ne)
 {
-   using C = SCfg<P>;
+   using C = SCfg<P, DIM>;
    constexpr int U = C::U8;
    const int lane = threadIdx.x & 63;
    const int nwaves = gridDim.x * C::NW;
@@ -306,13 +306,13 @@ __device__ inline void store_pair(double *p, double x, double y) // p 16-byte al
 #endif
 }
 
-template <int P>
-__global__ void __launch_bounds__(SCfg<P>::NT) bounds_kernel(int bt, const int *stencil27, int ne_owned, const double *xe_min,
+template <int P, int DIM = 3>
+__global__ void __launch_bounds__((SCfg<P, DIM>::NT)) bounds_kernel(int bt, const int *stencil27, int ne_owned, const double *xe_min,
                                                              const double *xe_max, const double *gh_min,
                                                              const double *gh_max, int gh_mstride, double *u_min, double *u_max,
                                                              int wide)
 {
-   using C = SCfg<P>;
+   using C = SCfg<P, DIM>;
    constexpr int U = C::UB;
    constexpr int L = U * C::D3, NP = L / 2, RP = (NP + 63) / 64; // doubles, pairs and store rounds of a pass
    static_assert(L % 2 == 0, "a pass starts 16-byte aligned");
@@ -376,10 +376,10 @@ __global__ void __launch_bounds__(SCfg<P>::NT) bounds_kernel(int bt, const int *
 // ClipScale (remhos_fct.cpp:449-541) (+ optional RK update) in one pass; du_lo, u_min, u_max are never materialised.
 // With LimitArgs::du_lo the LO rate of another solver (lo 3 / 4) takes the place of the mass-based average.
 // ---------------------------------------------------------------------------------------
-template <int P>
-__global__ void __launch_bounds__(SCfg<P>::NT) limit_fused_kernel(LimitArgs a)
+template <int P, int DIM = 3>
+__global__ void __launch_bounds__((SCfg<P, DIM>::NT)) limit_fused_kernel(LimitArgs a)
 {
-   using C = SCfg<P>;
+   using C = SCfg<P, DIM>;
    constexpr int U = C::U4;
    constexpr double eps = 1.0e-15;
    __shared__ MinMax s_cls[C::NW][U][27];

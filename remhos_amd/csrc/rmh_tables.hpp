@@ -18,11 +18,11 @@
 namespace rmh
 {
 
-// table layout shared by host and device code (offsets in doubles)
-template <int P>
-struct TabLayout
+// table layout shared by host and device code (offsets in doubles); NQ Gauss-Legendre points per direction
+template <int P, int NQ>
+struct TabLayoutQ
 {
-   static constexpr int D = P + 1, Q = P + 3;
+   static constexpr int D = P + 1, Q = NQ;
    static constexpr int oB = 0;             // B[q*D+i]   Bernstein values
    static constexpr int oG = oB + Q * D;    // G[q*D+i]   Bernstein derivatives
    static constexpr int oL = oG + Q * D;    // L[q*3+a]   mesh Lagrange values
@@ -36,6 +36,15 @@ struct TabLayout
    static constexpr int oLcu = oBgE + 2 * D; // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
    static constexpr int oCf = oLcu + 3 * D; // Cf[i*D+k] = C[k][i]: GL-tested -> Bernstein-tested moments (phi^B_i = sum_k C[k][i] l_k)
    static constexpr int N2 = oCf + D * D;   // extended table
+};
+// dim = 3: Q = p + 3 (order 2p + 2*3 - 1); dim = 2: Q = p + 2 (order 2p + 2*2 - 1) -- SURVEY A.2
+template <int P>
+struct TabLayout : TabLayoutQ<P, P + 3>
+{
+};
+template <int P>
+struct TabLayout2 : TabLayoutQ<P, P + 2>
+{
 };
 
 inline void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
@@ -144,10 +153,10 @@ inline void invert(int n, std::vector<double> &a)
    a = inv;
 }
 
-template <int P>
-inline std::vector<double> make_tables()
+template <int P, int NQ>
+inline std::vector<double> make_tables_q()
 {
-   using T = TabLayout<P>;
+   using T = TabLayoutQ<P, NQ>;
    constexpr int D = T::D, Q = T::Q;
    std::vector<double> tab(T::N2, 0.0);
    std::vector<double> xq, wq, xg, wg;
@@ -203,5 +212,8 @@ inline std::vector<double> make_tables()
    }
    return tab;
 }
+
+template <int P>
+inline std::vector<double> make_tables() { return make_tables_q<P, P + 3>(); }
 
 } // namespace rmh

@@ -22,9 +22,15 @@ def emu_library_path():
 
 
 def layout_from_oracle(r):
-    """r: oracle.remhos_oracle.Remhos (3-D).  Returns x0, vel, face_nbr, stencil27 in the
+    """r: oracle.remhos_oracle.Remhos (3-D or 2-D).  Returns x0, vel, face_nbr, stencil27 (2-D: the 3 x 3 stencil) in the
     C-ABI layouts of include/rmh.h."""
     lat = r.lat
+    if lat.dim == 2:
+        x0 = np.ascontiguousarray(r.X0.transpose(0, 2, 1))
+        v = r.V if r.exec_mode == 1 else r.vel(r.X0)
+        vel = np.ascontiguousarray(v.transpose(0, 2, 1))
+        st = np.stack([lat.shifted((ox, oy)) for oy in (-1, 0, 1) for ox in (-1, 0, 1)], axis=1).astype(np.int32)
+        return x0, vel, r.nbr.astype(np.int32), st
     assert lat.dim == 3
     x0 = np.ascontiguousarray(r.X0.transpose(0, 2, 1))
     v = r.V if r.exec_mode == 1 else r.vel(r.X0)
