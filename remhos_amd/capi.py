@@ -171,7 +171,7 @@ class Context:
         L.face_nbr, L.stencil27 = face_nbr.ctypes.data, stencil27.ctypes.data
         if subcell_vel is not None:
             subcell_vel = np.ascontiguousarray(subcell_vel, dtype=np.float64)
-            assert subcell_vel.shape == (ne, 3, (order + 1) ** 3)
+            assert subcell_vel.shape == (ne, dim, (order + 1) ** dim)
             L.subcell_vel = subcell_vel.ctypes.data
         L.device = device
         self.ne, self.order, self.ndof, self.dim = ne, order, (order + 1) ** dim, dim

@@ -38,9 +38,13 @@ struct Ho2Args
    double alpha, upw;
    double rel2, abs2;
    int max_iter, jacobi_step, mass_fix;
+   const double *subvel; // [ne][2][D2] sub-mesh node velocity (lo 4; rmh_layout.subcell_vel) or null
+   int rd_subcell;       // MODE 2: 1 subcell residual distribution (lo 4), 0 plain residual distribution (lo 3)
 };
 
-// MODE 0: HO solution, lumped mass, element extrema; MODE 4: lumped mass only (rmh_compute_lumped_mass)
+// MODE 0: HO solution, lumped mass, element extrema; MODE 4: lumped mass only (rmh_compute_lumped_mass);
+// MODE 2: the residual-distribution LO solvers (PAResidualDistribution[Subcell]::CalcLOSolution, remhos_lo.cpp:965-1034,
+// 1620-1802; host form :111-245): du = du_LO, lumped mass
 template <int P, int MODE>
 __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
 {
@@ -49,6 +53,8 @@ __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
    static_assert(Q2 <= 64 && D2 <= 64 && 4 * Q <= 64, "one lane per quadrature point, dof and face point");
    __shared__ double sT[T::N2];
    __shared__ double sX[2][9], sV[2][9], sU[D2], sN[4][D], sG[Q2], sW[Q2], sF[4][Q], sP[D2], sPQ[Q2];
+   constexpr int NS = P * P; // subcells
+   __shared__ double sX0[2][9], sS[4][Q], sSv[2][D2], sCP[MODE == 2 ? NS : 1][4], sCN[MODE == 2 ? NS : 1][4];
    const int tid = threadIdx.x;
    const size_t e = blockIdx.x;
    for (int i = tid; i < T::N2; i += 64) { sT[i] = a.tab[i]; }
@@ -57,8 +63,14 @@ __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
       const double x = a.x0[e * 18 + tid], v = a.vel[e * 18 + tid];
       sV[tid / 9][tid % 9] = v;
       sX[tid / 9][tid % 9] = a.move ? x + a.t * v : x;
+      sX0[tid / 9][tid % 9] = x;
    }
-   if (MODE == 0)
+   if (MODE == 2 && a.rd_subcell && tid < D2)
+   {
+      sSv[0][tid] = a.subvel[e * 2 * D2 + tid];
+      sSv[1][tid] = a.subvel[e * 2 * D2 + D2 + tid];
+   }
+   if (MODE == 0 || MODE == 2)
    {
       if (tid < D2) { sU[tid] = a.u[e * D2 + tid]; }
       if (tid < 4 * D)
@@ -99,7 +111,7 @@ __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
       const double w = W[qx] * W[qy];
       const double detJ = J[0][0] * J[1][1] - J[0][1] * J[1][0];
       sW[tid] = w * detJ;
-      if (MODE == 0)
+      if (MODE == 0 || MODE == 2)
       {
          // D = alpha w adj(J) v (remhos_lo.cpp:1113-1132), adj(J) = [[J11, -J01], [-J10, J00]]
          const double d0 = a.alpha * w * (J[1][1] * v[0] - J[0][1] * v[1]);
@@ -120,7 +132,7 @@ __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
       }
    }
    // ---- face points: upwind speed w max(0, +-v.n_out) and the jump of the traces ---------------------------
-   if (MODE == 0 && tid < 4 * Q)
+   if ((MODE == 0 || MODE == 2) && tid < 4 * Q)
    {
       const int f = tid / Q, q1 = tid % Q, c = f / 2, side = f % 2;
       // tangent dX/dxi_t at (xi_c = side, xi_t = x_q1): nodes of the face are ac = 2 side, at = 0..2
@@ -150,6 +162,7 @@ __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
          un_ += B[q1 * D + it] * sN[f][it];
       }
       sF[f][q1] = sp * (un_ - uo);
+      sS[f][q1] = sp;
    }
    __syncthreads();
    // ---- dofs: tests (Gauss-Legendre nodal basis for the solve, Bernstein for the lumped mass) ---------------
@@ -190,6 +203,131 @@ __global__ void __launch_bounds__(64) ho2d_kernel(Ho2Args a)
       }
    }
    if (dof) { a.m[e * D2 + tid] = mi; }
+   if (MODE == 2)
+   {
+      constexpr double eps = 1e-15, gamma = 1.0;
+      const double ui = dof ? sU[tid] : 0.0;
+      // z = K_vol u tested with the Bernstein basis; lumped upwind face fluxes: B^T D B 1 = B^T D (remhos_lo.cpp:854-868)
+      double zi = 0, fl = 0;
+      if (dof)
+      {
+#pragma unroll
+         for (int qy = 0; qy < Q; qy++)
+         {
+#pragma unroll
+            for (int qx = 0; qx < Q; qx++) { zi += B[qx * D + ix] * B[qy * D + iy] * sG[qx + Q * qy]; }
+         }
+#pragma unroll
+         for (int f = 0; f < 4; f++)
+         {
+            const int c = f / 2, side = f % 2;
+            const int ic = c == 0 ? ix : iy, it = c == 0 ? iy : ix;
+            if (ic == (side == 0 ? 0 : P))
+            {
+               double coef = 0;
+#pragma unroll
+               for (int q1 = 0; q1 < Q; q1++) { coef += B[q1 * D + it] * sS[f][q1]; }
+               fl += coef * (sN[f][it] - ui);
+            }
+         }
+      }
+      const double xmax = wave_bcast<63>(wave_minmax<false>(dof ? ui : -INFINITY));
+      const double xmin = wave_bcast<63>(wave_minmax<true>(dof ? ui : INFINITY));
+      const double xsum = wave_bcast<63>(wave_sum(ui));
+      const double rhoP = wave_bcast<63>(wave_sum(dof ? fmax(0.0, zi) : 0.0));
+      const double rhoN = wave_bcast<63>(wave_sum(dof ? fmin(0.0, zi) : 0.0));
+      double wP = (xmax - ui) / (D2 * xmax - xsum + eps);
+      double wN = (xmin - ui) / (D2 * xmin - xsum - eps);
+      if (a.rd_subcell)
+      {
+         // subcell fluctuations with the 1-point rule on the closed-uniform sub-mesh (remhos_lo.cpp:1051-1192, 1473-1612):
+         // lane = subcell (mx, my), corners j = jx + 2 jy
+         const bool sub = tid < NS;
+         const int mx = sub ? tid % P : 0, my = sub ? tid / P : 0;
+         const double *Lcu = sT + T::oLcu;
+         double fP = 0, fN = 0;
+         if (sub)
+         {
+            double xc[4][2], uc[4], vm[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+               const int cx = mx + (j & 1), cy = my + (j >> 1), dj = cx + D * cy;
+               uc[j] = sU[dj];
+#pragma unroll
+               for (int k = 0; k < 2; k++)
+               {
+                  // start position = Q2 map of the START mesh at (cx / p, cy / p) (MakeRefined, remhos.cpp:796-826), moved
+                  // with the sub-mesh velocity (remhos.cpp:837-853)
+                  double x = 0;
+#pragma unroll
+                  for (int ay = 0; ay < 3; ay++)
+                  {
+#pragma unroll
+                     for (int ax = 0; ax < 3; ax++) { x += Lcu[cx * 3 + ax] * Lcu[cy * 3 + ay] * sX0[k][ax + 3 * ay]; }
+                  }
+                  xc[j][k] = a.move ? x + a.t * sSv[k][dj] : x;
+                  vm[k] += 0.25 * sSv[k][dj];
+               }
+            }
+            // J_sub = sum_j corner_j (x) dpsi_j, dpsi_j = (+-1/2, +-1/2); weights W_j = dpsi_j . (alpha adj(J_sub) v_mid)
+            double Js[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+#pragma unroll
+               for (int k = 0; k < 2; k++)
+               {
+                  Js[k][0] += ((j & 1) ? 0.5 : -0.5) * xc[j][k];
+                  Js[k][1] += ((j >> 1) ? 0.5 : -0.5) * xc[j][k];
+               }
+            }
+            const double v0 = a.alpha * (Js[1][1] * vm[0] - Js[0][1] * vm[1]);
+            const double v1 = a.alpha * (-Js[1][0] * vm[0] + Js[0][0] * vm[1]);
+            double fluct = 0, smax = uc[0], smin = uc[0], ssum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+               fluct += (((j & 1) ? 0.5 : -0.5) * v0 + ((j >> 1) ? 0.5 : -0.5) * v1) * uc[j];
+               smax = fmax(smax, uc[j]);
+               smin = fmin(smin, uc[j]);
+               ssum += uc[j];
+            }
+            fP = fmax(0.0, fluct);
+            fN = fmin(0.0, fluct);
+            const double swP = 4 * smax - ssum + eps, swN = 4 * smin - ssum - eps;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+               sCP[tid][j] = fP * ((smax - uc[j]) / swP);
+               sCN[tid][j] = fN * ((smin - uc[j]) / swN);
+            }
+         }
+         const double sumFP = wave_bcast<63>(wave_sum(fP)), sumFN = wave_bcast<63>(wave_sum(fN));
+         __syncthreads();
+         double nwP = 0, nwN = 0;
+         if (dof)
+         {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+               const int sx = ix - (j & 1), sy = iy - (j >> 1); // the subcell that has this dof as corner j
+               if (sx >= 0 && sx < P && sy >= 0 && sy < P)
+               {
+                  nwP += sCP[sx + P * sy][j];
+                  nwN += sCN[sx + P * sy][j];
+               }
+            }
+         }
+         double aux = gamma / (rhoP + eps);
+         wP = wP * (1.0 - fmin(aux * sumFP, 1.0)) + fmin(aux, 1.0 / (sumFP + eps)) * nwP;
+         aux = gamma / (rhoN - eps);
+         wN = wN * (1.0 - fmin(aux * sumFN, 1.0)) + fmax(aux, 1.0 / (sumFN - eps)) * nwN;
+      }
+      if (dof) { a.du[e * D2 + tid] = (fl + wP * rhoP + wN * rhoN) / mi; }
+      if (a.xe_min && tid == 0) { a.xe_min[e] = xmin; a.xe_max[e] = xmax; }
+      return;
+   }
    if (MODE != 0) { return; }
    if (!dof) { b = 0; mi = 0; }
    if (a.xe_min)

@@ -305,6 +305,7 @@ int create_device_state_2d(rmh_ctx *c, const rmh_layout *L)
       for (int k = 0; k < 9; k++) { st[e * 27 + 9 + k] = L->stencil27[e * 9 + k]; }
    }
    if ((rc = upload(&c->d_st27, st.data(), ne * 27))) { return rc; }
+   if (L->subcell_vel && (rc = upload(&c->d_subvel, L->subcell_vel, ne * 2 * c->ndof))) { return rc; }
    RMH_DISPATCH(c, rc = create_tables_2d<P>(c));
    if (rc) { return rc; }
    RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
@@ -326,8 +327,8 @@ int launch_ho_2d(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.tab = c->d_tab;
    a.du = du;
    a.m = m;
-   a.xe_min = MODE == 0 ? c->d_xe_min : nullptr;
-   a.xe_max = MODE == 0 ? c->d_xe_max : nullptr;
+   a.xe_min = MODE != 4 ? c->d_xe_min : nullptr;
+   a.xe_max = MODE != 4 ? c->d_xe_max : nullptr;
    a.cg_iters = c->d_cg;
    a.t = t;
    a.move = c->exec_mode == 1 ? 1 : 0;
@@ -338,6 +339,8 @@ int launch_ho_2d(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.max_iter = c->max_iter;
    a.jacobi_step = c->jacobi_step;
    a.mass_fix = c->mass_fix;
+   a.subvel = c->d_subvel;
+   a.rd_subcell = c->lo_type == 3 ? 0 : 1;
    hipLaunchKernelGGL((ho2d_kernel<P, MODE>), dim3(c->ne), dim3(64), 0, c->stream, a);
    RMH_HIP(hipGetLastError());
    return 0;
@@ -434,7 +437,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    *out = nullptr;
    if (L->dim != 3 && L->dim != 2) { return fail(RMH_ERR_INVALID, "dim must be 3 (or 2: HO solver and granular limiter sequence)"); }
    const int nf = 2 * L->dim, nst = L->dim == 3 ? 27 : 9;
-   if (L->dim == 2 && (L->ne_ghost != 0 || L->subcell_vel)) { return fail(RMH_ERR_INVALID, "dim = 2: single rank, no subcell data"); }
+   if (L->dim == 2 && L->ne_ghost != 0) { return fail(RMH_ERR_INVALID, "dim = 2: single rank (ne_ghost = 0)"); }
    if (L->order < 1 || L->order > 6) { return fail(RMH_ERR_INVALID, "order must be in 1..6"); }
    if (L->mesh_order != 2) { return fail(RMH_ERR_INVALID, "mesh_order must be 2"); }
    if (L->ne_owned <= 0 || L->ne_ghost < 0) { return fail(RMH_ERR_INVALID, "bad element counts"); }
@@ -610,7 +613,8 @@ int lo_rd(rmh_ctx *c, const double *u, double *du_lo, int lo_type)
    if (rc) { return rc; }
    const int keep = c->lo_type;
    c->lo_type = lo_type;
-   RMH_DISPATCH(c, rc = (launch_ho<P, 2>(c, u, du_lo, c->d_m, c->t)));
+   if (c->dim == 2) { RMH_DISPATCH(c, rc = (launch_ho_2d<P, 2>(c, u, du_lo, c->d_m, c->t))); }
+   else { RMH_DISPATCH(c, rc = (launch_ho<P, 2>(c, u, du_lo, c->d_m, c->t))); }
    c->lo_type = keep;
    if (rc) { return rc; }
    c->ho_done = true; // lumped mass and element extrema are current
@@ -621,7 +625,6 @@ int lo_rd(rmh_ctx *c, const double *u, double *du_lo, int lo_type)
 int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 {
    if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
-   RMH_3D_ONLY(c, "rmh_lo_rdsubcell");
    if (c->p < 2) { return fail(RMH_ERR_INVALID, "Subcell schemes require FE order > 2."); } // remhos.cpp:612-616
    if (!c->d_subvel) { return fail(RMH_ERR_STATE, "rmh_lo_rdsubcell needs rmh_layout.subcell_vel"); }
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
@@ -631,7 +634,6 @@ int rmh_lo_rdsubcell(rmh_ctx *c, const double *u, double *du_lo)
 int rmh_lo_rd(rmh_ctx *c, const double *u, double *du_lo)
 {
    if (!c || !u || !du_lo) { return fail(RMH_ERR_INVALID, "null argument"); }
-   RMH_3D_ONLY(c, "rmh_lo_rd");
    if (c->p < 2) { return fail(RMH_ERR_INVALID, "rmh_lo_rd: the RD kernel is built for orders >= 2"); }
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
    return lo_rd(c, u, du_lo, 3);

@@ -52,7 +52,11 @@ class Backend:
         from remhos_amd.capi import Context
 
         x0, vel, nbr, st = layout_from_oracle(r)
-        ctx = Context(self.lib, order=r.T.p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+        sub = None
+        if r.cfg.lo == 4:  # sub-mesh node velocity (v_sub_gf, remhos.cpp:837-853)
+            sv = r.Vs if r.exec_mode == 1 else r.vel(r.Xs0)
+            sub = np.ascontiguousarray(sv.transpose(0, 2, 1))
+        ctx = Context(self.lib, order=r.T.p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st, subcell_vel=sub)
         assert ctx.dim == 2
         if self.gpu:
             ctx.set_stream(self.torch.cuda.current_stream().cuda_stream)
@@ -123,10 +127,18 @@ def run_case(bk, kw, pa, granular):
     def stage(u, t, dt, x_base, a, b, out):
         ctx.setup(t)
         ctx.ho_apply(u, k)
+        lo = kw.get("lo", 5)
         if not granular:
-            ctx.limit_fused(u, k, dt, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
+            if lo == 5:
+                ctx.limit_fused(u, k, dt, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
+            else:
+                (ctx.lo_rdsubcell if lo == 4 else ctx.lo_rd)(u, dulo)
+                ctx.limit_fused_lo(u, k, dulo, dt, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
             return
-        ctx.lo_massavg(u, k, dt, dulo)
+        if lo == 5:
+            ctx.lo_massavg(u, k, dt, dulo)
+        else:
+            (ctx.lo_rdsubcell if lo == 4 else ctx.lo_rd)(u, dulo)
         ctx.elem_minmax(u, xmn, xmx)
         ctx.bounds(xmn, xmx, umin, umax)
         if bk.gpu:
@@ -151,6 +163,22 @@ def run_case(bk, kw, pa, granular):
     xh, mh = bk.host(x), bk.host(m)
     ctx.close()
     return float((mh * xh).sum()), xh, steps, r
+
+
+def check_rd(bk, mesh, rs, p, prob, t, lo):
+    """PAResidualDistribution[Subcell]::CalcLOSolution (remhos_lo.cpp:965-1034, 1620-1802) in 2-D against the oracle's
+    restatement of the host form (remhos_lo.cpp:111-245); no linear solve involved"""
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.004, t_final=0.7, lo=lo)
+    r = Remhos(cfg)
+    ctx = bk.context(r)
+    uh = perturbed(r.u)
+    keep = {}
+    r.stage(uh, t, cfg.dt, keep)
+    u, dulo = bk.arr(uh), bk.arr(np.zeros_like(uh))
+    ctx.setup(t)
+    (ctx.lo_rdsubcell if lo == 4 else ctx.lo_rd)(u, dulo)
+    assert _rel(bk.host(dulo), keep["du_lo"]) < 1e-12
+    ctx.close()
 
 
 def _kw(e):
@@ -178,6 +206,12 @@ def test_2d_ctest0_first_step_emulated(emu):
     assert np.abs(x - r.u).max() < 1e-11
 
 
+@pytest.mark.parametrize("mesh,rs,p,prob,t,lo", [("inline-quad", 0, 2, 14, 0.3, 4), ("periodic-square", 1, 3, 5, 0.0, 4),
+                                                ("inline-quad", 0, 4, 14, 0.6, 4), ("inline-quad", 0, 3, 14, 0.5, 3)])
+def test_2d_rd_vs_oracle_emulated(emu, mesh, rs, p, prob, t, lo):
+    check_rd(emu, mesh, rs, p, prob, t, lo)
+
+
 def test_2d_refusals(emu):
     """what dim = 2 does not have says so (no silent 3-D kernel on 2-D data)"""
     r = Remhos(Config(mesh="inline-quad", rs=0, order=2, problem=14, dt=0.01, t_final=0.5, lo=5))
@@ -185,7 +219,7 @@ def test_2d_refusals(emu):
     u = emu.arr(r.u)
     from remhos_amd.capi import RmhError
 
-    for call in (lambda: ctx.stage_fused(u, 0.01, u * 0.0), lambda: ctx.lo_rdsubcell(u, u * 0.0)):
+    for call in (lambda: ctx.stage_fused(u, 0.01, u * 0.0), lambda: ctx.halo_pack_records(u, None, 0, u * 0.0)):
         with pytest.raises(RmhError, match="dim = 2"):
             call()
     ctx.close()
@@ -215,3 +249,27 @@ def test_2d_reference_ctests_gpu(dev, name, pa, granular):
     assert steps == e["max_steps"]
     assert abs(mass - e["mass"]) <= 1e-12 * abs(e["mass"]), (mass, e["mass"])
     assert abs(mass - e["mass"]) <= 5e-14 * (1.0 + abs(e["mass"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,rs,p,prob,t,lo", [("inline-quad", 1, 2, 14, 0.3, 4), ("periodic-square", 2, 3, 5, 0.0, 4),
+                                                ("inline-quad", 1, 3, 14, 0.6, 4), ("inline-quad", 1, 4, 14, 0.2, 4),
+                                                ("periodic-square", 1, 6, 5, 0.0, 4), ("inline-quad", 1, 3, 14, 0.5, 3)])
+def test_2d_rd_vs_oracle_gpu(dev, mesh, rs, p, prob, t, lo):
+    check_rd(dev, mesh, rs, p, prob, t, lo)
+
+
+AUTOTEST_2D = [e for e in KAT["autotest"] if e["mesh"] in ("inline-quad", "periodic-square") and e.get("fct", 2) == 2 and e["ho"] == 3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e", AUTOTEST_2D, ids=[e["name"] for e in AUTOTEST_2D])
+@pytest.mark.parametrize("granular", [False, True])
+def test_2d_reference_autotest_gpu(dev, e, granular):
+    """The 2-D lines of the reference's regression baseline for -ho 3 -lo 4 -fct 2 (autotest/out_baseline.dat:41-44 inline-quad
+    remap, 500 steps; :61-64 periodic-square transport, 200 steps -- BASELINE.json configs[0]'s case): final mass and maximum,
+    10 significant digits as the reference prints and diffs them, on the MI355X."""
+    kw = {k: e[k] for k in ("mesh", "rs", "order", "problem", "dt", "t_final", "lo")}
+    mass, x, steps, r = run_case(dev, kw, False, granular)
+    assert float(f"{mass:.10g}") == e["mass"], (mass, e["mass"])
+    assert float(f"{x.max():.10g}") == e["max"], (x.max(), e["max"])

@@ -30,7 +30,9 @@ SELECTED = ["tests/test_emu_cpu.py::test_generic_orders_multi_block_race_free", 
             "tests/test_emu_cpu.py::test_kernels_vs_oracle", "tests/test_emu_cpu.py::test_mass_completion_emulated",
             "tests/test_golden.py::test_emulated_kernels_vs_stage_vectors",
             # the wavefront-local LDS hand-offs of the streaming kernels (rmh_stream.hpp: class tables behind wave_lds_fence)
-            "tests/test_emu_cpu.py::test_streaming_kernels_every_order"]
+            "tests/test_emu_cpu.py::test_streaming_kernels_every_order",
+            # dim = 2: the one-wavefront-per-element HO / RD kernel and the 2-D instances of the streaming kernels
+            "tests/test_2d.py::test_2d_stage_vs_oracle_emulated", "tests/test_2d.py::test_2d_rd_vs_oracle_emulated"]
 
 
 def _run(variant, runtime, extra_env):
