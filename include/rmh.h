@@ -95,6 +95,9 @@ typedef struct {
  * checked: RMH_ERR_INVALID otherwise).
  * face_nbr[ne_owned][6], stencil27[ne_owned][27]: outputs (caller-allocated). */
 int rmh_build_tables(int ne_owned, int ne_total, const int *elem_vertices, int *face_nbr, int *stencil27);
+/* The same for quadrilaterals (dim = 2): elem_vertices[ne_total][4], corner k = kx + 2 ky (MFEM's quadrilateral order 0..3 maps
+ * to {0, 1, 3, 2}); outputs face_nbr[ne_owned][4] (f = 2*c + side) and the 3 x 3 stencil [ne_owned][9]. */
+int rmh_build_tables_2d(int ne_owned, int ne_total, const int *elem_vertices, int *face_nbr, int *stencil9);
 
 /* Creation / destruction.  Replaces the construction of LocalInverseHOSolver, MassBasedAvg /
  * PAResidualDistributionSubcell, ClipScaleSolver and DofInfo (remhos.cpp:730, 912-995,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "rmh_dt_estimate_reset", "rmh_dt_estimate_update", "rmh_dt_estimate_get", "rmh_invalidate_extrema",
     "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
     "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_minmax_begin", "rmh_exchange_minmax_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce", "rmh_comm_count",
-    "rmh_build_tables", "rmh_product_ratio", "rmh_elem_minmax_masked", "rmh_fct_product",
+    "rmh_build_tables", "rmh_build_tables_2d", "rmh_product_ratio", "rmh_elem_minmax_masked", "rmh_fct_product",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_exchange_peer.argtypes = [p, i, C.POINTER(i), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll), C.POINTER(ll)]
     lib.rmh_allreduce.argtypes = [p, C.POINTER(d), i, i]
     lib.rmh_build_tables.argtypes = [i, i, p, p, p]
+    lib.rmh_build_tables_2d.argtypes = [i, i, p, p, p]
     lib.rmh_product_ratio.argtypes = [p, p, p, p, p, p]
     lib.rmh_elem_minmax_masked.argtypes = [p, p, p, p, p, p]
     lib.rmh_fct_product.argtypes = [p, p, p, p, p, p, p, p, p, d, p]

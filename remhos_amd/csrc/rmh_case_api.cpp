@@ -124,36 +124,40 @@ int rmhd_case_save(const rmhd_case *c, double t, const double *u, const char *me
 }
 
 
-// include/rmh.h: neighbour tables from the vertex ids of the elements (any element numbering)
-int rmh_build_tables(int ne_owned, int ne_total, const int *ev, int *face_nbr, int *stencil27)
+// include/rmh.h: neighbour tables from the vertex ids of the elements (any element numbering); DIM = 3: 8 corners, 6 faces,
+// 27-entry stencil; DIM = 2: 4 corners, 4 faces, 9-entry stencil
+extern "C++" {
+template <int DIM>
+static int build_tables_dim(int ne_owned, int ne_total, const int *ev, int *face_nbr, int *stencil)
 {
-   if (ne_owned <= 0 || ne_total < ne_owned || !ev || !face_nbr || !stencil27) { return RMH_ERR_INVALID; }
+   constexpr int NC = 1 << DIM, NF = 2 * DIM, NST = DIM == 3 ? 27 : 9, CENTRE = NST / 2, ALL = NC - 1;
+   if (ne_owned <= 0 || ne_total < ne_owned || !ev || !face_nbr || !stencil) { return RMH_ERR_INVALID; }
    std::unordered_map<int, std::vector<int>> v2e; // vertex -> elements (owned and ghost)
-   for (int e = 0; e < ne_total; e++) { for (int k = 0; k < 8; k++) { v2e[ev[(size_t)e * 8 + k]].push_back(e); } }
-   std::fill(stencil27, stencil27 + (size_t)ne_owned * 27, -1);
+   for (int e = 0; e < ne_total; e++) { for (int k = 0; k < NC; k++) { v2e[ev[(size_t)e * NC + k]].push_back(e); } }
+   std::fill(stencil, stencil + (size_t)ne_owned * NST, -1);
    std::vector<int> cand;
    for (int e = 0; e < ne_owned; e++)
    {
-      const int *ve = ev + (size_t)e * 8;
+      const int *ve = ev + (size_t)e * NC;
       cand.clear();
-      for (int k = 0; k < 8; k++) { const auto &l = v2e[ve[k]]; cand.insert(cand.end(), l.begin(), l.end()); }
+      for (int k = 0; k < NC; k++) { const auto &l = v2e[ve[k]]; cand.insert(cand.end(), l.begin(), l.end()); }
       std::sort(cand.begin(), cand.end());
       cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
       for (int o : cand)
       {
-         if (o == e) { stencil27[(size_t)e * 27 + 13] = e; continue; }
-         const int *vo = ev + (size_t)o * 8;
+         if (o == e) { stencil[(size_t)e * NST + CENTRE] = e; continue; }
+         const int *vo = ev + (size_t)o * NC;
          // corners of e shared with o, and the corners of o they coincide with
-         int off[3] = {0, 0, 0}, n = 0, and_e = 7, or_e = 0, and_o = 7, or_o = 0;
-         for (int k = 0; k < 8; k++)
+         int off[3] = {0, 0, 0}, n = 0, and_e = ALL, or_e = 0, and_o = ALL, or_o = 0;
+         for (int k = 0; k < NC; k++)
          {
-            for (int j = 0; j < 8; j++)
+            for (int j = 0; j < NC; j++)
             {
                if (ve[k] == vo[j]) { n++; and_e &= k; or_e |= k; and_o &= j; or_o |= j; }
             }
          }
-         bool ok = n == 4 || n == 2 || n == 1;
-         for (int d = 0; d < 3 && ok; d++)
+         bool ok = n == 1 || n == 2 || (DIM == 3 && n == 4);
+         for (int d = 0; d < DIM && ok; d++)
          {
             const int be_and = (and_e >> d) & 1, be_or = (or_e >> d) & 1;
             const int bo_and = (and_o >> d) & 1, bo_or = (or_o >> d) & 1;
@@ -164,12 +168,23 @@ int rmh_build_tables(int ne_owned, int ne_total, const int *ev, int *face_nbr, i
          // not a face / edge / vertex contact with aligned axes: rotated neighbour, or a periodic direction with fewer
          // than 3 elements (the same element on both sides)
          if (!ok) { return RMH_ERR_INVALID; }
-         stencil27[(size_t)e * 27 + (off[0] + 1) + 3 * (off[1] + 1) + 9 * (off[2] + 1)] = o;
+         stencil[(size_t)e * NST + (off[0] + 1) + 3 * (off[1] + 1) + (DIM == 3 ? 9 * (off[2] + 1) : 0)] = o;
       }
-      const int fs[6] = {12, 14, 10, 16, 4, 22};
-      for (int f = 0; f < 6; f++) { face_nbr[(size_t)e * 6 + f] = stencil27[(size_t)e * 27 + fs[f]]; }
+      const int fs3[6] = {12, 14, 10, 16, 4, 22}, fs2[4] = {3, 5, 1, 7};
+      for (int f = 0; f < NF; f++) { face_nbr[(size_t)e * NF + f] = stencil[(size_t)e * NST + (DIM == 3 ? fs3[f] : fs2[f])]; }
    }
    return RMH_OK;
+}
+} // extern "C++"
+
+int rmh_build_tables(int ne_owned, int ne_total, const int *ev, int *face_nbr, int *stencil27)
+{
+   return build_tables_dim<3>(ne_owned, ne_total, ev, face_nbr, stencil27);
+}
+
+int rmh_build_tables_2d(int ne_owned, int ne_total, const int *ev, int *face_nbr, int *stencil9)
+{
+   return build_tables_dim<2>(ne_owned, ne_total, ev, face_nbr, stencil9);
 }
 
 } // extern "C"

@@ -105,3 +105,47 @@ def test_stage_on_renumbered_mesh(lib):
     y = stage(c.x0, c.vel, c.face_nbr, c.stencil27, c.u0)
     yp = stage(c.x0[inv], c.vel[inv], nbr_p, st_p, c.u0[inv])
     assert np.array_equal(yp, y[inv])
+
+
+@pytest.mark.parametrize("mesh,rs", [("inline-quad", 0), ("inline-quad", 1), ("periodic-square", 0), ("periodic-square", 1)])
+def test_tables_2d_from_vertices_equal_oracle_lattice_tables(lib, mesh, rs):
+    """rmh_build_tables_2d: the quadrilateral analogue (4 corners, 4 faces, 3 x 3 stencil) against the oracle's lattice tables
+    -- the inputs of the dim = 2 tests (tests/test_2d.py) -- also for a random element and vertex numbering."""
+    from oracle.remhos_oracle import make_lattice
+    from tests.helpers import layout_from_oracle
+
+    lat = make_lattice(mesh, rs, 2)
+    nx, ny = lat.n
+    per = mesh.startswith("periodic")
+    vx, vy = (nx, ny) if per else (nx + 1, ny + 1)
+    ev = np.empty((nx * ny, 4), dtype=np.int32)
+    for ey in range(ny):
+        for ex in range(nx):
+            for k in range(4):
+                ix, iy = ex + (k & 1), ey + (k >> 1)
+                if per:
+                    ix, iy = ix % nx, iy % ny
+                ev[ex + nx * ey, k] = ix + vx * iy
+
+    class R:  # what layout_from_oracle reads for the tables
+        pass
+
+    nbr_o = lat.face_neighbors().astype(np.int32)
+    st_o = np.stack([lat.shifted((ox, oy)) for oy in (-1, 0, 1) for ox in (-1, 0, 1)], axis=1).astype(np.int32)
+    lib.rmh_build_tables_2d.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def build2(ev_):
+        ev_ = np.ascontiguousarray(ev_, dtype=np.int32)
+        nbr, st = np.empty((len(ev_), 4), dtype=np.int32), np.empty((len(ev_), 9), dtype=np.int32)
+        return lib.rmh_build_tables_2d(len(ev_), len(ev_), ev_.ctypes.data, nbr.ctypes.data, st.ctypes.data), nbr, st
+
+    rc, nbr, st = build2(ev)
+    assert rc == 0 and np.array_equal(nbr, nbr_o) and np.array_equal(st, st_o)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(len(ev)).astype(np.int32)
+    inv = np.argsort(perm)
+    vperm = rng.permutation(ev.max() + 1).astype(np.int32)
+    rc, nbr_p, st_p = build2(vperm[ev][inv])
+    assert rc == 0
+    remap = lambda t: np.where(t >= 0, perm[np.maximum(t, 0)], -1)  # noqa: E731
+    assert np.array_equal(nbr_p[perm], remap(nbr_o)) and np.array_equal(st_p[perm], remap(st_o))
