@@ -24,7 +24,7 @@ struct RMHContext
    // x0: start positions of the mesh nodes (remhos.cpp:530-531); v_gf: remap displacement (remhos.cpp:562-584) or the
    // advection velocity sampled at the nodes (transport); both in the order-2 nodal space of the mesh.
    // ghost_vertices: the corner vertex ids of the face-, edge- and vertex-neighbour elements owned by other ranks,
-   // [n_ghost][8] in the element's lexicographic corner order with GLOBAL vertex ids (empty on one rank); the owned
+   // [n_ghost][8] in the element's lexicographic corner order with GLOBAL vertex ids (empty on one rank, and for dim = 2); the owned
    // elements' ids are taken from the mesh.  For periodic meshes pass the identified (periodic) vertex ids through
    // owned_vertices instead of letting the constructor read them.
    RMHContext(ParFiniteElementSpace &pfes, const GridFunction &x0, const GridFunction &v_gf, int exec_mode,
@@ -32,26 +32,30 @@ struct RMHContext
               const std::vector<int> *owned_vertices = nullptr)
    {
       Mesh &mesh = *pfes.GetMesh();
-      MFEM_VERIFY(mesh.Dimension() == 3, "the MI355X hot path is built for 3D hexahedral meshes");
+      const int dim = mesh.Dimension();
+      // 3: hexahedra (the whole API); 2: quadrilaterals (HO / LO solvers and the granular limiter sequence, rmh.h "dim = 2")
+      MFEM_VERIFY(dim == 3 || dim == 2, "the MI355X hot path is built for hexahedral and quadrilateral tensor-lattice meshes");
       const int ne = pfes.GetNE();
-      const int n_ghost = (int)ghost_vertices.size() / 8;
+      const int nc = 1 << dim, nf = 2 * dim, nst = dim == 3 ? 27 : 9; // corners, faces, stencil entries per element
+      const int n_ghost = (int)ghost_vertices.size() / nc;
+      MFEM_VERIFY(dim == 3 || n_ghost == 0, "dim = 2 runs on one rank");
 
-      // E-vectors of the nodes: [ne][3][27], node a = ax + 3 (ay + 3 az)
+      // E-vectors of the nodes: [ne][dim][3^dim], node a = ax + 3 (ay + 3 az)
       const FiniteElementSpace &nfes = *x0.FESpace();
-      MFEM_VERIFY(nfes.GetOrder(0) == 2 && nfes.GetVDim() == 3, "mesh nodes must be order 2 (-mo 2, remhos.cpp:222)");
+      MFEM_VERIFY(nfes.GetOrder(0) == 2 && nfes.GetVDim() == dim, "mesh nodes must be order 2 (-mo 2, remhos.cpp:222)");
       const Operator *R = nfes.GetElementRestriction(ElementDofOrdering::LEXICOGRAPHIC);
       Vector x0_e(R->Height()), v_e(R->Height());
       R->Mult(x0, x0_e);
       R->Mult(v_gf, v_e);
-      // MFEM's E-vector layout is (27 nodes, vdim, ne) with the node index fastest: exactly [ne][3][27]
-      // corner vertex ids in lexicographic order; MFEM's hexahedron numbers its corners 0..3 counter-clockwise on the
-      // bottom face, 4..7 on the top one
+      // MFEM's E-vector layout is (3^dim nodes, vdim, ne) with the node index fastest: exactly [ne][dim][3^dim]
+      // corner vertex ids in lexicographic order; MFEM numbers the corners of a quadrilateral, and of the bottom and the top
+      // face of a hexahedron, counter-clockwise
       static const int lex_of_mfem[8] = {0, 1, 3, 2, 4, 5, 7, 6};
-      std::vector<int> ev((size_t)(ne + n_ghost) * 8);
+      std::vector<int> ev((size_t)(ne + n_ghost) * nc);
       if (owned_vertices)
       {
-         MFEM_VERIFY((int)owned_vertices->size() == 8 * ne, "owned_vertices must hold 8 ids per element");
-         for (int i = 0; i < 8 * ne; i++) { ev[i] = (*owned_vertices)[i]; }
+         MFEM_VERIFY((int)owned_vertices->size() == nc * ne, "owned_vertices must hold 2^dim ids per element");
+         for (int i = 0; i < nc * ne; i++) { ev[i] = (*owned_vertices)[i]; }
       }
       else
       {
@@ -59,17 +63,18 @@ struct RMHContext
          for (int e = 0; e < ne; e++)
          {
             mesh.GetElementVertices(e, v);
-            for (int k = 0; k < 8; k++) { ev[(size_t)e * 8 + lex_of_mfem[k]] = v[k]; }
+            for (int k = 0; k < nc; k++) { ev[(size_t)e * nc + lex_of_mfem[k]] = v[k]; }
          }
       }
-      for (size_t i = 0; i < ghost_vertices.size(); i++) { ev[(size_t)ne * 8 + i] = ghost_vertices[i]; }
+      for (size_t i = 0; i < ghost_vertices.size(); i++) { ev[(size_t)ne * nc + i] = ghost_vertices[i]; }
       // neighbour tables for any element numbering (replaces the H1 bounds space of DofInfo, remhos_tools.cpp:355-379)
-      std::vector<int> face_nbr((size_t)ne * 6), stencil27((size_t)ne * 27);
-      MFEM_VERIFY(rmh_build_tables(ne, ne + n_ghost, ev.data(), face_nbr.data(), stencil27.data()) == 0,
+      std::vector<int> face_nbr((size_t)ne * nf), stencil((size_t)ne * nst);
+      MFEM_VERIFY((dim == 3 ? rmh_build_tables(ne, ne + n_ghost, ev.data(), face_nbr.data(), stencil.data())
+                            : rmh_build_tables_2d(ne, ne, ev.data(), face_nbr.data(), stencil.data())) == 0,
                   "rmh_build_tables: the mesh is not an aligned tensor lattice");
 
       rmh_layout L = {};
-      L.dim = 3;
+      L.dim = dim;
       L.order = pfes.GetOrder(0);
       L.mesh_order = 2;
       L.exec_mode = exec_mode;
@@ -78,7 +83,7 @@ struct RMHContext
       L.x0 = x0_e.HostRead();
       L.vel = v_e.HostRead();
       L.face_nbr = face_nbr.data();
-      L.stencil27 = stencil27.data();
+      L.stencil27 = stencil.data();
       L.subcell_vel = nullptr;
       L.device = Device::GetId();
       MFEM_VERIFY(rmh_create(&L, &ctx) == 0, rmh_last_error());

@@ -65,7 +65,9 @@ for name in args.names:
     m_ptr = ctx.lumped_mass_ptr()
     vec = 8.0 * n
     sten = 4.0 * 27 * ne
+    hob = {1: 8.0 * (2 * 8 + 6 * 4 + 162), 2: 8.0 * (2 * 27 + 6 * 9 + 162)}.get(args.order, 8.0 * (2 * (args.order + 1) ** 3 + 6 * (args.order + 1) ** 2 + 162))
     rows = [
+        ("ho_apply (HO alg. bytes)", lambda: ctx.ho_apply(u, du_ho), hob * ne, (du_ho,)),
         ("elem_minmax", lambda: ctx.elem_minmax(u, xe_min, xe_max), vec + 16.0 * ne, (xe_min, xe_max)),
         ("bounds", lambda: ctx.bounds(xe_min, xe_max, umin, umax), 2 * vec + sten + 16.0 * ne, (umin, umax)),
         ("lo_massavg", lambda: ctx.lo_massavg(u, du_ho, dt, du_lo), 4 * vec, (du_lo,)),
