@@ -1,5 +1,6 @@
-"""One-off robustness sweep (GPU): the one-kernel stage against the oracle over option combinations that the test suite
-does not enumerate exhaustively (order x LO solver x bounds type x remap/transport x mesh)."""
+"""One-off robustness sweep (GPU): the one-kernel stage -- and, with --granular, the HO kernel + LO solver + fused limiter
+(rmh_stream.hpp) and the reference's call sequence -- against the oracle over option combinations that the test suite does
+not enumerate exhaustively (order x LO solver x bounds type x remap/transport x mesh)."""
 import itertools
 import sys
 
@@ -13,6 +14,7 @@ from tests.helpers import layout_from_oracle, perturbed  # noqa: E402
 
 REL = {1: 1e-12, 2: 1e-12, 3: 5e-10, 4: 5e-9, 5: 1e-7, 6: 2e-7}
 lib = load_library()
+GRANULAR = "--granular" in sys.argv
 COMPLETION = "--completion" in sys.argv  # the converged solve + Jacobi step + constant mode: the same tolerances hold
 bad = 0
 n = 0
@@ -42,7 +44,22 @@ for p, lo, bt, (mesh, prob, rs) in itertools.product((1, 2, 3, 4, 5, 6), (3, 4, 
     u = torch.from_numpy(u_h).to("cuda:0")
     y, du = torch.empty_like(u), torch.empty_like(u)
     ctx.setup(t)
-    ctx.stage_fused(u, cfg.dt, y, du=du, dt_rk=cfg.dt)
+    if GRANULAR:
+        k, dulo, du2, umin, umax = (torch.empty_like(u) for _ in range(5))
+        xmn, xmx = (torch.empty(u.shape[0], dtype=u.dtype, device=u.device) for _ in range(2))
+        ctx.ho_apply(u, k)
+        if lo == 5:
+            ctx.lo_massavg(u, k, cfg.dt, dulo)
+            ctx.limit_fused(u, k, cfg.dt, du=du)
+        else:
+            (ctx.lo_rdsubcell if lo == 4 else ctx.lo_rd)(u, dulo)
+            ctx.limit_fused_lo(u, k, dulo, cfg.dt, du=du)
+        ctx.elem_minmax(u, xmn, xmx)
+        ctx.bounds(xmn, xmx, umin, umax)
+        ctx.fct_clipscale(u, ctx.lumped_mass_ptr(), k, dulo, umin, umax, cfg.dt, du2)
+        du = torch.where((du - du2).abs() > (du2 - torch.from_numpy(du_ref).to(u.device)).abs(), du, du2)  # the worse of the two
+    else:
+        ctx.stage_fused(u, cfg.dt, y, du=du, dt_rk=cfg.dt)
     torch.cuda.synchronize()
     err = float(np.abs(du.cpu().numpy() - du_ref).max() / np.abs(du_ref).max())
     n += 1
