@@ -79,8 +79,9 @@ typedef struct {
  * `stencil27` = the 3 x 3 element stencil [ne][9] (entry (ox+1) + 3*(oy+1)), ne_ghost = 0, subcell_vel [ne][2][(p+1)^2] or NULL; E-vectors
  * carry (p+1)^2 doubles per element; Q = p + 2 quadrature points per direction.  Entry points: rmh_setup,
  * rmh_ho_apply, rmh_lumped_mass, rmh_compute_lumped_mass, rmh_lo_massavg, rmh_lo_rd, rmh_lo_rdsubcell, rmh_elem_minmax, rmh_bounds, rmh_fct_clipscale,
- * rmh_limit_fused, rmh_limit_fused_lo, the mass-rule / bounds-type / dt-control setters and getters, timers.  Everything else
- * (one-kernel stage, product fields, exchange) returns RMH_ERR_INVALID for a 2-D context. */
+ * rmh_limit_fused, rmh_limit_fused_lo, rmh_stage_fused (the whole rank: HO kernel, RD solver for lo 3 / 4 and the fused limiter run
+ * as a sequence inside the library; no tokens), the mass-rule / bounds-type / dt-control setters and getters, timers.  Everything
+ * else (element ranges of a stage, product fields, exchange) returns RMH_ERR_INVALID for a 2-D context. */
 
 /* Neighbour tables from mesh topology (host, no GPU): face_nbr and stencil27 of rmh_layout for ANY element numbering,
  * from the vertex ids of the elements -- what a binding has at hand (Mesh::GetElementVertices; periodic meshes: the

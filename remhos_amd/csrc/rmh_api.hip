@@ -488,7 +488,7 @@ void rmh_destroy(rmh_ctx *c)
    if (!c) { return; }
    (void)hipSetDevice(c->device);
    exchange_free(c);
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_m, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_m, c->d_scr_ho, c->d_scr_lo, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {
@@ -810,10 +810,27 @@ int rmh_stage_fused_chain(rmh_ctx *c, const double *u, double dt, const double *
 {
    if (out_token) { *out_token = 0; }
    if (!c || !u || !y_out) { return fail(RMH_ERR_INVALID, "null argument"); }
-   RMH_3D_ONLY(c, "rmh_stage_fused_chain");
    RMH_ENTER(c);
    if (!(dt > 0.0)) { return fail(RMH_ERR_INVALID, "dt must be positive"); }
    if (y_out == u || du == u) { return fail(RMH_ERR_INVALID, "rmh_stage_fused: the output must not alias u"); }
+   if (c->dim == 2)
+   {
+      // dim = 2: the whole stage as a sequence inside the library -- HO kernel (lumped mass, element extrema), the RD solver
+      // for lo 3 / 4, then the fused limiter with the RK update (rmh_2d.hpp, rmh_stream.hpp); whole rank only, no tokens
+      if (e_begin != 0 || e_end != c->ne || !finish) { return fail(RMH_ERR_INVALID, "rmh_stage_fused_range: dim = 2 runs the whole rank in one call"); }
+      if ((c->lo_type == 3 || c->lo_type == 4) && c->p < 2) { return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 3 / 4 needs order >= 2"); }
+      if (c->lo_type == 4 && !c->d_subvel) { return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 4 needs rmh_layout.subcell_vel"); }
+      const size_t n = (size_t)c->ne * c->ndof;
+      if (!c->d_scr_ho) { RMH_HIP(hipMalloc((void **)&c->d_scr_ho, n * sizeof(double))); }
+      if (c->lo_type != 5 && !c->d_scr_lo) { RMH_HIP(hipMalloc((void **)&c->d_scr_lo, n * sizeof(double))); }
+      int rc2 = rmh_ho_apply(c, u, c->d_scr_ho);
+      if (rc2) { return rc2; }
+      if (c->lo_type == 4) { rc2 = rmh_lo_rdsubcell(c, u, c->d_scr_lo); }
+      else if (c->lo_type == 3) { rc2 = rmh_lo_rd(c, u, c->d_scr_lo); }
+      if (rc2) { return rc2; }
+      return c->lo_type == 5 ? rmh_limit_fused(c, u, c->d_scr_ho, dt, du, x_base, a, b, dt_rk, y_out)
+                             : rmh_limit_fused_lo(c, u, c->d_scr_ho, c->d_scr_lo, dt, du, x_base, a, b, dt_rk, y_out);
+   }
    if (e_begin < 0 || e_end > c->ne || e_begin > e_end) { return fail(RMH_ERR_INVALID, "rmh_stage_fused_range: bad element range"); }
    if (c->lo_type == 4 && (c->p < 2 || !c->d_subvel))
    {

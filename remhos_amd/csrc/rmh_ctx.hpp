@@ -45,6 +45,7 @@ struct rmh_ctx
    double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
    double *d_fgeo = nullptr;                        // face speed coefficients (face_geom_kernel)
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
+   double *d_scr_ho = nullptr, *d_scr_lo = nullptr; // dim = 2: du_HO / du_LO between the kernels of rmh_stage_fused (made on first use)
    double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)
    // d_xe_min / d_xe_max hold the element extrema of the output of the last FINISHED fused stage iff xe_token != 0; the
    // stage returned that token, and only a caller that presents it gets them reused (rmh_stage_fused_chain)

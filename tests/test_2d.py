@@ -60,6 +60,8 @@ class Backend:
         assert ctx.dim == 2
         if self.gpu:
             ctx.set_stream(self.torch.cuda.current_stream().cuda_stream)
+        if r.cfg.lo in (3, 4):
+            ctx.set_lo_type(r.cfg.lo)
         if pa:
             ctx.set_mass_tol(0.0, 1e-8, 100)  # DGMassInverse's rule (remhos_ho.cpp:79-80) ...
             ctx.set_mass_completion(True, True)  # ... completed (include/remhos_amd/solvers.hpp)
@@ -126,8 +128,15 @@ def run_case(bk, kw, pa, granular):
 
     def stage(u, t, dt, x_base, a, b, out):
         ctx.setup(t)
-        ctx.ho_apply(u, k)
         lo = kw.get("lo", 5)
+        if granular == "stage":  # the whole stage behind one entry point (a sequence inside the library for dim = 2)
+            if out is u:  # (rmh_stage_fused must not write over its input)
+                ctx.stage_fused(u, dt, k, x_base=x_base, a=a, b=b, dt_rk=dt)
+                out[...] = k
+            else:
+                ctx.stage_fused(u, dt, out, x_base=x_base, a=a, b=b, dt_rk=dt)
+            return
+        ctx.ho_apply(u, k)
         if not granular:
             if lo == 5:
                 ctx.limit_fused(u, k, dt, x_base=x_base, a=a, b=b, dt_rk=dt, y_out=out)
@@ -204,6 +213,9 @@ def test_2d_ctest0_first_step_emulated(emu):
     assert steps == out["steps"] == 1
     assert abs(mass - out["mass"]) <= 1e-13 * abs(out["mass"])
     assert np.abs(x - r.u).max() < 1e-11
+    # the same step through rmh_stage_fused (one entry point per stage)
+    mass2, x2, _, _ = run_case(emu, kw, True, "stage")
+    assert abs(mass2 - out["mass"]) <= 1e-13 * abs(out["mass"]) and np.abs(x2 - r.u).max() < 1e-11
 
 
 @pytest.mark.parametrize("mesh,rs,p,prob,t,lo", [("inline-quad", 0, 2, 14, 0.3, 4), ("periodic-square", 1, 3, 5, 0.0, 4),
@@ -219,7 +231,7 @@ def test_2d_refusals(emu):
     u = emu.arr(r.u)
     from remhos_amd.capi import RmhError
 
-    for call in (lambda: ctx.stage_fused(u, 0.01, u * 0.0), lambda: ctx.halo_pack_records(u, None, 0, u * 0.0)):
+    for call in (lambda: ctx.stage_fused_range(u, 0.01, u * 0.0, 0, 1, True), lambda: ctx.halo_pack_records(u, None, 0, u * 0.0)):
         with pytest.raises(RmhError, match="dim = 2"):
             call()
     ctx.close()
@@ -238,7 +250,7 @@ def test_2d_stage_vs_oracle_gpu(dev, mesh, rs, p, prob, t, bt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,pa,granular", [("ctest0", False, True), ("ctest0", True, False), ("ctest1", False, False),
                                               ("ctest2", False, False), ("ctest2", True, True), ("ctest5", True, False),
-                                              ("ctest5", True, True)])
+                                              ("ctest5", True, True), ("ctest0", True, "stage"), ("ctest1", False, "stage")])
 def test_2d_reference_ctests_gpu(dev, name, pa, granular):
     """The 2-D entries of the reference's test table on the MI355X: final mass against the reference's 17-digit constants
     (its own check: 10 eps relative to 1 + |x|, remhos_tests.cpp:13-23; BASELINE.json: 1e-12 relative).  pa = False: the
@@ -264,7 +276,7 @@ AUTOTEST_2D = [e for e in KAT["autotest"] if e["mesh"] in ("inline-quad", "perio
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("e", AUTOTEST_2D, ids=[e["name"] for e in AUTOTEST_2D])
-@pytest.mark.parametrize("granular", [False, True])
+@pytest.mark.parametrize("granular", [False, True, "stage"])
 def test_2d_reference_autotest_gpu(dev, e, granular):
     """The 2-D lines of the reference's regression baseline for -ho 3 -lo 4 -fct 2 (autotest/out_baseline.dat:41-44 inline-quad
     remap, 500 steps; :61-64 periodic-square transport, 200 steps -- BASELINE.json configs[0]'s case): final mass and maximum,

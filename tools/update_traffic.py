@@ -6,7 +6,9 @@ sources it was measured on (bench.py refuses an entry whose hash differs), the m
 
 FETCH_SIZE on gfx950 under-reports coalesced reads (MI355X_MICROARCH.md: exactly 1/2 for 16-byte-per-lane streams); for
 this kernel's 8-byte-per-lane loads the factor was calibrated in round 1 on limit_fused_kernel, whose read bytes are
-known exactly: 1.771.  WRITE_SIZE needs no correction."""
+known exactly: 1.771 (`hbm_bytes_per_launch`).  Round 4's streaming kernels (profiles/r04_streaming_traffic.txt) show the guide's
+factor 2 to be exact for these loads too -- the first-generation limiter read less than was assumed -- so bench.py reports
+`hbm_bytes_per_launch_x2` as `roofline.traffic` and the calibrated figure as `traffic_cal1771`.  WRITE_SIZE needs no correction."""
 import csv
 import glob
 import json
