@@ -51,7 +51,7 @@ typedef struct {
 typedef struct {
    int order, exec_mode, ndof, ne_owned, ne_ghost, n_peers;
    int ne_halo;       /* owned elements [0, ne_halo) reach a ghost through their 27-stencil */
-   int pad_;
+   int dim;           /* 3: hexahedra; 2: quadrilaterals (inline-quad, periodic-square: one rank; arrays [ne][2][9], 4 faces, 3 x 3 stencil) */
    long long ne_global;
    int n[3], lo[3], nl[3];
    double dt;

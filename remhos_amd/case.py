@@ -32,7 +32,7 @@ class RmhdConfig(C.Structure):
 class RmhdCaseInfo(C.Structure):
     _fields_ = [
         ("order", C.c_int), ("exec_mode", C.c_int), ("ndof", C.c_int), ("ne_owned", C.c_int),
-        ("ne_ghost", C.c_int), ("n_peers", C.c_int), ("ne_halo", C.c_int), ("pad_", C.c_int), ("ne_global", C.c_longlong),
+        ("ne_ghost", C.c_int), ("n_peers", C.c_int), ("ne_halo", C.c_int), ("dim", C.c_int), ("ne_global", C.c_longlong),
         ("n", C.c_int * 3), ("lo", C.c_int * 3), ("nl", C.c_int * 3), ("dt", C.c_double),
         ("bb_min", C.c_double * 3), ("bb_max", C.c_double * 3),
     ]
@@ -127,14 +127,15 @@ class Case:
         self.dt = info.dt
         self.bb_min, self.bb_max = list(info.bb_min), list(info.bb_max)
         ne, nd = self.ne_owned, self.ndof
-        self.x0 = _view(lib.rmhd_case_x0(h), (ne, 3, 27), np.float64)
-        self.vel = _view(lib.rmhd_case_vel(h), (ne, 3, 27), np.float64)
+        dim = self.dim = info.dim  # 3, or 2 for the quadrilateral lattices (inline-quad, periodic-square)
+        self.x0 = _view(lib.rmhd_case_x0(h), (ne, dim, 3**dim), np.float64)
+        self.vel = _view(lib.rmhd_case_vel(h), (ne, dim, 3**dim), np.float64)
         self.u0 = _view(lib.rmhd_case_u0(h), (ne, nd), np.float64)
         self.s0 = _view(lib.rmhd_case_s0(h), (ne, nd), np.float64)
         sv = lib.rmhd_case_subcell_vel(h)
-        self.subcell_vel = _view(sv, (ne, 3, nd), np.float64) if sv else None
-        self.face_nbr = _view(lib.rmhd_case_face_nbr(h), (ne, 6), np.int32)
-        self.stencil27 = _view(lib.rmhd_case_stencil27(h), (ne, 27), np.int32)
+        self.subcell_vel = _view(sv, (ne, dim, nd), np.float64) if sv else None
+        self.face_nbr = _view(lib.rmhd_case_face_nbr(h), (ne, 2 * dim), np.int32)
+        self.stencil27 = _view(lib.rmhd_case_stencil27(h), (ne, 3**dim), np.int32)
         self.owned_gid = _view(lib.rmhd_case_owned_gid(h), (ne,), np.int64)
         self.ghost_gid = _view(lib.rmhd_case_ghost_gid(h), (self.ne_ghost,), np.int64)
         self.peers = []

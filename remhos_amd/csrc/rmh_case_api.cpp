@@ -70,6 +70,7 @@ int rmhd_case_get_info(const rmhd_case *c, rmhd_case_info *info)
    info->ne_owned = d.ne_owned;
    info->ne_ghost = d.ne_ghost;
    info->ne_halo = d.ne_halo;
+   info->dim = d.dim;
    info->n_peers = (int)d.peers.size();
    info->ne_global = d.ne_global;
    for (int k = 0; k < 3; k++)

@@ -506,7 +506,7 @@ extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, i
    if (!err.empty()) { g_driver_error = err; return -1; }
 
    rmh_layout L;
-   L.dim = 3;
+   L.dim = cd.dim; // (2: the reference's quadrilateral lattices, one rank -- build_case_2d)
    L.order = cd.order;
    L.mesh_order = 2;
    L.exec_mode = cd.exec_mode;
@@ -947,6 +947,7 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       const std::string err = build_case(cc, b.cd);
       if (!err.empty()) { g_driver_error = err; cleanup(); return -1; }
       rmh_layout L;
+      if (b.cd.dim != 3) { g_driver_error = "the partitioned stage loop is for the 3-D cases"; cleanup(); return -1; }
       L.dim = 3; L.order = b.cd.order; L.mesh_order = 2; L.exec_mode = b.cd.exec_mode;
       L.ne_owned = b.cd.ne_owned; L.ne_ghost = b.cd.ne_ghost;
       L.x0 = b.cd.x0.data(); L.vel = b.cd.vel.data(); L.face_nbr = b.cd.face_nbr.data(); L.stencil27 = b.cd.stencil27.data();

@@ -191,8 +191,252 @@ double u0_function(int problem, const double *bb_min, const double *bb_max, cons
 // Simple nonlinear function (remhos.cpp:2357-2361): physical coordinates, no bounding-box map
 double s0_function(const double x[3]) { return 2.0 + std::sin(2 * M_PI * x[0]) * std::sin(2 * M_PI * x[1]); }
 
+// ---- dim = 2 ------------------------------------------------------------------------------------------
+// remhos.cpp:2001-2120 with dim = 2
+void velocity_function_2d(int problem, const double *bb_min, const double *bb_max, const double x[2], double v[2])
+{
+   double X[2];
+   for (int i = 0; i < 2; i++) { X[i] = 2 * (x[i] - (bb_min[i] + bb_max[i]) * 0.5) / (bb_max[i] - bb_min[i]); }
+   v[0] = v[1] = 0.0;
+   switch (problem % 20)
+   {
+      case 0: v[0] = std::sqrt(2. / 3.); v[1] = std::sqrt(1. / 3.); break;
+      case 1:
+      case 2:
+      case 4: { const double w = M_PI / 2; v[0] = -w * X[1]; v[1] = w * X[0]; break; }
+      case 5: v[0] = 1.0; v[1] = 1.0; break;
+      case 10:
+      case 12:
+      case 13:
+      case 14:
+      case 15:
+      case 16:
+      case 17:
+         // Taylor-Green deformation; map [-1,1] to [0,1]
+         for (int d = 0; d < 2; d++) { X[d] = X[d] * 0.5 + 0.5; }
+         v[0] = std::sin(M_PI * X[0]) * std::cos(M_PI * X[1]);
+         v[1] = -std::cos(M_PI * X[0]) * std::sin(M_PI * X[1]);
+         break;
+      default: break;
+   }
+}
+
+namespace
+{
+inline double box2D(double x0, double y0, double x1, double y1, double theta, double ox, double oy, double x, double y)
+{
+   const double s = std::sin(theta * M_PI / 180), c = std::cos(theta * M_PI / 180);
+   const double xn = c * (x - ox) - s * (y - oy) + ox;
+   const double yn = s * (x - ox) + c * (y - oy) + oy;
+   return (xn > x0 && xn < x1 && yn > y0 && yn < y1) ? 1.0 : 0.0;
+}
+inline double ring2(double rin, double rout, double cx, double cy, const double y[2])
+{
+   const double r = std::sqrt((y[0] - cx) * (y[0] - cx) + (y[1] - cy) * (y[1] - cy));
+   return (r > rin && r < rout) ? 1.0 : 0.0;
+}
+} // namespace
+
+// remhos.cpp:2201-2355 with dim = 2
+double u0_function_2d(int problem, const double *bb_min, const double *bb_max, const double x[2])
+{
+   double X[2];
+   for (int i = 0; i < 2; i++) { X[i] = 2 * (x[i] - (bb_min[i] + bb_max[i]) * 0.5) / (bb_max[i] - bb_min[i]); }
+   switch (problem % 10)
+   {
+      case 0:
+      case 1:
+      {
+         const double rx = 0.45, ry = 0.25, cx = 0., cy = -0.2, w = 10.;
+         return (std::erfc(w * (X[0] - cx - rx)) * std::erfc(-w * (X[0] - cx + rx)) * std::erfc(w * (X[1] - cy - ry)) *
+                 std::erfc(-w * (X[1] - cy + ry))) / 16;
+      }
+      case 4:
+      {
+         // slotted disk, cone and hump ("pacman" remap runs use it as problem 14)
+         const double scale = 0.0225, coef = 0.5 / std::sqrt(scale);
+         const bool slit = (X[0] <= -0.05) || (X[0] >= 0.05) || (X[1] >= 0.7);
+         const double r_disk = X[0] * X[0] + (X[1] - 0.5) * (X[1] - 0.5);
+         const double r_cone = X[0] * X[0] + (X[1] + 0.5) * (X[1] + 0.5);
+         const double r_hump = (X[0] + 0.5) * (X[0] + 0.5) + X[1] * X[1];
+         if (slit && r_disk <= 4. * scale) { return 1.0; }
+         return (1. - coef * std::sqrt(r_cone)) * (r_cone <= 4. * scale ? 1.0 : 0.0) +
+                .25 * (1. + std::cos(M_PI * coef * std::sqrt(r_hump))) * (r_hump <= 4. * scale ? 1.0 : 0.0);
+      }
+      case 5:
+      {
+         // balls and jacks: a rotated cross and two rings, indicator values
+         const double y[2] = {50. * (x[0] + 1.), 50. * (x[1] + 1.)};
+         const double rect1 = box2D(14., 3., 17., 26., -45., 15.5, 11.5, y[0], y[1]);
+         const double rect2 = box2D(7., 10., 32., 13., -45., 15.5, 11.5, y[0], y[1]);
+         return (rect1 + rect2 - rect1 * rect2) + ring2(7., 10., 40., 40., y) + ring2(3., 7., 40., 20., y);
+      }
+      default: return 0.0;
+   }
+}
+
+// The reference's 2-D lattice meshes on ONE rank: data/inline-quad.mesh (4 x 4 quadrilaterals on [0,1]^2) and
+// data/periodic-square.mesh (3 x 3 on [-1,1]^2, 9-decimal coordinates: part of the reference's answers).  Same steps as the
+// 3-D builder below: CFL step, Q2 nodes and remap displacement (with the reference's "t advances first" loop), per-element
+// node copies, nodal initial condition at the closed-uniform points, sub-mesh velocity for lo 4, neighbour tables.
+static std::string build_case_2d(const CaseConfig &cfg, CaseData &out)
+{
+   std::vector<double> coarse;
+   bool periodic = false;
+   if (cfg.mesh == "inline-quad") { coarse = {0.0, 0.25, 0.5, 0.75, 1.0}; }
+   else if (cfg.mesh == "periodic-square") { coarse = {-1.0, -0.333333333, 0.333333333, 1.0}; periodic = true; }
+   else { return "unknown 2-D lattice mesh '" + cfg.mesh + "'"; }
+   if (cfg.order < 1 || cfg.order > 6) { return "order must be in 1..6"; }
+   if (cfg.px != 1 || cfg.py != 1 || cfg.pz != 1 || cfg.rank != 0 || cfg.self_wrap != 0) { return "dim = 2 runs on one rank"; }
+   if (cfg.rs_extra[0] || cfg.rs_extra[1] || cfg.rs_extra[2]) { return "dim = 2: no rs_extra"; }
+   if (cfg.lo_type != 3 && cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 3, 4 or 5"; }
+   const std::vector<double> verts = refine(coarse, cfg.rs);
+   const int N = (int)verts.size() - 1, p = cfg.order, D = p + 1, problem = cfg.problem;
+   out = CaseData();
+   out.dim = 2;
+   out.order = p;
+   out.exec_mode = problem < 10 ? 0 : 1;
+   out.ndof = D * D;
+   out.periodic = periodic;
+   out.ne_global = (long long)N * N;
+   out.ne_owned = N * N;
+   for (int d = 0; d < 3; d++)
+   {
+      out.n[d] = d < 2 ? N : 1;
+      out.lo[d] = 0;
+      out.nl[d] = out.n[d];
+      out.bb_min[d] = d < 2 ? verts.front() : 0.0;
+      out.bb_max[d] = d < 2 ? verts.back() : 0.0;
+   }
+   const int ne = out.ne_owned, nn1 = 2 * N + 1;
+   const double *bmin = out.bb_min, *bmax = out.bb_max;
+   std::vector<double> n1(nn1);
+   for (int i = 0; i <= N; i++) { n1[2 * i] = verts[i]; }
+   for (int i = 0; i < N; i++) { n1[2 * i + 1] = 0.5 * verts[i] + 0.5 * verts[i + 1]; }
+   // time step (remhos.cpp:538-553): 0.25 * |det J(center)|^(1/2) / |v(center)|
+   double dt = cfg.dt;
+   if (dt < 0.0)
+   {
+      dt = INFINITY;
+      for (int ey = 0; ey < N; ey++)
+      {
+         for (int ex = 0; ex < N; ex++)
+         {
+            const double hx = n1[2 * ex + 2] - n1[2 * ex], hy = n1[2 * ey + 2] - n1[2 * ey];
+            const double xc[2] = {n1[2 * ex + 1], n1[2 * ey + 1]};
+            double v[2];
+            velocity_function_2d(problem, bmin, bmax, xc, v);
+            dt = std::fmin(dt, 0.25 * std::sqrt(std::fabs(hx * hy)) / std::sqrt(v[0] * v[0] + v[1] * v[1] + 1e-14));
+         }
+      }
+   }
+   out.dt = dt;
+   // lattice nodes: positions and remap displacement (remhos.cpp:562-584)
+   const bool remap = out.exec_mode == 1;
+   std::vector<double> xn((size_t)2 * nn1 * nn1), vn((size_t)2 * nn1 * nn1);
+   for (int iy = 0; iy < nn1; iy++)
+   {
+      for (int ix = 0; ix < nn1; ix++)
+      {
+         const double x0[2] = {n1[ix], n1[iy]};
+         double x[2] = {x0[0], x0[1]}, v[2];
+         velocity_function_2d(problem, bmin, bmax, x, v);
+         if (remap)
+         {
+            double t = 0.0; // (the reference's order: t advances BEFORE min(dt, t_final - t) is taken)
+            while (t < cfg.t_final)
+            {
+               t += dt;
+               const double hh = std::min(dt, cfg.t_final - t);
+               for (int c = 0; c < 2; c++) { x[c] = x[c] + hh * v[c]; }
+               velocity_function_2d(problem, bmin, bmax, x, v);
+            }
+            for (int c = 0; c < 2; c++) { v[c] = x[c] - x0[c]; }
+         }
+         const size_t k = (size_t)ix + (size_t)nn1 * iy;
+         for (int c = 0; c < 2; c++) { xn[2 * k + c] = x0[c]; vn[2 * k + c] = v[c]; }
+      }
+   }
+   out.x0.resize((size_t)ne * 18);
+   out.vel.resize((size_t)ne * 18);
+   out.u0.resize((size_t)ne * out.ndof);
+   out.s0.resize((size_t)ne * out.ndof);
+   const bool lo4 = cfg.lo_type == 4;
+   if (lo4) { out.subcell_vel.assign((size_t)ne * 2 * out.ndof, 0.0); }
+   out.owned_gid.resize(ne);
+   std::vector<double> Lcu(3 * D);
+   for (int i = 0; i < D; i++) { lag2((double)i / p, &Lcu[3 * i]); }
+   for (int e = 0; e < ne; e++)
+   {
+      const int ex = e % N, ey = e / N;
+      out.owned_gid[e] = e;
+      double *ex0 = &out.x0[(size_t)e * 18], *ev = &out.vel[(size_t)e * 18];
+      for (int ay = 0; ay < 3; ay++)
+      {
+         for (int ax = 0; ax < 3; ax++)
+         {
+            const size_t k = (size_t)(2 * ex + ax) + (size_t)nn1 * (2 * ey + ay);
+            for (int c = 0; c < 2; c++)
+            {
+               ex0[c * 9 + ax + 3 * ay] = xn[2 * k + c];
+               ev[c * 9 + ax + 3 * ay] = vn[2 * k + c];
+            }
+         }
+      }
+      for (int iy = 0; iy < D; iy++)
+      {
+         for (int ix = 0; ix < D; ix++)
+         {
+            double x[3] = {0, 0, 0};
+            for (int ay = 0; ay < 3; ay++)
+            {
+               for (int ax = 0; ax < 3; ax++)
+               {
+                  const double w = Lcu[3 * ix + ax] * Lcu[3 * iy + ay];
+                  for (int c = 0; c < 2; c++) { x[c] += w * ex0[c * 9 + ax + 3 * ay]; }
+               }
+            }
+            const int i = ix + D * iy;
+            out.u0[(size_t)e * out.ndof + i] = u0_function_2d(problem, bmin, bmax, x); // remhos.cpp:878-884
+            out.s0[(size_t)e * out.ndof + i] = s0_function(x);
+            if (lo4)
+            {
+               // remap: v_sub_gf, the instantaneous velocity at the sub-mesh nodes, zero on the domain boundary of non-periodic
+               // meshes (remhos.cpp:837-853); transport: the advection velocity at the sub-mesh nodes
+               double v[2];
+               velocity_function_2d(problem, bmin, bmax, x, v);
+               const bool bdr = remap && !periodic && ((ex == 0 && ix == 0) || (ex == N - 1 && ix == p) || (ey == 0 && iy == 0) || (ey == N - 1 && iy == p));
+               for (int c = 0; c < 2; c++) { out.subcell_vel[((size_t)e * 2 + c) * out.ndof + i] = bdr ? 0.0 : v[c]; }
+            }
+         }
+      }
+   }
+   // neighbour tables: 3 x 3 stencil (entry (ox+1) + 3 (oy+1)), faces f = 2 c + side
+   out.stencil27.assign((size_t)ne * 9, -1);
+   out.face_nbr.assign((size_t)ne * 4, -1);
+   if (periodic && N < 3) { return "a periodic direction needs at least 3 elements"; }
+   for (int e = 0; e < ne; e++)
+   {
+      const int ex = e % N, ey = e / N;
+      for (int oy = -1; oy <= 1; oy++)
+      {
+         for (int ox = -1; ox <= 1; ox++)
+         {
+            int gx = ex + ox, gy = ey + oy;
+            if (periodic) { gx = (gx + N) % N; gy = (gy + N) % N; }
+            if (gx < 0 || gx >= N || gy < 0 || gy >= N) { continue; }
+            out.stencil27[(size_t)e * 9 + (ox + 1) + 3 * (oy + 1)] = gx + N * gy;
+         }
+      }
+      const int fs[4] = {3, 5, 1, 7};
+      for (int f = 0; f < 4; f++) { out.face_nbr[(size_t)e * 4 + f] = out.stencil27[(size_t)e * 9 + fs[f]]; }
+   }
+   return "";
+}
+
 std::string build_case(const CaseConfig &cfg, CaseData &out)
 {
+   if (cfg.mesh == "inline-quad" || cfg.mesh == "periodic-square") { return build_case_2d(cfg, out); }
    MeshDef md;
    if (!lookup_mesh(cfg.mesh, md)) { return "unknown lattice mesh '" + cfg.mesh + "' (periodic-cube, cube01_hex)"; }
    if (cfg.order < 1 || cfg.order > 6) { return "order must be in 1..6"; }
@@ -592,6 +836,7 @@ void gauss_legendre_01(int n, std::vector<double> &x, std::vector<double> &w)
 std::string lp_error_sums(const CaseData &d, int problem, double t_exact, const double *u, double err[3])
 {
    err[0] = err[1] = err[2] = 0.0;
+   if (d.dim != 3) { return "error norms are implemented for the 3-D cases"; }
    const int prob = problem % 10;
    if (prob != 0 && prob != 4) { return "no exact solution is defined for this problem (4: rotation, 0: translation)"; }
    if (prob == 0 && !d.periodic) { return "the translated exact field is defined on the periodic meshes"; }
@@ -707,6 +952,7 @@ std::string lp_error_sums(const CaseData &d, int problem, double t_exact, const 
 std::string save_mfem(const CaseData &d, double t, const double *u, const char *mesh_path, const char *gf_path)
 {
    if (!mesh_path) { return "null mesh path"; }
+   if (d.dim != 3) { return "-save writes the 3-D meshes"; }
    if ((long long)d.ne_owned != d.ne_global)
    {
       return "rmhd_case_save writes the mesh of a single-rank case (PrintAsOne / SaveAsOne)";

@@ -39,6 +39,7 @@ struct Peer
 
 struct CaseData
 {
+   int dim = 3; // 3: hexahedra; 2: quadrilaterals (single rank: x0 / vel [ne][2][9], face_nbr [ne][4], stencil27 = 3 x 3 [ne][9])
    int order = 0, exec_mode = 0, ndof = 0;
    int ne_owned = 0, ne_ghost = 0;
    int ne_halo = 0;        // owned elements [0, ne_halo) have a ghost in their 27-stencil (ordered first)
@@ -67,6 +68,9 @@ double s0_function(const double x[3]); // remhos.cpp:2357-2361
 
 // returns an empty string on success, an error message otherwise
 std::string build_case(const CaseConfig &cfg, CaseData &out);
+// problem definitions for dim = 2 (the same functions of remhos.cpp restricted to two coordinates)
+void velocity_function_2d(int problem, const double *bb_min, const double *bb_max, const double x[2], double v[2]);
+double u0_function_2d(int problem, const double *bb_min, const double *bb_max, const double x[2]);
 // Error norms the way remhos() reports them (remhos.cpp:1438-1470: ParGridFunction::ComputeLpError against the initial
 // condition for the solid-body rotation, problem 4): L1, L2, L-infinity of |u_h - u_ex| by Gauss-Legendre quadrature
 // of order 2 p + 3 on every element [MFEM: GridFunction::ComputeLpError], the maximum over the quadrature points.  Also

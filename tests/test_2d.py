@@ -224,6 +224,23 @@ def test_2d_rd_vs_oracle_emulated(emu, mesh, rs, p, prob, t, lo):
     check_rd(emu, mesh, rs, p, prob, t, lo)
 
 
+@pytest.mark.parametrize("fused,pa,lo", [(1, 1, 5), (0, 0, 4)])
+def test_2d_cpp_driver_emulated(emu, fused, pa, lo):
+    """rmhd_run (the C++ restatement of remhos(): case builder build_case_2d, solver classes, RK3 loop, report) on the first
+    step of ctest #0's case: one-call stages (rmh_stage_fused) / the solver classes' call sequence, lo 5 / lo 4"""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    kw = dict(_kw(CTEST["ctest0"]), max_steps=1, lo=lo)
+    cfg = make_config(kw["mesh"], kw["rs"], kw["order"], kw["problem"], kw["dt"], kw["t_final"], max_steps=1, lo_type=lo, fused=fused, pa=pa)
+    res = RmhdResult()
+    assert emu.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, emu.lib.rmhd_last_error()
+    out = Remhos(Config(**kw)).run()
+    assert res.steps == out["steps"] == 1
+    assert abs(res.final_mass - out["mass"]) <= 1e-13 * abs(out["mass"]) and abs(res.max_value - out["max"]) <= 1e-12
+
+
 def test_2d_refusals(emu):
     """what dim = 2 does not have says so (no silent 3-D kernel on 2-D data)"""
     r = Remhos(Config(mesh="inline-quad", rs=0, order=2, problem=14, dt=0.01, t_final=0.5, lo=5))
@@ -285,3 +302,38 @@ def test_2d_reference_autotest_gpu(dev, e, granular):
     mass, x, steps, r = run_case(dev, kw, False, granular)
     assert float(f"{mass:.10g}") == e["mass"], (mass, e["mass"])
     assert float(f"{x.max():.10g}") == e["max"], (x.max(), e["max"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,pa", [("ctest0", 0), ("ctest0", 1), ("ctest1", 0), ("ctest2", 0), ("ctest5", 1)])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_2d_cpp_driver_reference_ctests_gpu(dev, name, pa, fused):
+    """The same constants through the product's own harness -- rmhd_run: C++ case builder (build_case_2d: the mesh, the remap
+    displacement, the initial field, the CFL step), solver classes, RK3 loop, report -- no oracle anywhere in the run.  What
+    `remhos_amd_run -m data/inline-quad.mesh -p 14 -rs 4 -o 3 -dt -1 -tf 0.5 -ms 5 -ho 3 -lo 5 -fct 2 [-pa]` prints."""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    e = CTEST[name]
+    cfg = make_config(e["mesh"], e["rs"], e["order"], e["problem"], e["dt"], e["t_final"], max_steps=e["max_steps"], fused=fused, pa=pa)
+    res = RmhdResult()
+    assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
+    assert res.steps == e["max_steps"]
+    assert abs(res.final_mass - e["mass"]) <= 5e-14 * (1.0 + abs(e["mass"])), (res.final_mass, e["mass"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e", AUTOTEST_2D, ids=[e["name"] for e in AUTOTEST_2D])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_2d_cpp_driver_reference_autotest_gpu(dev, e, fused):
+    """autotest/out_baseline.dat:41-44, 61-64 (-ho 3 -lo 4 -fct 2 in 2-D; periodic-square is BASELINE configs[0]'s case) through
+    rmhd_run: mass and maximum, ten printed digits"""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    cfg = make_config(e["mesh"], e["rs"], e["order"], e["problem"], e["dt"], e["t_final"], lo_type=4, fused=fused)
+    res = RmhdResult()
+    assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
+    assert float(f"{res.final_mass:.10g}") == e["mass"] and float(f"{res.max_value:.10g}") == e["max"], (res.final_mass, res.max_value)

@@ -18,6 +18,11 @@ CASES = [
     ("cube01_hex", 1, 2, 10, -1.0, 0.5),
     ("periodic-cube", 1, 3, 10, -1.0, 0.5),
     ("periodic-cube", 1, 2, 0, 0.015, 2.0),
+    # dim = 2 (build_case_2d): the meshes of the reference's 2-D ctest / autotest entries
+    ("inline-quad", 1, 2, 14, -1.0, 0.5),
+    ("inline-quad", 2, 3, 14, 0.0015, 0.75),
+    ("periodic-square", 1, 3, 5, 0.004, 0.8),
+    ("periodic-square", 0, 2, 0, 0.01, 0.5),
 ]
 
 
@@ -34,6 +39,8 @@ def test_case_matches_oracle(lib, mesh, rs, p, prob, dt, tf):
     assert np.array_equal(c.stencil27, st)
     if r.exec_mode == 1:
         assert np.abs(c.subcell_vel - r.Vs.transpose(0, 2, 1)).max() < 1e-15
+    else:
+        assert np.abs(c.subcell_vel - r.vel(r.Xs0).transpose(0, 2, 1)).max() < 1e-15
 
 
 @pytest.mark.parametrize("mesh,rs,part,extra", [("periodic-cube", 1, (2, 1, 1), (0, 0, 0)), ("periodic-cube", 1, (2, 2, 2), (0, 0, 0)),
