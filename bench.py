@@ -517,6 +517,35 @@ def granular_block(args, lib, world, rank, dev, dist, backend):
             "timing": f"each streaming kernel alone, {reps} launches between two HIP events on the context's stream, after 2 RK steps"}
 
 
+def config0_block(lib):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case, 2-D periodic-square transport with RK3 -- through the
+    product's harness on the GPU (rmhd_run: C++ case builder, solver classes, dim = 2 kernels): the autotest line
+    `-m data/periodic-square.mesh -p 5 -rs 3 -dt 0.004 -tf 0.8 -ho 3 -lo 4 -fct 2` (order 3, 200 steps; autotest/test.sh:51,
+    expected autotest/out_baseline.dat:61-64) with its printed mass and maximum as a verdict, and configs[0]'s own order 2.
+    A parity block, not a performance claim: 9 216 / 5 184 dofs, a few launches of ~10 us per stage."""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    out = {"what": "BASELINE configs[0] (2D periodic-square transport, RK3, -ho 3 -lo 4 -fct 2) on the GPU through rmhd_run; dim = 2 kernels "
+                   "(remhos_amd/csrc/rmh_2d.hpp + the streaming kernels), the reference's call sequence (fused = 0)"}
+    ref = {"mass": 0.1623263888, "max": 0.7145371968, "source": "autotest/out_baseline.dat:61-64 (10 significant digits, order 3)"}
+    for order in (3, 2):
+        res = RmhdResult()
+        cfg = make_config("periodic-square", 3, order, 5, 0.004, 0.8, lo_type=4, fused=0)
+        if lib.rmhd_run(C.byref(cfg), C.byref(res)) != 0:
+            out[f"o{order}"] = {"error": lib.rmhd_last_error().decode()}
+            continue
+        blk = {"workload": f"periodic-square -p 5 -rs 3 -o {order} -dt 0.004 -tf 0.8 -ho 3 -lo 4 -fct 2", "steps": res.steps,
+               "dofs": int(res.global_dofs), "final_mass": res.final_mass, "max_value": res.max_value,
+               "value": res.fom_wall, "unit": "MDOFs*RK-stage/s (wall clock of the whole loop)", "wall_s": res.wall}
+        if order == 3:
+            blk["reference"] = ref
+            blk["pass"] = bool(float(f"{res.final_mass:.10g}") == ref["mass"] and float(f"{res.max_value:.10g}") == ref["max"])
+        out[f"o{order}"] = blk
+    return out
+
+
 def measure_cpp_loop(args, lib, world, rank, device, comm_file):
     """N > 1: the C++ stage loop (rmhd_run_partitioned, remhos_amd/csrc/rmh_driver.hip) -- one process per GPU, the
     halo exchange as grouped RCCL send/recv inside the library, no Python between the launches (at N = 8 strong
@@ -787,6 +816,8 @@ def main():
     if extras and default_case and args.lo == 5 and world == 1 and not args.unfused and not args.two_kernels:
         granular = granular_block(args, lib, world, rank, dev, dist, backend)
 
+    config0 = config0_block(lib) if (extras and default_case and world == 1) else None
+
     lo4 = None
     if extras and default_case and args.lo == 5:
         # the LO solver BASELINE.json's north_star names: subcell residual distribution (-lo 4) in the one-kernel stage
@@ -838,6 +869,8 @@ def main():
             out["lo4"] = lo4
         if granular is not None:
             out["granular"] = granular
+        if config0 is not None:
+            out["configs0_2d"] = config0
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, args.order, args.rs, args.mass_solve)
         print(json.dumps(out), flush=True)
