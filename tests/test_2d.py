@@ -337,3 +337,22 @@ def test_2d_cpp_driver_reference_autotest_gpu(dev, e, fused):
     res = RmhdResult()
     assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
     assert float(f"{res.final_mass:.10g}") == e["mass"] and float(f"{res.max_value:.10g}") == e["max"], (res.final_mass, res.max_value)
+
+
+AUTOTEST_2D_HO2 = [e for e in KAT["autotest"] if e["mesh"] in ("inline-quad", "periodic-square") and e["ho"] == 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e", AUTOTEST_2D_HO2, ids=[e["name"] for e in AUTOTEST_2D_HO2])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_2d_cpp_driver_reference_autotest_ho2_lo3_gpu(dev, e, fused):
+    """autotest/out_baseline.dat:78-81, 98-101: -ho 2 -lo 3 -fct 2 -pa in 2-D (CGHOSolver = the local solve to rel 1e-12,
+    plain PAResidualDistribution) through rmhd_run on the MI355X: mass and maximum, ten printed digits"""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    cfg = make_config(e["mesh"], e["rs"], e["order"], e["problem"], e["dt"], e["t_final"], lo_type=e["lo"], ho_type=2, pa=1, fused=fused)
+    res = RmhdResult()
+    assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
+    assert float(f"{res.final_mass:.10g}") == e["mass"] and float(f"{res.max_value:.10g}") == e["max"], (res.final_mass, res.max_value)
