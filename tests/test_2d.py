@@ -202,22 +202,6 @@ def test_2d_stage_vs_oracle_emulated(emu, mesh, rs, p, prob, t, bt):
     check_stage(emu, mesh, rs, p, prob, t, bt)
 
 
-def test_2d_ctest0_first_step_emulated(emu):
-    """The first step of ctest #4 / #9 / #10 of the reference's table (inline-quad -pa -p 14 -rs 1 -o 2, CFL step) through
-    the emulated kernels, granular call sequence, -pa mass rule: mass and field against the oracle, which reproduces the
-    reference's 17-digit constant for the whole run (tests/test_oracle_kat.py).  The five-step run against the constant
-    itself is the GPU test below (100 s per run under the OS-thread emulation)."""
-    kw = dict(_kw(CTEST["ctest0"]), max_steps=1)
-    mass, x, steps, r = run_case(emu, kw, True, True)
-    out = r.run()
-    assert steps == out["steps"] == 1
-    assert abs(mass - out["mass"]) <= 1e-13 * abs(out["mass"])
-    assert np.abs(x - r.u).max() < 1e-11
-    # the same step through rmh_stage_fused (one entry point per stage)
-    mass2, x2, _, _ = run_case(emu, kw, True, "stage")
-    assert abs(mass2 - out["mass"]) <= 1e-13 * abs(out["mass"]) and np.abs(x2 - r.u).max() < 1e-11
-
-
 @pytest.mark.parametrize("mesh,rs,p,prob,t,lo", [("inline-quad", 0, 2, 14, 0.3, 4), ("periodic-square", 1, 3, 5, 0.0, 4),
                                                 ("inline-quad", 0, 4, 14, 0.6, 4), ("inline-quad", 0, 3, 14, 0.5, 3)])
 def test_2d_rd_vs_oracle_emulated(emu, mesh, rs, p, prob, t, lo):
@@ -227,7 +211,10 @@ def test_2d_rd_vs_oracle_emulated(emu, mesh, rs, p, prob, t, lo):
 @pytest.mark.parametrize("fused,pa,lo", [(1, 1, 5), (0, 0, 4)])
 def test_2d_cpp_driver_emulated(emu, fused, pa, lo):
     """rmhd_run (the C++ restatement of remhos(): case builder build_case_2d, solver classes, RK3 loop, report) on the first
-    step of ctest #0's case: one-call stages (rmh_stage_fused) / the solver classes' call sequence, lo 5 / lo 4"""
+    step of ctest #0's case (= #4 / #9 / #10 with -pa) through the emulated kernels: one-call stages (rmh_stage_fused) with the
+    -pa mass rule / the solver classes' call sequence with lo 4 -- mass and maximum against the oracle, which reproduces the
+    reference's constants for the whole runs (tests/test_oracle_kat.py).  The five-step runs against the constants themselves
+    are the GPU tests below (100 s per run under the OS-thread emulation)."""
     import ctypes as C
 
     from remhos_amd.case import RmhdResult, make_config
