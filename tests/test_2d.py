@@ -343,3 +343,24 @@ def test_2d_cpp_driver_reference_autotest_ho2_lo3_gpu(dev, e, fused):
     res = RmhdResult()
     assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
     assert float(f"{res.final_mass:.10g}") == e["mass"] and float(f"{res.max_value:.10g}") == e["max"], (res.final_mass, res.max_value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,prob,lo,dt,tf,fused", [("inline-quad", 14, 4, 0.06, 0.75, 1), ("inline-quad", 14, 4, 0.06, 0.75, 0),
+                                                      ("periodic-square", 5, 4, 0.02, 0.3, 1), ("periodic-square", 5, 5, 0.02, 0.3, 0)])
+def test_2d_cpp_driver_bounds_type_1_and_dt_control_gpu(dev, mesh, prob, lo, dt, tf, fused):
+    """-bt 1 -dtc 1 (remhos.cpp:1178-1197, 1968-1998; remhos_tools.cpp:381-430) in 2-D through rmhd_run against the oracle:
+    the same accepted and repeated steps, the same final dt, mass and maximum.  (The reference's own auto-dt baselines run
+    -fct 4, which is restated in the oracle only; tests/test_oracle_kat.py pins these options there.)"""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    r = Remhos(Config(mesh=mesh, rs=1, order=3, problem=prob, dt=dt, t_final=tf, lo=lo, fct=2, bounds_type=1, dt_control=1))
+    out = r.run()
+    cfg = make_config(mesh, 1, 3, prob, dt, tf, lo_type=lo, fused=fused, bounds_type=1, dt_control=1)
+    res = RmhdResult()
+    assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
+    assert (res.steps, res.repeats) == (out["steps"], r.repeats), (res.steps, res.repeats, out["steps"], r.repeats)
+    assert abs(res.dt - out["dt"]) <= 1e-12 * out["dt"]
+    assert abs(res.final_mass - out["mass"]) <= 1e-12 * abs(out["mass"]) and abs(res.max_value - out["max"]) <= 1e-10
