@@ -31,7 +31,7 @@ def emulib():
     return bind_driver(load_library(emu_library_path()))
 
 
-@pytest.mark.parametrize("mesh,prob", [("periodic-cube", 0), ("cube01_hex", 4)])
+@pytest.mark.parametrize("mesh,prob", [("periodic-cube", 0), ("cube01_hex", 4), ("periodic-square", 0), ("inline-quad", 4)])
 def test_error_norms_emulated(emulib, mesh, prob):
     compare(emulib, mesh, 0, 2, prob, 0.02, 0.1, 2, 1e-12)
 
@@ -57,7 +57,9 @@ def gpulib():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh,rs,p,prob,steps", [("periodic-cube", 1, 3, 0, 20), ("periodic-cube", 2, 2, 0, 10), ("cube01_hex", 2, 3, 4, 10)])
+@pytest.mark.parametrize("mesh,rs,p,prob,steps", [("periodic-cube", 1, 3, 0, 20), ("periodic-cube", 2, 2, 0, 10), ("cube01_hex", 2, 3, 4, 10),
+                                                  # dim = 2 (the solid-body rotation of the reference's README runs, -p 4, and the translation)
+                                                  ("inline-quad", 3, 3, 4, 20), ("periodic-square", 2, 2, 0, 20)])
 def test_error_norms_gpu(gpulib, mesh, rs, p, prob, steps):
     compare(gpulib, mesh, rs, p, prob, 0.01, 0.5, steps, 1e-10)
 
