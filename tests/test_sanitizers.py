@@ -32,7 +32,9 @@ SELECTED = ["tests/test_emu_cpu.py::test_generic_orders_multi_block_race_free", 
             # the wavefront-local LDS hand-offs of the streaming kernels (rmh_stream.hpp: class tables behind wave_lds_fence)
             "tests/test_emu_cpu.py::test_streaming_kernels_every_order",
             # dim = 2: the one-wavefront-per-element HO / RD kernel and the 2-D instances of the streaming kernels
-            "tests/test_2d.py::test_2d_stage_vs_oracle_emulated", "tests/test_2d.py::test_2d_rd_vs_oracle_emulated"]
+            "tests/test_2d.py::test_2d_stage_vs_oracle_emulated", "tests/test_2d.py::test_2d_rd_vs_oracle_emulated",
+            # ... and the 2-D host side: build_case_2d, the driver on a 2-D context, the 2-D error norms
+            "tests/test_2d.py::test_2d_cpp_driver_emulated", "tests/test_error_norms.py::test_error_norms_emulated"]
 
 
 def _run(variant, runtime, extra_env):
