@@ -48,6 +48,8 @@ struct SCfg                  //  in the middle layer of the 27-entry table, ever
    // elements a wavefront has in flight per pass: ~8 loads per lane and array for the kernels that read one or two
    // arrays, ~4 for the fused limiter (four to five arrays, six live values per dof)
    static constexpr int U8 = DPT >= 5 ? 1 : (DPT >= 3 ? 2 : (DPT == 2 ? 4 : 8));
+   // (fused limiter, RK update form, swept: p = 3: 1 471 us, 2 413, 4 390, 8 440; p = 4: 1 238, 2 214, 4 217; p = 5: 1 153, 2 163;
+   //  p = 6: 1 232, 2 252)
    static constexpr int U4 = DPT >= 3 ? 1 : (DPT == 2 ? 2 : 4);
    // bounds (write-only): an even number -- the pass is stored in 16-byte pieces -- measured per order with the streaming
    // stores (p = 3: 8 163 us, 16 201 us; p = 4: 4 138 us, 8 104 us; p = 5: 2 72 us, 4 60 us, 16 68 us; p = 6: 2 175 us, 4 160 us,
