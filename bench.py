@@ -92,6 +92,157 @@ MASS_SOLVE = {  # name -> (rel_tol, abs_tol, max_iter, jacobi_step, constant_mod
 }
 
 
+COMPACT_LIMIT = 6144  # the driver keeps an ~8 KB tail of stdout: the final line must fit with room to spare
+
+
+def _num(x, sig=7):
+    """numbers of the compact line: `sig` significant digits (the full precision is in bench_detail.json)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):  # (masses and maxima are compared digit by digit with the reference's prints: keep 13)
+        return {k: _num(v, 13 if k in ("final_mass", "max_value") else sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, sig) for v in x]
+    return x
+
+
+def _short_workload(w):
+    """'periodic-cube -rs 5 -o 3 -p 10 remap, -pa ... (BASELINE configs[1]); 96x96x96 = ...' -> the part before ';'"""
+    return w.split(";")[0].replace(", RK3-SSP", " RK3").replace("-pa -ho 3 ", "-pa ").strip() if isinstance(w, str) else w
+
+
+def _roof(r):
+    """the contract's roofline object, numbers only (what each field means: DESIGN.md 5)"""
+    if not r:
+        return None
+    return {"kernel": r["kernel"].split(" (")[0], "bound": "hbm", "binds": "fp64-valu", "achieved": r["achieved"], "peak": r["peak"],
+            "unit": r["unit"], "frac": r["frac"], "traffic": r.get("traffic"), "avg_launch_ms": r["avg_launch_ms"],
+            "alg_bytes_per_launch": r["alg_bytes_per_launch"]}
+
+
+def _fp64(r):
+    return {"achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+            "fp64_share_of_valu_insts": r["fp64_share_of_valu_insts"]} if r else None
+
+
+def _mc(m):
+    """mass_check -> numbers and verdicts only"""
+    if not m:
+        return None
+    o = {"mass_rel_dev": m["mass_rel_dev"], "field_max_dev": m["field_max_dev"], "pass": m["pass"]}
+    if m.get("chaotic_dt"):
+        o["chaotic_dt"] = True
+    if m.get("stable_dt"):
+        s = m["stable_dt"]
+        o["stable_dt"] = {"steps": s["steps"], "mass_rel_dev": s["mass_rel_dev"], "field_max_dev": s["field_max_dev"], "pass": s["pass"],
+                          "value": s.get("value_at_this_dt"), "cg_iters": s.get("cg_iters")}
+    return o
+
+
+def _sub(b):
+    """a secondary block of the line: value, ms_per_step, avg_launch_ms, frac, pass"""
+    if not b:
+        return None
+    o = {"value": b["value"], "ms_per_step": b["ms_per_step"]}
+    r = b.get("roofline") or {}
+    o["avg_launch_ms"] = b.get("avg_launch_ms", r.get("avg_launch_ms"))
+    o["frac"] = r.get("frac", b.get("roofline_hbm_model_frac"))
+    if b.get("roofline_fp64"):
+        o["fp64_frac"] = b["roofline_fp64"]["frac"]
+    if r.get("traffic") is not None:
+        o["traffic"] = r["traffic"]
+    c = b.get("config") or {}
+    if "workload" in c or "workload" in b:
+        o["workload"] = _short_workload(c.get("workload", b.get("workload")))
+    fm = c.get("final_mass", b.get("final_mass"))
+    if fm is not None:
+        o["final_mass"] = fm
+    it = c.get("mass_cg_max_iters", b.get("mass_cg_max_iters"))
+    if it is not None:
+        o["cg_iters"] = it
+    if b.get("mass_check"):
+        o["mass_check"] = _mc(b["mass_check"])
+        o["pass"] = b["mass_check"]["pass"]
+    return o
+
+
+def compact_line(out, detail_file="bench_detail.json"):
+    """The ONE line the driver parses: the contract's fields + numbers-only sub-blocks, < COMPACT_LIMIT bytes.  `out` is the
+    full result dict (written to `detail_file`); every explanatory string lives in DESIGN.md 5."""
+    c = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": _short_workload(c.get("workload")), "global_dofs": c.get("global_dofs"), "elements": c.get("elements"),
+                      "partition": c.get("partition"), "mass_solve": c.get("mass_solve"), "cg_iters": c.get("mass_cg_max_iters"),
+                      "dt": c.get("dt"), "final_mass": c.get("final_mass"), "max_value": c.get("max_value")}
+    if c.get("stage_loop"):
+        line["config"]["stage_loop"] = c["stage_loop"]
+    line["roofline"] = _roof(out.get("roofline"))
+    line["roofline_fp64"] = _fp64(out.get("roofline_fp64"))
+    if "rccl_ranks" in out:
+        line["rccl_ranks"] = out["rccl_ranks"]
+    if out.get("exchange"):
+        x = out["exchange"]
+        line["exchange"] = {"transport": str(x.get("transport", "")).split(" ")[0], "neighbour_ranks": x.get("neighbour_ranks"),
+                            "send_bytes_per_stage_rank0": x.get("send_bytes_per_stage_rank0")}
+    if out.get("strong"):
+        line["strong"] = out["strong"]
+    if out.get("mass_check"):
+        line["mass_check"] = _mc(out["mass_check"])
+    for k in ("p6", "transport", "cube01_p4"):
+        if out.get(k):
+            line[k] = _sub(out[k])
+    if out.get("sustained"):
+        s = out["sustained"]
+        line["sustained"] = {k: s[k] for k in ("steps", "value", "ms_per_step", "first_step_ms", "median_step_ms", "p95_step_ms")}
+        smi = s.get("smi") or {}
+        if smi.get("sclk_MHz"):
+            line["sustained"]["sclk_MHz_min"] = min(smi["sclk_MHz"])
+            line["sustained"]["power_W_max"] = max(smi["power_W"])
+    if out.get("lo4"):
+        line["lo4"] = {k: dict(_sub(v), form=v.get("form")) for k, v in out["lo4"].items()}
+    if out.get("granular"):
+        g = out["granular"]
+        line["granular"] = {"reference_call_sequence": {k: g["reference_call_sequence"][k] for k in ("value", "ms_per_step")},
+                            "ho_plus_fused_limiter": {k: g["ho_plus_fused_limiter"][k] for k in ("value", "ms_per_step")},
+                            "ho_kernel_ms": g["ho_kernel"]["avg_launch_ms"],
+                            "streaming": {k.replace("_kernel", ""): {"ms": v["avg_launch_ms"], "frac": v["frac"]}
+                                          for k, v in g["streaming_kernels"].items()}}
+    if out.get("configs0_2d"):
+        line["configs0_2d"] = {k: {kk: v.get(kk) for kk in ("final_mass", "max_value", "value", "pass", "error") if kk in v}
+                               for k, v in out["configs0_2d"].items() if isinstance(v, dict)}
+    if out.get("cpu_baseline"):
+        b = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"],
+                                "sample": b.get("sample_short", b.get("sample", ""))[:160]}
+    line["detail"] = detail_file
+    line = _num(line)
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= COMPACT_LIMIT:  # never let the record outgrow the driver's tail again: drop the optional blocks, last first
+        for k in ("configs0_2d", "granular", "sustained", "lo4", "cube01_p4", "transport", "mass_check", "exchange"):
+            line.pop(k, None)
+            txt = json.dumps(line, separators=(",", ":"))
+            if len(txt) < COMPACT_LIMIT:
+                break
+    return txt
+
+
+def emit(out, n_gpus):
+    """Write the full result to bench_detail[_nN].json (repo root, and gpurun_out/ when it exists) and print the compact line
+    as the LAST line of stdout."""
+    name = "bench_detail.json" if n_gpus == 1 else f"bench_detail_n{n_gpus}.json"
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as e:
+                print(f"bench.py: could not write {os.path.join(d, name)}: {e}", file=sys.stderr)
+    print(compact_line(out, name), flush=True)
+
+
 _X2 = {}  # key -> measured HBM bytes per launch with the guide's FETCH_SIZE correction (x 2) instead of the calibrated one
 
 
@@ -154,6 +305,7 @@ def cpu_baseline(lib, order, rs, mass_solve="pa", budget_s=12.0):
         "unit": "MDOFs*RK-stage/s",
         "cores": cp.threads,
         "kind": "port",
+        "sample_short": f"periodic-cube -rs {rs_cpu} -o {order} -p 10 -lo 5 -fct 2, {ndofs} dofs, {stages} RK stages in {el:.2f} s, {cp.threads} OpenMP threads",
         "sample": f"oracle/cpu_port.cpp (C++/OpenMP, {cp.threads} threads = the CPUs the container may use (affinity mask capped by the "
                   f"cgroup quota), element batches of {cp.simd_width} per SIMD vector, "
                   f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}): periodic-cube -rs {rs_cpu} "
@@ -197,9 +349,18 @@ def all_ranks_ok(tag, world, rank, ok, timeout_s=180.0):
         if all(v in ("0", "1") for v in vals):
             break
         time.sleep(0.05)
-    import atexit
+    if rank == 0:  # rank 0 is the one that prints: it clears ALL the files, after every rank had time to read them
+        import atexit
 
-    atexit.register(lambda: os.path.exists(mine) and os.remove(mine))
+        def _clean():
+            time.sleep(1.0)
+            for r in range(world):
+                try:
+                    os.remove(f"{base}.rc{r}")
+                except OSError:
+                    pass
+
+        atexit.register(_clean)
     return all(v == "1" for v in vals)
 
 
@@ -673,7 +834,10 @@ def main():
             port = os.environ.get("MASTER_PORT", "0")
             # the launch's tag: the launcher's port, and its run id / the agent's pid so that a stale file of an earlier launch
             # on the same port is never taken for this one's (rmh_driver.hip: read_or_write_id)
-            tag = f"{port}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+            # -- built only from what EVERY rank shares: the agent's pid only when one agent started all ranks of the job
+            one_agent = os.environ.get("LOCAL_WORLD_SIZE") == str(world)
+            tag = (f"{port}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('RMH_LAUNCH_NONCE', '')}"
+                   f"_{os.getppid() if one_agent else 0}")
             os.environ.setdefault("RMH_COMM_NONCE", str(int(hashlib.sha256(tag.encode()).hexdigest()[:12], 16)))
             out = measure_cpp_loop(args, lib, world, rank, local_rank, os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rmh_bench_{port}.id"))
             # decided collectively: either every rank's C++ loop succeeded, or ALL ranks take the Python loop
@@ -687,7 +851,7 @@ def main():
                     "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                     "rccl_ranks": out["config"].get("comm_ranks")}
             line.update({k: v for k, v in out.items() if k not in ("value", "ms_per_step")})
-            print(json.dumps(line), flush=True)
+            emit(line, args.gpus)
         if not args.py_loop:
             return
 
@@ -773,7 +937,8 @@ def main():
                                 **compare(st, args.mass_solve),
                                 "field_criterion": "field_max_dev bounded by the per-stage tolerance of the element-local solve at this order "
                                                    "times the steps (tests/test_gpu_high_order_runs.py): 25 x 1e-7 at p = 6",
-                                "value_at_this_dt": st[args.mass_solve]["value"]}
+                                "value_at_this_dt": st[args.mass_solve]["value"],
+                                "cg_iters": st[args.mass_solve]["config"]["mass_cg_max_iters"]}
             out["stable_dt"]["pass"] = bool(out["stable_dt"]["pass"] and out["stable_dt"]["field_max_dev"] < 25 * {5: 5e-9, 6: 1e-7}[order])
             del st
             torch.cuda.empty_cache()
@@ -873,7 +1038,7 @@ def main():
             out["configs0_2d"] = config0
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, args.order, args.rs, args.mass_solve)
-        print(json.dumps(out), flush=True)
+        emit(out, args.gpus)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

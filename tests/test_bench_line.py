@@ -1,0 +1,70 @@
+"""bench.py's final stdout line is a machine record: it must stay small enough for the driver's stdout tail and parse.
+
+Round 4's line had grown to 22 KB (prose inside every roofline block) and the driver record ended with `parsed: null`.
+The canned result is that run's full output (tests/golden/bench_result_r04.json = gpurun_out/bench_drv.json of round 4)."""
+import json
+import os
+
+import bench
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def canned():
+    with open(os.path.join(HERE, "golden", "bench_result_r04.json")) as f:
+        return json.load(f)
+
+
+def test_compact_line_is_small_and_round_trips():
+    full = canned()
+    assert len(json.dumps(full)) > 20000  # the thing that broke the driver's parse
+    txt = bench.compact_line(full)
+    assert "\n" not in txt and len(txt) < bench.COMPACT_LIMIT == 6144
+    line = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("periodic-cube -rs 5 -o 3 -p 10") and "configs[1]" in line["config"]["workload"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert abs(line["value"] - full["value"]) < 1e-6 * full["value"]
+    # the masses keep the digits they are compared on
+    assert abs(line["config"]["final_mass"] - full["config"]["final_mass"]) < 1e-12
+    assert line["p6"]["pass"] is False and line["p6"]["mass_check"]["stable_dt"]["pass"] is True
+    assert line["configs0_2d"]["o3"]["pass"] is True
+
+
+def test_compact_line_has_no_prose():
+    line = json.loads(bench.compact_line(canned()))
+
+    def strings(x, path=""):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                yield from strings(v, f"{path}.{k}")
+        elif isinstance(x, str):
+            yield path, x
+
+    for path, s in strings(line):
+        assert len(s) <= 160, (path, s)
+
+
+def test_compact_line_sheds_blocks_rather_than_outgrow_the_limit():
+    full = canned()
+    full["lo4"] = {f"p{k}": full["lo4"]["p3"] for k in range(40)}  # an absurdly wide block
+    txt = bench.compact_line(full)
+    assert len(txt) < bench.COMPACT_LIMIT
+    line = json.loads(txt)
+    assert "roofline" in line and "cpu_baseline" in line and "lo4" not in line
+
+
+def test_multi_gpu_line_is_compact_too():
+    full = canned()
+    full.update({"n_gpus": 8, "rccl_ranks": 8, "scaling": "weak",
+                 "exchange": {"transport": "RCCL grouped ncclSend/ncclRecv inside the library", "neighbour_ranks": 7,
+                              "send_bytes_per_stage_rank0": 123456, "recv_bytes_per_stage_rank0": 123456}})
+    for k in ("p6", "lo4", "granular", "sustained", "configs0_2d", "cpu_baseline"):
+        full.pop(k)
+    line = json.loads(bench.compact_line(full, "bench_detail_n8.json"))
+    assert line["rccl_ranks"] == 8 and line["exchange"]["neighbour_ranks"] == 7 and line["detail"] == "bench_detail_n8.json"
