@@ -36,6 +36,7 @@ on the kernel's own stream inside the timed region) and `cpu_baseline` (the C++/
 oracle/ timed on the host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
 """
 import argparse
+import copy
 import hashlib
 import json
 import os
@@ -317,8 +318,12 @@ def cpu_baseline(lib, order, rs, mass_solve="pa", budget_s=12.0):
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run) and
-    pass its output and exit code through.  Nothing in this process has touched the GPU (torch is not even imported)."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process group (torch.distributed.run) and
+    pass its output and exit code through.  Nothing in this process has touched the GPU (torch is not even imported).
+    Watchdog: after $RMH_BENCH_TIMEOUT seconds (default 1500) the children -- the whole process group, never this process
+    re-exec'ed -- are terminated and the exit code is 124."""
+    import signal
+
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -326,7 +331,61 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    env.setdefault("RMH_LAUNCH_NONCE", f"{os.getpid()}_{int(time.time())}")  # (shared by every rank of this launch)
+    limit = float(os.environ.get("RMH_BENCH_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus} ranks did not finish within {limit:.0f} s -- terminating them (per-rank logs: "
+              f"{rank_log_path('*')})", file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+
+
+def rank_log_path(rank):
+    d = os.path.join(ROOT, "gpurun_out")
+    return os.path.join(d if os.path.isdir(d) else os.environ.get("TMPDIR", "/tmp"), f"bench_rank{rank}.log")
+
+
+_T0 = time.time()
+
+
+def rank_log(rank, msg):
+    """every rank of an N > 1 run keeps its own log (first contact with a multi-GPU node: know where each rank stopped)"""
+    try:
+        with open(rank_log_path(rank), "a") as f:
+            f.write(f"[{time.strftime('%H:%M:%S')} +{time.time() - _T0:7.1f}s pid {os.getpid()}] {msg}\n")
+    except OSError:
+        pass
+
+
+def start_rank_watchdog(rank, world):
+    """N > 1: a rank stuck in a collective never returns by itself.  After $RMH_BENCH_RANK_TIMEOUT seconds (default 1200)
+    the rank says so in its log and on stderr and exits with 124 (os._exit: no exec, no clean-up that could block)."""
+    import threading
+
+    limit = float(os.environ.get("RMH_BENCH_RANK_TIMEOUT", "1200"))
+
+    def fire():
+        msg = f"rank {rank}/{world}: watchdog -- not finished after {limit:.0f} s, exiting (see {rank_log_path(rank)})"
+        rank_log(rank, msg)
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def all_ranks_ok(tag, world, rank, ok, timeout_s=180.0):
@@ -803,6 +862,8 @@ def main():
     ap.add_argument("--no-smi", action="store_true", help=argparse.SUPPRESS)  # (accepted for old recipes: sampling is opt-in now)
     ap.add_argument("--sustained-steps", type=int, default=200)
     ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N > 1, weak scaling: do not also run the strong-scaling leg (the same -rs mesh partitioned, BASELINE configs[3])")
     ap.add_argument("--py-loop", action="store_true",
                     help="N > 1: drive the stages from Python (remhos_amd/stepper.py over torch.distributed) instead of the C++ loop")
     args = ap.parse_args()
@@ -825,11 +886,18 @@ def main():
     if args.gpus > 1 and not args.py_loop:
         # the C++ loop: nothing of torch is needed (RCCL is reached by the library itself); one rank per GPU as launched,
         # the ncclUniqueId through a file named after this launch's MASTER_PORT
+        start_rank_watchdog(rank, world)
+        rank_log(rank, f"start: rank {rank}/{world} local_rank {local_rank} scaling {args.scaling} args {sys.argv[1:]}")
         lib = bind_driver(load_library())
-        out = None
+        rank_log(rank, "library loaded")
+        out, strong = None, None
         if one_gpu:
             if rank == 0:
                 out = measure_cpp_loop(args, lib, world, 0, 0, None)
+                if args.scaling == "weak" and not args.no_strong_leg:
+                    a2 = copy.copy(args)
+                    a2.scaling = "strong"
+                    strong = measure_cpp_loop(a2, lib, world, 0, 0, None)
         else:
             port = os.environ.get("MASTER_PORT", "0")
             # the launch's tag: the launcher's port, and its run id / the agent's pid so that a stale file of an earlier launch
@@ -839,10 +907,24 @@ def main():
             tag = (f"{port}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('RMH_LAUNCH_NONCE', '')}"
                    f"_{os.getppid() if one_agent else 0}")
             os.environ.setdefault("RMH_COMM_NONCE", str(int(hashlib.sha256(tag.encode()).hexdigest()[:12], 16)))
-            out = measure_cpp_loop(args, lib, world, rank, local_rank, os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rmh_bench_{port}.id"))
+            idf = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rmh_bench_{port}")
+            rank_log(rank, f"C++ loop ({args.scaling}): rmhd_run_partitioned, id file {idf}.id")
+            out = measure_cpp_loop(args, lib, world, rank, local_rank, idf + ".id")
+            rank_log(rank, f"C++ loop returned: {'ok' if out is not None else 'FAILED: ' + lib.rmhd_last_error().decode()}")
             # decided collectively: either every rank's C++ loop succeeded, or ALL ranks take the Python loop
             if not all_ranks_ok(tag.replace("/", "_"), world, rank, out is not None):
+                rank_log(rank, "not every rank succeeded: all ranks take the Python loop")
                 out = None
+            if out is not None and args.scaling == "weak" and not args.no_strong_leg:
+                # BASELINE configs[3] in the same line: the SAME -rs mesh box-partitioned over the ranks (a second communicator
+                # through its own id file; skipped as a whole unless every rank got through it)
+                a2 = copy.copy(args)
+                a2.scaling = "strong"
+                rank_log(rank, "C++ loop (strong leg)")
+                strong = measure_cpp_loop(a2, lib, world, rank, local_rank, idf + "_strong.id")
+                rank_log(rank, f"strong leg returned: {'ok' if strong is not None else 'FAILED: ' + lib.rmhd_last_error().decode()}")
+                if not all_ranks_ok(tag.replace("/", "_") + "_strong", world, rank, strong is not None):
+                    strong = None
         if out is None and not one_gpu:
             args.py_loop = True  # best effort: the stages driven from Python over torch.distributed (nccl)
         elif rank == 0 and out is not None:
@@ -851,7 +933,14 @@ def main():
                     "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                     "rccl_ranks": out["config"].get("comm_ranks")}
             line.update({k: v for k, v in out.items() if k not in ("value", "ms_per_step")})
+            if strong is not None:
+                line["strong_detail"] = strong
+                line["strong"] = {"workload": _short_workload(strong["config"]["workload"]), "value": strong["value"],
+                                  "ms_per_step": strong["ms_per_step"], "global_dofs": strong["config"]["global_dofs"],
+                                  "avg_launch_ms": strong["roofline"]["avg_launch_ms"], "frac": strong["roofline"]["frac"],
+                                  "final_mass": strong["config"]["final_mass"], "rccl_ranks": strong["config"].get("comm_ranks")}
             emit(line, args.gpus)
+        rank_log(rank, "done" if not args.py_loop else "falling back to the Python loop")
         if not args.py_loop:
             return
 

@@ -111,6 +111,18 @@ const char *rmh_version(void);
 /* All work of ctx is enqueued on `hip_stream` (a hipStream_t; NULL = default stream). */
 int rmh_set_stream(rmh_ctx *ctx, void *hip_stream);
 
+/* A non-blocking stream for a context whose kernels leave `reserve_cus` compute units of `device` alone
+ * (hipExtStreamCreateWithCUMask; 0 = an ordinary non-blocking stream).  Why: the halo exchange of a partitioned stage
+ * (rmh_exchange_begin, RCCL send / recv kernels on the library's exchange stream -- the reference's
+ * ParGridFunction::ExchangeFaceNbrData inside K.Mult, remhos_ho.cpp:122) is launched microseconds AFTER the interior
+ * stage kernel has taken every workgroup slot of the chip, and then only finds a CU as that kernel drains
+ * (profiles/r04_rccl_selfloop_timeline.txt: 10 us alone, 406 us behind a full-chip launch).  With a few CUs kept free of
+ * the context stream the exchange kernels start at once.  The cleared mask bits are spread so that every XCD gives up
+ * the same number of CUs.  The C++ stage loops (rmhd_run_partitioned, rmhd_run_rank) create their context streams
+ * through this call with reserve_cus = $RMH_COMM_CUS (default 0).  Destroy with rmh_stream_destroy. */
+int rmh_stream_create_reserving(int device, int reserve_cus, void **hip_stream);
+int rmh_stream_destroy(void *hip_stream);
+
 /* Remap re-setup: AdvectionOperator::MultUnlimited moves the mesh to pseudo-time t and
  * re-assembles M_HO, K_HO and the lumped mass (remhos.cpp:1598-1637).  Here the geometry is
  * recomputed inside the kernels from x0 + t*vel (matrix-free), so this call only records t. */

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librmh.so")
 
 # every symbol include/rmh.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
-    "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_setup",
+    "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_stream_create_reserving", "rmh_stream_destroy", "rmh_setup",
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_lo_rd", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range", "rmh_stage_fused_chain",
@@ -80,6 +80,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_last_error.restype = C.c_char_p
     lib.rmh_version.restype = C.c_char_p
     lib.rmh_set_stream.argtypes = [p, p]
+    lib.rmh_stream_create_reserving.argtypes = [i, i, C.POINTER(p)]
+    lib.rmh_stream_destroy.argtypes = [p]
     lib.rmh_setup.argtypes = [p, d]
     lib.rmh_set_ghost_u.argtypes = [p, p]
     lib.rmh_set_ghost_minmax.argtypes = [p, p, p]

@@ -7,6 +7,7 @@
 #include "rmh_2d.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -476,6 +477,17 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
    c->dim = L->dim;
    c->ndof = (c->p + 1) * (c->p + 1) * (c->dim == 3 ? c->p + 1 : 1);
    c->gh_ustride = c->ndof;
+   if (c->ng > 0)
+   {
+      const int nst = c->dim == 3 ? 27 : 9;
+      for (int e = c->ne - 1; e >= 0 && c->ghost_readers_end == 0; e--)
+      {
+         for (int k = 0; k < nst; k++)
+         {
+            if (L->stencil27[(size_t)e * nst + k] >= c->ne) { c->ghost_readers_end = e + 1; break; }
+         }
+      }
+   }
    // every failure past this point releases the context and whatever it already owns
    const int rc = c->dim == 3 ? create_device_state(c, L) : create_device_state_2d(c, L);
    if (rc) { rmh_destroy(c); return rc; }
@@ -502,6 +514,45 @@ int rmh_set_stream(rmh_ctx *c, void *s)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
    c->stream = (hipStream_t)s;
+   return RMH_OK;
+}
+
+int rmh_stream_create_reserving(int device, int reserve_cus, void **hip_stream)
+{
+   if (!hip_stream || reserve_cus < 0) { return fail(RMH_ERR_INVALID, "rmh_stream_create_reserving: bad argument"); }
+   *hip_stream = nullptr;
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { return fail(RMH_ERR_INVALID, "bad device ordinal"); }
+   RMH_HIP(hipSetDevice(device));
+   hipStream_t s = nullptr;
+   if (reserve_cus == 0)
+   {
+      RMH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+      *hip_stream = s;
+      return RMH_OK;
+   }
+   hipDeviceProp_t prop;
+   RMH_HIP(hipGetDeviceProperties(&prop, device));
+   const int ncu = prop.multiProcessorCount;
+   if (reserve_cus >= ncu) { return fail(RMH_ERR_INVALID, "rmh_stream_create_reserving: cannot reserve every compute unit"); }
+   std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+   for (int b = 0; b < ncu; b++) { mask[b / 32] |= 1u << (b % 32); }
+   // bit i * (ncu / k) + i, i < k: one CU per XCD for k = 8 whether the mask enumerates the CUs XCD by XCD (32 consecutive
+   // bits each) or round-robin over the XCDs
+   const int stride = ncu / reserve_cus;
+   for (int i = 0; i < reserve_cus; i++)
+   {
+      const int b = (i * stride + i % (stride > 0 ? stride : 1)) % ncu;
+      mask[b / 32] &= ~(1u << (b % 32));
+   }
+   RMH_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+   *hip_stream = s;
+   return RMH_OK;
+}
+
+int rmh_stream_destroy(void *hip_stream)
+{
+   if (hip_stream) { RMH_HIP(hipStreamDestroy((hipStream_t)hip_stream)); }
    return RMH_OK;
 }
 
@@ -752,6 +803,11 @@ int rmh_fct_product(rmh_ctx *c, const double *us, const double *m, const double 
    return timer_end(c, 3, ep);
 }
 
+// Ghost data (neighbour traces, ghost element extrema) is valid between rmh_exchange_end and the next rmh_exchange_begin,
+// and only if no rmh_exchange_minmax_* has put another field's extrema there since.  Only element ranges that reach a ghost
+// reader are held to that: the interior range of a split stage is launched while the exchange is in flight.
+static const char *ghosts_not_ready(const rmh_ctx *c, int e_begin); // (defined behind rmh_comm.hpp, which has struct Exchange)
+
 static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, const double *du_lo, double dt, double *du,
                             const double *x_base, double a, double b, double dt_rk, double *y_out)
 {
@@ -760,7 +816,7 @@ static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, co
    RMH_ENTER(c);
    extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
-   if (c->ng > 0 && c->gh_foreign) { return fail(RMH_ERR_STATE, "the ghost extrema hold another field's values (rmh_exchange_minmax_*): exchange u first"); }
+   if (const char *why = ghosts_not_ready(c, 0)) { return fail(RMH_ERR_STATE, why); }
    LimitArgs la;
    la.u = u;
    la.du_ho = du_ho;
@@ -838,7 +894,7 @@ int rmh_stage_fused_chain(rmh_ctx *c, const double *u, double dt, const double *
    }
    if (c->lo_type == 3 && c->p < 2) { return fail(RMH_ERR_STATE, "rmh_stage_fused with lo 3 needs order >= 2"); }
    if (c->ng > 0 && (!c->u_ghost || !c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost data not set"); }
-   if (c->ng > 0 && c->gh_foreign) { return fail(RMH_ERR_STATE, "the ghost extrema hold another field's values (rmh_exchange_minmax_*): exchange u first"); }
+   if (const char *why = ghosts_not_ready(c, e_begin)) { return fail(RMH_ERR_STATE, why); }
    int rc = 0;
    // Element extrema of the stage input.  They are at hand only if the caller PRESENTS the token the stage that wrote u
    // returned -- its statement that u is that stage's untouched output.  Anything else (no token, a stale one, a vector
@@ -1060,3 +1116,11 @@ int rmh_set_mass_completion(rmh_ctx *c, int jacobi_step, int constant_mode)
 } // extern "C"
 
 #include "rmh_comm.hpp"
+
+static const char *ghosts_not_ready(const rmh_ctx *c, int e_begin)
+{
+   if (c->ng <= 0 || e_begin >= c->ghost_readers_end) { return nullptr; }
+   if (c->xch && c->xch->gen_begin != c->xch->gen_end) { return "the exchange of u is still in flight (rmh_exchange_end first): this element range reads ghost data"; }
+   if (c->gh_foreign) { return "the ghost extrema hold another field's values (rmh_exchange_minmax_*): exchange u first"; }
+   return nullptr;
+}

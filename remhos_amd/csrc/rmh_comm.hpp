@@ -522,9 +522,8 @@ int rmh_exchange_begin(rmh_ctx *c, const double *u)
    if (x->gen_begin != x->gen_end) { return fail(RMH_ERR_STATE, "rmh_exchange_begin: the previous exchange was not ended"); }
    RMH_ENTER(c);
    x->gen_begin++;
-   // (the exchange under way rewrites the ghost extrema with this vector's; what reads them waits for rmh_exchange_end --
-   // the interior range of a split stage, launched in between, reads no ghost)
-   c->gh_foreign = false;
+   // (the exchange under way rewrites the ghost extrema with this vector's; they are valid -- and gh_foreign cleared -- at
+   // rmh_exchange_end; the interior range of a split stage, launched in between, reads no ghost: ghosts_not_ready, rmh_api.hip)
    if (x->peers.empty()) { return RMH_OK; }
    // local peers read the send buffer on THEIR exchange streams: the previous copies out of it must be done before
    // it is overwritten (their ev_done is recorded behind those copies)

@@ -55,6 +55,7 @@ struct rmh_ctx
    double stage_dt = 0.0;
    int *d_nbr = nullptr, *d_st27 = nullptr, *d_cg = nullptr;
    const double *u_ghost = nullptr, *gh_min = nullptr, *gh_max = nullptr;
+   int ghost_readers_end = 0; // 1 + the last owned element whose stencil reaches a ghost: ranges from here on read no ghost data
    bool gh_foreign = false; // ghost extrema overwritten by rmh_exchange_minmax_* (another field's) since the last exchange of u
    int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)
    int gh_compact = 0; // 1: ghost records are [min | max | D^2 face trace] cells (rmh_exchange_setup, compact)

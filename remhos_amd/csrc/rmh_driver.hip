@@ -954,7 +954,15 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
       L.subcell_vel = b.cd.subcell_vel.empty() ? nullptr : b.cd.subcell_vel.data();
       L.device = device;
       RMHD_TRY(rmh_create(&L, &b.ctx));
-      RMHD_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+      {
+         // RMH_COMM_CUS = k: the stage kernels leave k compute units to the exchange stream (rmh_stream_create_reserving; only
+         // where RCCL kernels run beside them -- same-process blocks exchange by device copies)
+         const char *ecu = std::getenv("RMH_COMM_CUS");
+         const int kcu = (rccl && ecu) ? std::atoi(ecu) : 0;
+         void *sv = nullptr;
+         RMHD_TRY(rmh_stream_create_reserving(device, kcu > 0 ? kcu : 0, &sv));
+         b.stream = (hipStream_t)sv;
+      }
       RMHD_TRY(rmh_set_stream(b.ctx, b.stream));
       RMHD_TRY(rmh_set_lo_type(b.ctx, cc.lo_type));
       RMHD_TRY(rmh_set_bounds_type(b.ctx, cfg->bounds_type));

@@ -85,7 +85,10 @@ struct K2Cfg : TabLayout<P>
    // ds_read_b128: -6 % LDS cycles, +16 % conflicts elsewhere, +-0 in time).  Padding the six trace blocks (D^2 + 2) and other
    // element strides (== 8 or 24 mod 32) took 13-25 % of the conflicts away at -0.5 ... +0.2 % in time; the face-major order of
    // the face rows (ho_kernel2) takes 23 % at +0.25 % and needs the element stride == 2 (mod 32).
-   static constexpr int S2 = D2 + 1; // padded row stride of U1 / M1
+#ifndef RMH_S2PAD
+#define RMH_S2PAD 1
+#endif
+   static constexpr int S2 = D2 + (RMH_S2PAD); // padded row stride of U1 / M1
    static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
@@ -376,6 +379,29 @@ __device__ inline double fdiv(double a, double b)
    const double q = a * r;
    return fma(fma(-b, q, a), r, q);
 #else
+   return a / b;
+#endif
+}
+
+// The same quotient with the refined reciprocal of b made once (fdiv_rcp) and shared by several divisions by the same b --
+// the limiter divides by dt twice per dof: a / b costs three instructions instead of eight, the value is fdiv's bit for bit
+__device__ inline double fdiv_rcp(double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RMH_FAST_DIV
+   double r = __builtin_amdgcn_rcp(b);
+   r = fma(fma(-b, r, 1.0), r, r);
+   return fma(fma(-b, r, 1.0), r, r);
+#else
+   return b;
+#endif
+}
+__device__ inline double fdiv_by(double a, double b, double r)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RMH_FAST_DIV
+   const double q = a * r;
+   return fma(fma(-b, q, a), r, q);
+#else
+   (void)r;
    return a / b;
 #endif
 }
@@ -2529,6 +2555,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];
       double dtc = INFINITY; // UpdateTimeStepEstimate(u, du_LO, u_min, u_max), remhos.cpp:1839-1842
+      const bool want_dt = L.dt_est != nullptr; // (uniform: without -dtc the candidates -- two IEEE divisions per dof -- are not formed)
+      const double r_dt = fdiv_rcp(L.dt);
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -2541,10 +2569,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             const int s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
             const double lo = RMH_W(eb)[C::oLim + s3], hi = RMH_W(eb)[C::oLim + 27 + s3];
             const double ubar = fdiv(mass[r], vol[r]);
-            if (!BOTH) { dlo[r] = fdiv(ubar - uu[r], L.dt); } // MassBasedAvg; with RD dlo is already there
-            dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi));
+            if (!BOTH) { dlo[r] = fdiv_by(ubar - uu[r], L.dt, r_dt); } // MassBasedAvg; with RD dlo is already there
+            if (want_dt) { dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi)); }
             const double u_new_lo = uu[r] + L.dt * dlo[r];
-            const double m_dt = fdiv(mm[r], L.dt);
+            const double m_dt = fdiv_by(mm[r], L.dt, r_dt);
             const double f_clip_min = m_dt * (lo - u_new_lo);
             const double f_clip_max = m_dt * (hi - u_new_lo);
             double fc = mm[r] * (xg[r] - dlo[r]);
@@ -2554,7 +2582,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             pos[r] = fmax(fc, 0.0);
          }
       }
-      if (L.dt_est)
+      if (want_dt)
       {
          dtc = wave_minmax<true>(dtc);
          if ((tid & 63) == 63) { atomic_min_nonneg(L.dt_est, dtc); }
@@ -2573,8 +2601,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          {
             const double new_mass = sumNeg[r] + sumPos[r];
             double fc = fcl[r];
-            if (new_mass > eps) { fc = fmin(0.0, fc) - fdiv(fmax(0.0, fc) * sumNeg[r], sumPos[r]); }
-            if (new_mass < -eps) { fc = fmax(0.0, fc) - fdiv(fmin(0.0, fc) * sumPos[r], sumNeg[r]); }
+            {
+               // the two rescale branches (remhos_fct.cpp:523-532) exclude each other: one division, operands selected first
+               const bool up = new_mass > eps, dn = new_mass < -eps;
+               const double fpos = fmax(0.0, fc), fneg = fmin(0.0, fc);
+               const double q = fdiv(up ? fpos * sumNeg[r] : fneg * sumPos[r], up ? sumPos[r] : sumNeg[r]);
+               if (up) { fc = fneg - q; }
+               else if (dn) { fc = fpos - q; }
+            }
             const double dui = dlo[r] + fdiv(fc, mm[r]);
             ynew[r] = (L.x_base ? L.rk_a * xb[r] : 0.0) + L.rk_b * (uu[r] + L.dt_rk * dui);
             if (e0 + t / D3 < L.e_end)

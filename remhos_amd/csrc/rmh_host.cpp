@@ -275,6 +275,22 @@ double u0_function_2d(int problem, const double *bb_min, const double *bb_max, c
    }
 }
 
+// The problem ids whose velocity field AND initial condition are implemented above (remhos.cpp:2001-2355 defines more:
+// 2, 3, 6, 7 and 11 have no branch here).  An id outside the set used to run silently with v = 0 or u0 = 0 -- and with
+// -dt -1 a CFL step of 0.25 h / 1e-7; now it is an error of the case builder.
+static std::string check_problem(int problem)
+{
+   const int pv = problem % 20, pu = problem % 10;
+   const bool vel_ok = pv == 0 || pv == 1 || pv == 2 || pv == 4 || pv == 5 || pv == 10 || (pv >= 12 && pv <= 17);
+   const bool u0_ok = pu == 0 || pu == 1 || pu == 4 || pu == 5;
+   if (problem < 0 || !vel_ok || !u0_ok)
+   {
+      return "problem " + std::to_string(problem) + " is not implemented (velocity: 0, 1, 2, 4, 5, 10, 12-17 mod 20; initial field: 0, 1, 4, 5 mod 10)";
+   }
+   return "";
+}
+
+
 // The reference's 2-D lattice meshes on ONE rank: data/inline-quad.mesh (4 x 4 quadrilaterals on [0,1]^2) and
 // data/periodic-square.mesh (3 x 3 on [-1,1]^2, 9-decimal coordinates: part of the reference's answers).  Same steps as the
 // 3-D builder below: CFL step, Q2 nodes and remap displacement (with the reference's "t advances first" loop), per-element
@@ -290,6 +306,7 @@ static std::string build_case_2d(const CaseConfig &cfg, CaseData &out)
    if (cfg.px != 1 || cfg.py != 1 || cfg.pz != 1 || cfg.rank != 0 || cfg.self_wrap != 0) { return "dim = 2 runs on one rank"; }
    if (cfg.rs_extra[0] || cfg.rs_extra[1] || cfg.rs_extra[2]) { return "dim = 2: no rs_extra"; }
    if (cfg.lo_type != 3 && cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 3, 4 or 5"; }
+   if (const std::string e = check_problem(cfg.problem); !e.empty()) { return e; }
    const std::vector<double> verts = refine(coarse, cfg.rs);
    const int N = (int)verts.size() - 1, p = cfg.order, D = p + 1, problem = cfg.problem;
    out = CaseData();
@@ -444,6 +461,7 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
    const int nranks = cfg.px * cfg.py * cfg.pz;
    if (cfg.rank < 0 || cfg.rank >= nranks) { return "bad rank"; }
    if (cfg.lo_type != 3 && cfg.lo_type != 4 && cfg.lo_type != 5) { return "lo_type must be 3, 4 or 5"; }
+   if (const std::string e = check_problem(cfg.problem); !e.empty()) { return e; }
 
    // per direction: -rs levels plus rs_extra[d] more (0 in the reference's meshes; the weak-scaling lattices of
    // bench.py refine the directions that carry two partition blocks once more)

@@ -206,6 +206,10 @@ enum { hipStreamNonBlocking = 1 };
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return 0; }
+struct hipDeviceProp_t { int multiProcessorCount = 256; };
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { *p = hipDeviceProp_t(); return 0; }
+// (the emulation has no compute units to mask: the stream is an ordinary one; the mask itself is checked by the caller's test)
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, unsigned n, const unsigned *mask) { return (n && mask) ? hipStreamCreate(s) : 1; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }

@@ -1,0 +1,143 @@
+"""The option sweep and the whole-remap soak that earlier rounds ran by hand (tests/sweep_parity.py, tools/soak_granular.py),
+as collected tests: one RK stage of every order x LO solver x bounds type through the one-kernel stage AND through the
+granular entry points, against the oracle (MassBasedAvg remhos_lo.cpp:247-324, PAResidualDistribution(Subcell)
+remhos_lo.cpp:1620-1802, ClipScale remhos_fct.cpp:449-541, bounds remhos_tools.cpp:432-523)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = {1: 1e-12, 2: 1e-12, 3: 5e-10, 4: 5e-9, 5: 1e-7, 6: 2e-7}  # per-stage tolerance: cond-limited local mass solve
+MESHES = {"remap-cube01": ("cube01_hex", 10, 1), "transport-periodic": ("periodic-cube", 0, 0), "remap-periodic": ("periodic-cube", 10, 0)}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+
+    assert torch.cuda.is_available()
+    from remhos_amd.capi import load_library
+
+    return load_library()
+
+
+def one_stage(lib, p, lo, bt, mesh_key, granular, completion=False):
+    import torch
+
+    from oracle.remhos_oracle import Config, Remhos
+    from remhos_amd.capi import Context
+    from tests.helpers import layout_from_oracle, perturbed
+
+    mesh, prob, rs = MESHES[mesh_key]
+    if p >= 5 and mesh == "cube01_hex":
+        rs = 0
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=prob, dt=0.01, t_final=0.7, lo=lo, bounds_type=bt)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    sub = None
+    if lo == 4:
+        sv = r.Vs if r.exec_mode == 1 else r.vel(r.Xs0)
+        sub = np.ascontiguousarray(sv.transpose(0, 2, 1))
+    ctx = Context(lib, order=p, exec_mode=r.exec_mode, x0=x0, vel=vel, face_nbr=nbr, stencil27=st, subcell_vel=sub)
+    ctx.set_bounds_type(bt)
+    if completion:
+        ctx.set_mass_completion(True, True)
+    if lo != 5:
+        ctx.set_lo_type(lo)
+    u_h = perturbed(r.u)
+    t = 0.35 if r.exec_mode == 1 else 0.0
+    du_ref = r.stage(u_h, t, cfg.dt)
+    u = torch.from_numpy(u_h).to("cuda:0")
+    y, du = torch.empty_like(u), torch.empty_like(u)
+    ctx.setup(t)
+    errs = {}
+    scale = np.abs(du_ref).max()
+    if granular:
+        k, dulo, du2, umin, umax = (torch.empty_like(u) for _ in range(5))
+        xmn, xmx = (torch.empty(u.shape[0], dtype=u.dtype, device=u.device) for _ in range(2))
+        ctx.ho_apply(u, k)
+        if lo == 5:
+            ctx.lo_massavg(u, k, cfg.dt, dulo)
+            ctx.limit_fused(u, k, cfg.dt, du=du)
+        else:
+            (ctx.lo_rdsubcell if lo == 4 else ctx.lo_rd)(u, dulo)
+            ctx.limit_fused_lo(u, k, dulo, cfg.dt, du=du)
+        ctx.elem_minmax(u, xmn, xmx)
+        ctx.bounds(xmn, xmx, umin, umax)
+        ctx.fct_clipscale(u, ctx.lumped_mass_ptr(), k, dulo, umin, umax, cfg.dt, du2)
+        torch.cuda.synchronize()
+        errs["ho + fused limiter"] = float(np.abs(du.cpu().numpy() - du_ref).max() / scale)
+        errs["reference call sequence"] = float(np.abs(du2.cpu().numpy() - du_ref).max() / scale)
+    else:
+        ctx.stage_fused(u, cfg.dt, y, du=du, dt_rk=cfg.dt)
+        torch.cuda.synchronize()
+        errs["one-kernel stage"] = float(np.abs(du.cpu().numpy() - du_ref).max() / scale)
+        # the RK update of the same call: y = u + dt du
+        assert np.abs(y.cpu().numpy() - (u_h + cfg.dt * du.cpu().numpy())).max() < 1e-14
+    ctx.close()
+    return errs
+
+
+@pytest.mark.parametrize("mesh_key", list(MESHES))
+@pytest.mark.parametrize("bt", [0, 1])
+@pytest.mark.parametrize("lo", [3, 4, 5])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6])
+def test_sweep_one_kernel_stage(lib, p, lo, bt, mesh_key):
+    """96 combinations (order x LO solver x bounds type x mesh/problem); lo 3 / 4 need order >= 2"""
+    if lo != 5 and p < 2:
+        pytest.skip("residual-distribution LO solvers need order >= 2 (remhos.cpp:748-760)")
+    for name, err in one_stage(lib, p, lo, bt, mesh_key, granular=False).items():
+        assert err < REL[p], (name, err)
+
+
+@pytest.mark.parametrize("mesh_key", ["remap-cube01", "transport-periodic"])
+@pytest.mark.parametrize("bt", [0, 1])
+@pytest.mark.parametrize("lo", [3, 4, 5])
+@pytest.mark.parametrize("p", [2, 3, 4, 6])
+def test_sweep_granular_entry_points(lib, p, lo, bt, mesh_key):
+    """the same stage through rmh_ho_apply + LO solver + rmh_limit_fused(_lo), and through the reference's call sequence
+    (elem_minmax, bounds, fct_clipscale): 48 combinations"""
+    for name, err in one_stage(lib, p, lo, bt, mesh_key, granular=True).items():
+        assert err < REL[p], (name, err)
+
+
+@pytest.mark.parametrize("p,lo", [(3, 5), (6, 5), (3, 4)])
+def test_sweep_with_mass_completion(lib, p, lo):
+    """converged solve + Jacobi step + constant mode (rmh_set_mass_completion): the same tolerances hold"""
+    for name, err in one_stage(lib, p, lo, 0, "remap-cube01", granular=False, completion=True).items():
+        assert err < REL[p], (name, err)
+
+
+@pytest.mark.parametrize("order,rs,lo", [(3, 3, 5), (2, 3, 5), (4, 2, 5), (6, 2, 5), (3, 2, 4)])
+def test_soak_granular_paths_agree_over_a_whole_remap(order, rs, lo):
+    """tools/soak_granular.py at test size: the whole remap (pseudo-time 0 -> 1) through the one-kernel stage, HO kernel +
+    fused limiter, and the reference's call sequence -- final masses to 1e-12, fields to round-off growth."""
+    import torch
+
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import Case, bind_driver, make_config
+    from remhos_amd.stepper import Stepper
+
+    lib = bind_driver(load_library())
+    case = Case(lib, make_config("periodic-cube", rs, order, 10, -1.0, 0.5, lo_type=lo, pa=1))
+    res = {}
+    for name, kw in (("one-kernel", dict()), ("ho+limiter", dict(one_kernel=False)), ("call-sequence", dict(fused=False))):
+        st = Stepper(lib, case, device="cuda:0", **kw)
+        m0, _ = st.local_mass_and_max(0.0)
+        if order >= 5:
+            st.dt = case.dt / (2 * order + 1)  # the stable step: runs a rounding error apart stay together
+            n = st.run(max_steps=60)
+        else:
+            n = st.run()
+        torch.cuda.synchronize()
+        m1, umax = st.local_mass_and_max()
+        assert n > 10 and abs(m1 - m0) <= 1e-12 * abs(m0), (name, n, m0, m1)
+        assert float(st.x.min()) > -1e-10 and umax < 1.0 + 1e-10  # bounds preservation (remhos_fct.cpp:449-541)
+        res[name] = (st.x.clone(), m1)
+        st.close()
+    ref, mref = res["one-kernel"]
+    for name in ("ho+limiter", "call-sequence"):
+        x, m = res[name]
+        assert abs(m - mref) <= 1e-12 * abs(mref), name
+        assert float((x - ref).abs().max()) < (1e-7 if order >= 5 else 1e-8), name

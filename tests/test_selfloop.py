@@ -149,7 +149,7 @@ def test_selfloop_solver_classes_emulated(emulib, kw, monkeypatch):
 def test_state_checks_of_the_exchange_and_the_split_stage(emulib):
     """Round-4 state checks (advisor findings): (i) the ranges of one fused stage must name the same u and dt -- a stage
     that is abandoned or fails leaves no stale extrema behind; (ii) after rmh_exchange_minmax_* the ghost extrema belong to
-    another field: the limiters of u refuse them until u is exchanged again; (iii) rmh_comm_count without a communicator."""
+    another field: the limiters of u refuse them -- for the element ranges that read ghosts -- until u is exchanged again; (iii) rmh_comm_count without a communicator."""
     import pytest as _pytest
     import torch
 
@@ -191,7 +191,14 @@ def test_state_checks_of_the_exchange_and_the_split_stage(emulib):
     xe_min, xe_max = torch.zeros(ne, dtype=u.dtype), torch.ones(ne, dtype=u.dtype)
     c.exchange_minmax(xe_min, xe_max)
     with _pytest.raises(RuntimeError, match="another field"):
-        c.stage_fused_range(u, dt, z, nh, ne, False)
+        c.stage_fused_range(u, dt, z, 0, nh, True)  # the halo shell reads the ghost extrema
+    # (round 5, advisor: the interior range reads no ghost and is NOT refused; a range that does is refused while the
+    # exchange is in flight -- the ghost extrema are valid from rmh_exchange_end on, not from rmh_exchange_begin)
+    c.exchange_begin(u)
+    c.stage_fused_range(u, dt, z, nh, ne, False)
+    with _pytest.raises(RuntimeError, match="in flight"):
+        c.stage_fused_range(u, dt, z, 0, nh, True)
+    c.exchange_end()
     c.exchange_begin(u)
     c.stage_fused_range(u, dt, z, nh, ne, False)
     c.exchange_end()

@@ -28,10 +28,11 @@ args = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ref = None
 for name in args.names:
+    name, _, form = name.partition("@")  # "main@split": HO kernel + LO kernel + fused limiter instead of the one-kernel stage
     path = os.path.join(root, "remhos_amd", f"librmh_{name}.so" if name not in ("", "main") else "librmh.so")
     lib = bind_driver(load_library(path))
     case = Case(lib, make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, lo_type=args.lo, pa=0 if args.exact else 1))
-    st = Stepper(lib, case, device="cuda:0")
+    st = Stepper(lib, case, device="cuda:0", one_kernel=(form != "split"))
     for _ in range(2):
         st.step(case.dt)
     st.ctx.enable_timers(True)
@@ -52,7 +53,7 @@ for name in args.names:
     else:
         diff = float((x - ref).abs().max())
     nd = case.ne_global * case.ndof
-    print(f"{name or 'main':14s} {1e-6 * nd * 3 * args.steps / el:9.1f} MDOFs*stage/s  kernel {1e3 * tim[0] / (3 * args.steps):7.4f} ms  "
+    print(f"{(name or 'main') + ('@' + form if form else ''):14s} {1e-6 * nd * 3 * args.steps / el:9.1f} MDOFs*stage/s  kernel {1e3 * tim[0] / (3 * args.steps):7.4f} ms (lo {1e3 * tim[2] / (3 * args.steps):.4f} lim {1e3 * tim[3] / (3 * args.steps):.4f})  "
           f"cg {it}  mass {mass:.15g}  max|x - x_first| {diff:.3e}", flush=True)
     st.close()
     del st, case
