@@ -46,6 +46,11 @@ typedef struct {
                          (remhos.cpp:888-904, 1709-1738, 1848-1915); remap mode, -fct 2, fixed dt, an IDP solver        */
    int ode_solver;    /* -s  : 3 (or 0) RK3 SSP; 11 / 12 / 13 forward Euler / RK2 / RK3 IDP solvers
                          (remhos_solvers.cpp; what -ps runs with in the reference's tests)                              */
+   int tile_rows;     /* element NUMBERING of the case builder (dim = 3): 0 = the lattice order x, y, z; T > 0 = strips of T
+                         lattice rows in y, and inside a strip z before y -- the elements a stage kernel has in flight at a
+                         time then hold each other's face neighbours in all three directions (L2 hits instead of HBM reads of
+                         the neighbour traces, extrema and shared face-table blocks).  The same mesh and the same results,
+                         element for element (owned_gid maps the numbering); halo elements still come first.               */
 } rmhd_config;
 
 typedef struct {

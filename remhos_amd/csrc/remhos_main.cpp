@@ -57,6 +57,7 @@ int main(int argc, char **argv)
       else if (a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { c.ode_solver = std::atoi(next()); }
       else if (a == "-ps") { c.ps = 1; }
+      else if (a == "-tile") { c.tile_rows = std::atoi(next()); } // element numbering of the case builder (rmh_driver.h)
       else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
    }
    if ((ho != 2 && ho != 3) || fct != 2 || c.lo_type < 3 || c.lo_type > 5)

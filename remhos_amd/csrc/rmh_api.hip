@@ -109,9 +109,10 @@ template <int P>
 int ensure_face_table(rmh_ctx *c)
 {
    if (c->d_fgeo) { return 0; }
-   RMH_HIP(hipMalloc((void **)&c->d_fgeo, (size_t)c->ne * FaceGeo<P>::PER_ELEM * sizeof(double)));
+   RMH_HIP(hipMalloc((void **)&c->d_fgeo, (size_t)c->face_slots * FaceGeo<P>::SLOT * sizeof(double)));
    hipLaunchKernelGGL((face_geom_kernel<P>), dim3(c->ne), dim3(256), 0, c->stream, (const double *)c->d_x0,
-                      (const double *)c->d_vel, (const double *)c->d_tab, c->exec_mode == 1 ? 1 : 0, c->d_fgeo);
+                      (const double *)c->d_vel, (const double *)c->d_tab, c->exec_mode == 1 ? 1 : 0,
+                      (const int *)c->d_face_rows, c->d_fgeo);
    RMH_HIP(hipGetLastError());
    return 0;
 }
@@ -132,6 +133,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
    a.subvel = c->d_subvel;
    a.subx0 = c->d_subx0;
    a.fgeo = nullptr;
+   a.face_rows = nullptr;
    a.subvmid = c->d_subvmid;
    a.du = du;
    a.m = m;
@@ -172,6 +174,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
       {
          if (int rc = ensure_face_table<P2>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
+         a.face_rows = c->d_face_rows;
       }
       hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
@@ -182,6 +185,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
+         a.face_rows = c->d_face_rows;
       }
       hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
@@ -206,6 +210,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
    a.subvel = c->d_subvel;
    a.subx0 = c->d_subx0;
    a.fgeo = nullptr;
+   a.face_rows = nullptr;
    a.subvmid = c->d_subvmid;
    a.du = du;
    a.m = c->d_m;
@@ -249,6 +254,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       {
          if (int rc = ensure_face_table<P4>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
+         a.face_rows = c->d_face_rows;
       }
       hipLaunchKernelGGL((ho_kernel2<P4, 3>), dim3(grid), dim3(C::NT), 0, c->stream, a);
    }
@@ -261,6 +267,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
          a.fgeo = c->d_fgeo;
+         a.face_rows = c->d_face_rows;
       }
       hipLaunchKernelGGL((ho_kernel2<P, 1>), dim3(grid), dim3(C::NT), 0, c->stream, a);
    }
@@ -379,6 +386,45 @@ int create_device_state(rmh_ctx *c, const rmh_layout *L)
    }
    if ((rc = upload(&c->d_nbr, L->face_nbr, ne * 6))) { return rc; }
    if ((rc = upload(&c->d_st27, L->stencil27, ne * 27))) { return rc; }
+   {
+      // Face speed table, one block per face (FaceGeo, rmh_ho2.hpp): the low face c of element e owns block 3 e + c; the
+      // high face reads the block of the neighbour's low face with the sign flipped where that neighbour is an owned
+      // element that names e back and the nine face nodes of x0 and v agree BIT BY BIT on the two sides (then the two rows
+      // are the same numbers with opposite signs); otherwise -- boundary, ghost neighbour, a periodic seam of a remap run --
+      // it keeps a block of its own behind the regular ones.
+      std::vector<int> rows(ne * 6);
+      long long slots = 3 * (long long)ne;
+      const int st3[3] = {1, 3, 9};
+      for (size_t e = 0; e < ne; e++)
+      {
+         for (int cdir = 0; cdir < 3; cdir++)
+         {
+            rows[e * 6 + 2 * cdir] = (int)(3 * e + cdir);
+            const int nb = L->face_nbr[e * 6 + 2 * cdir + 1];
+            bool shared = nb >= 0 && (size_t)nb < ne && L->face_nbr[(size_t)nb * 6 + 2 * cdir] == (int)e && (size_t)nb != e;
+            if (shared)
+            {
+               const int n1 = st3[(cdir + 1) % 3], n2 = st3[(cdir + 2) % 3], hi = 2 * st3[cdir];
+               for (const double *arr : {L->x0, L->vel})
+               {
+                  const double *me = arr + e * 81, *ot = arr + (size_t)nb * 81;
+                  for (int comp = 0; comp < 3 && shared; comp++)
+                  {
+                     for (int a = 0; a < 9; a++)
+                     {
+                        const int off = comp * 27 + (a % 3) * n1 + (a / 3) * n2;
+                        if (std::memcmp(&me[off + hi], &ot[off], sizeof(double)) != 0) { shared = false; break; }
+                     }
+                  }
+               }
+            }
+            if (slots >= 0x7fffffffLL) { return fail(RMH_ERR_INVALID, "too many faces for the 31-bit block index of the face speed table"); }
+            rows[e * 6 + 2 * cdir + 1] = shared ? (int)((3u * (unsigned)nb + (unsigned)cdir) | 0x80000000u) : (int)slots++;
+         }
+      }
+      c->face_slots = slots;
+      if ((rc = upload(&c->d_face_rows, rows.data(), ne * 6))) { return rc; }
+   }
    if (L->subcell_vel)
    {
       if ((rc = upload(&c->d_subvel, L->subcell_vel, ne * 3 * c->ndof))) { return rc; }
@@ -500,7 +546,7 @@ void rmh_destroy(rmh_ctx *c)
    if (!c) { return; }
    (void)hipSetDevice(c->device);
    exchange_free(c);
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_m, c->d_scr_ho, c->d_scr_lo, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_face_rows, c->d_m, c->d_scr_ho, c->d_scr_lo, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {

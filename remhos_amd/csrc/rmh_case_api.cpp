@@ -36,6 +36,7 @@ CaseConfig to_config(const rmhd_config &c)
    k.rank = c.rank;
    for (int d = 0; d < 3; d++) { k.rs_extra[d] = c.rs_extra[d]; }
    k.self_wrap = c.self_wrap;
+   k.tile_rows = c.tile_rows > 0 ? c.tile_rows : 0;
    return k;
 }
 } // namespace remhos

@@ -44,6 +44,8 @@ struct rmh_ctx
    double *d_x0h = nullptr, *d_velh = nullptr; // x0, vel in the hierarchical node basis (what ho_kernel2 reads)
    double *d_subx0 = nullptr, *d_subvmid = nullptr; // lo 4 set-up data (subcell_setup_kernel)
    double *d_fgeo = nullptr;                        // face speed coefficients (face_geom_kernel)
+   int *d_face_rows = nullptr;                      // [ne][6] table block of every element face (FaceGeo, rmh_ho2.hpp)
+   long long face_slots = 0;                        // blocks in d_fgeo: 3 ne + the high faces that keep their own
    double *d_m = nullptr, *d_xe_min = nullptr, *d_xe_max = nullptr;
    double *d_scr_ho = nullptr, *d_scr_lo = nullptr; // dim = 2: du_HO / du_LO between the kernels of rmh_stage_fused (made on first use)
    double *d_xe_min2 = nullptr, *d_xe_max2 = nullptr; // extrema of the fused stage's output (swapped in)

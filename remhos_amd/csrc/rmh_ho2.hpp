@@ -85,10 +85,14 @@ struct K2Cfg : TabLayout<P>
    // ds_read_b128: -6 % LDS cycles, +16 % conflicts elsewhere, +-0 in time).  Padding the six trace blocks (D^2 + 2) and other
    // element strides (== 8 or 24 mod 32) took 13-25 % of the conflicts away at -0.5 ... +0.2 % in time; the face-major order of
    // the face rows (ho_kernel2) takes 23 % at +0.25 % and needs the element stride == 2 (mod 32).
+   // (round 5: "odd" must hold for the stride itself -- D^2 + 1 is EVEN at odd D (p = 2, 4, 6), and then the column pass's
+   // ds_read2_b64 of a U1 / M1 row (banks mod 32 dwords, 16-lane groups) sends lanes qx = 0 and qx = 8 to the same banks: p = 6
+   // SQ_LDS_BANK_CONFLICT 1.10e8 -> 4.4e7 per launch (-60 %), LDS-array cycles -11 %, 21.7 k -> 22.1 k MDOFs*stage/s (+2.0 %),
+   // lo 4 at p = 6 +1.2 %; p = 2, 4 +-0; D^2 + 4 the same as D^2 + 2.  Bit-identical.)
 #ifndef RMH_S2PAD
-#define RMH_S2PAD 1
+#define RMH_S2PAD ((D2 & 1) ? 2 : 1)
 #endif
-   static constexpr int S2 = D2 + (RMH_S2PAD); // padded row stride of U1 / M1
+   static constexpr int S2 = D2 + (RMH_S2PAD); // padded row stride of U1 / M1: odd
    static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
@@ -165,7 +169,10 @@ struct K2Cfg : TabLayout<P>
    // (p = 4, round 4: four wavefronts per SIMD -- 128 VGPRs, 140 B/lane of scratch -- 20.8 k -> 17.4 k MDOFs*stage/s on cube01_hex -rs 5)
    // (lo 4 at p = 6, round 4: with the slim layout below the kernel's LDS admits a fifth workgroup per CU, i.e. 2.5 wavefronts per
    // SIMD; asking for 3 gives 168 VGPRs + 76 B/lane of scratch and 10.0 k instead of 11.7 k MDOFs*stage/s -- it stays at 2)
-   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0));
+#ifndef RMH_WAVES6_LO4
+#define RMH_WAVES6_LO4 2
+#endif
+   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : ((P == 6 && BOTH) ? RMH_WAVES6_LO4 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0)));
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
@@ -183,8 +190,10 @@ template <int CTRL>
 __device__ inline double dpp_value(double v)
 {
    const int lo = __double2loint(v), hi = __double2hiint(v);
-   const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-   const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+   // (bound_ctrl: a lane without a source gets 0 from the instruction itself -- with all rows and banks enabled the destination
+   // then needs no zero-initialisation: one v_mov_b32 less per DPP move, 84 per split-column wavefront at p = 6)
+   const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+   const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
    return __hiloint2double(hi2, lo2);
 }
 
@@ -352,6 +361,19 @@ __device__ inline void raise_flag(int *flag)
 #else
    __atomic_store_n(flag, 1, __ATOMIC_RELAXED);
 #endif
+}
+
+// An LDS offset (in doubles) the compiler must treat as a value it knows nothing about.  Why: an address "lane part +
+// large constant" makes the DS load/store optimizer rebase EVERY pair of 8-byte reads it merges into a ds_read2_b64 (whose two
+// offsets reach 2040 bytes) -- v_mov_b32 const, v_mad_u32_u24 lane, stride, const per pair: at p = 6 the column pass carried 158
+// v_mad + 150 v_mov for its 98 U1 reads and its table rows (13 % of the phase's VALU instructions).  With the whole base made
+// opaque the constants that remain are the small offsets inside a row, which fit the instruction.
+__device__ inline int opaque_lds_offset(int x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   asm volatile("" : "+v"(x));
+#endif
+   return x;
 }
 
 // nothing is scheduled across this point (keeps the LDS table reads of the split columns next to their uses: hoisted
@@ -793,17 +815,25 @@ __device__ inline int axis_next2(const int c) { return (0x12u >> (2 * c)) & 3u; 
 //    w_q1 w_q2 (v . n_out)(t),   n_out = +-(dX/dxi1 x dX/dxi2),  X(t) = x0 + t v,
 // is the quadratic c0 + c1 t + c2 t^2 with c_k = +-w v.n_k, n_0 = T1x x T2x, n_1 = T1x x T2v + T1v x T2x, n_2 = T1v x T2v
 // (T1x, T1v: tangents of x0 and of v); a static mesh (transport) has c1 = c2 = 0.  What the face rows of ho_kernel2
-// evaluated from the 27 nodes every stage (DGTraceIntegrator set-up, remhos.cpp:651-657) is read from
-//    fgeo[e][q2][k][f*Q + q1]    (3 Q * 6 Q doubles per element)
+// evaluated from the 27 nodes every stage (DGTraceIntegrator set-up, remhos.cpp:651-657) is read from a table
 // instead: 2 FMAs per point in place of ~50, for HBM bytes the stage has to spare.
+// Round 5: one block of the table per FACE, not per element side (the reference's face quadrature data is per face too,
+// remhos_lo.cpp:513-610).  The two sides of an interior face see the same nine nodes and opposite normals, so the block of
+// the side with the low local face (side 0: slot 3 e + c) serves the neighbour's high face with the sign flipped -- the same
+// bits, negated.  A high face keeps a block of its own ("orphan" slot, behind the 3 ne regular ones) where that does not
+// hold: boundary faces, ghost neighbours, and periodic seams of a remap run, whose two node copies slide against each other
+// (SURVEY 8d).  face_rows[e][6] (made on the host by rmh_create from the node data itself, bit by bit) holds the slot of
+// every element face, bit 31 set = read with the sign flipped:
+//    fgeo[slot][q2][k][q1]    (3 Q * Q doubles per slot; ~3.1 instead of 6 slots per element on a periodic lattice)
 template <int P>
 struct FaceGeo
 {
-   static constexpr int Q = K2Cfg<P>::Q, R = 6 * Q, PER_ELEM = 3 * Q * R;
+   static constexpr int Q = K2Cfg<P>::Q, R = 6 * Q, SLOT = 3 * Q * Q;
 };
+constexpr int RMH_FACE_FLIP = (int)0x80000000u;
 
 template <int P>
-__global__ void face_geom_kernel(const double *x0, const double *vel, const double *tab, const int move, double *fgeo)
+__global__ void face_geom_kernel(const double *x0, const double *vel, const double *tab, const int move, const int *face_rows, double *fgeo)
 {
    using C = K2Cfg<P>;
    constexpr int Q = C::Q, R = 6 * Q;
@@ -813,6 +843,8 @@ __global__ void face_geom_kernel(const double *x0, const double *vel, const doub
    {
       const int q2 = pt / R, r = pt % R;
       const int f = r / Q, q1 = r % Q;
+      const int row = face_rows[e * 6 + f];
+      if (row < 0) { continue; } // served by the neighbour's block
       const int c = f >> 1, side = f & 1;
       const int n0 = side ? 2 * axis_stride<3>(c) : 0, n1 = axis_stride<3>(axis_next(c)), n2 = axis_stride<3>(axis_next2(c));
       double t1x[3], t1v[3], t2x[3], t2v[3], vf[3];
@@ -846,7 +878,7 @@ __global__ void face_geom_kernel(const double *x0, const double *vel, const doub
          ck[2] += vf[comp] * (t1v[i] * t2v[j] - t1v[j] * t2v[i]);
       }
       const double w = (side ? 1.0 : -1.0) * tab[C::oW + q1] * tab[C::oW + q2];
-      for (int k = 0; k < 3; k++) { fgeo[e * FaceGeo<P>::PER_ELEM + (size_t)(q2 * 3 + k) * R + r] = w * ck[k]; }
+      for (int k = 0; k < 3; k++) { fgeo[(size_t)row * FaceGeo<P>::SLOT + (size_t)(q2 * 3 + k) * Q + q1] = w * ck[k]; }
    }
 }
 
@@ -968,6 +1000,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // partial z-leg sums added across the three lanes (DPP row shifts) -- and it takes the face rows off the first one's hands.
    constexpr bool CSPL = SPL && C::CSPL;
    const int frt = CSPL ? (tid ^ 64) : tid; // face-row index of this thread (round 0)
+   // opaque LDS row bases (opaque_lds_offset) where an element block is larger than a ds_read2_b64 reaches
+#ifndef RMH_OPAQUE_BASE
+#define RMH_OPAQUE_BASE (P >= 4)
+#endif
+   constexpr bool OPQ = RMH_OPAQUE_BASE;
    typedef tabp_t<P> tabp;
    tabp gtb = (tabp)c_tab[P]; // constant memory: compile-time indices become scalar loads
    tabp gt = gtb;
@@ -1013,7 +1050,17 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // sums stay in the wavefront, RMH_WAVE_DOT)
    if (tid < 4) { s_flag[tid] = 0; }
    // all global loads are issued before the first LDS store so that they are in flight together
-   // (neighbour indices first: the trace loads depend on them)
+   // (neighbour indices first: the trace loads depend on them; with them the table slots of this thread's face rows)
+   constexpr bool FMJ = RMH_FACE_MAJOR && NB > 1;
+   constexpr int NFR = (NB * 6 * Q + NT - 1) / NT;
+   int fri[NFR];
+#pragma unroll
+   for (int jp = 0; jp < NFR; jp++)
+   {
+      const int fr = min(frt + jp * NT, NB * 6 * Q - 1);
+      const int feb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q), ff = FMJ ? fr / (NB * Q) : (fr % (6 * Q)) / Q;
+      fri[jp] = a.face_rows[(size_t)min(e0 + feb, a.e_end - 1) * 6 + ff];
+   }
    load_batch<C, FUSED>(a, e0, tid, nbi, sti, gx0, gv, gu);
    // table copy for lane-dependent indexing: loaded behind the element data, stored with it (a copy loop at the top of
    // the kernel put a full memory round trip in front of the first element load)
@@ -1083,23 +1130,21 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // access group then work on ONE face of several elements -- the same node and trace offsets, element blocks apart (EL == 2
    // mod 32: different banks) -- instead of on several faces of one element, whose trace blocks (D^2 doubles apart) and face
    // nodes share banks (tools/pmc_variants.sh: the face rows were 30 % of the p = 3 stage's bank conflicts)
-   constexpr bool FMJ = RMH_FACE_MAJOR && NB > 1;
    constexpr bool HX = (RMH_HIER & 1) != 0, HY = (RMH_HIER & 2) != 0, HZ = (RMH_HIER & 4) != 0; // hierarchical directions of the mesh nodes
-   constexpr int NFR = (NB * 6 * Q + NT - 1) / NT;
    double fgc[NFR][3 * Q];
    {
 #pragma unroll
       for (int jp = 0; jp < NFR; jp++)
       {
          const int fr = min(frt + jp * NT, NB * 6 * Q - 1);
-         const int feb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q), frow = FMJ ? (fr / (NB * Q)) * Q + fr % Q : fr % (6 * Q);
-         const double *fg = a.fgeo + (size_t)min(e0 + feb, a.e_end - 1) * FaceGeo<P>::PER_ELEM + frow;
+         // (the block of this row's face: the element's own, or the face neighbour's with the sign flipped -- FaceGeo)
+         const double *fg = a.fgeo + (size_t)(fri[jp] & ~RMH_FACE_FLIP) * FaceGeo<P>::SLOT + fr % Q;
          // (a static mesh -- transport -- has c1 = c2 = 0: their loads are pointed at the c0 row, which is in the cache anyway, and
          // the face rows multiply them by zero; straight-line loads either way: a.move is uniform over the launch)
          // (+3.8 % for transport at p = 3, remap +-0; not at p >= 4, where the extra scalar arithmetic of the 21-27 loads costs remap 0.4-0.7 %)
          const int mv = (a.move || P >= 4) ? 1 : 0;
 #pragma unroll
-         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[(k - (1 - mv) * (k % 3)) * 6 * Q]; }
+         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[(k - (1 - mv) * (k % 3)) * Q]; }
       }
    }
    // diagnostic: the largest iteration count so far, read here -- behind the element loads, a uniform load whose
@@ -1356,12 +1401,13 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       double tq[D], tq2[D];
 #pragma unroll
       for (int k2 = 0; k2 < D; k2++) { tq[k2] = 0.0; tq2[k2] = 0.0; }
+      const double upw_row = (fri[jp] < 0) ? -a.upw : a.upw; // (the neighbour's block of this face: opposite normal, FaceGeo)
 #pragma unroll
       for (int q2 = 0; q2 < Q; q2++)
       {
          tabp gt = RMH_TABK();
          // w_q1 w_q2 max(0, upw * v.n_out) at time t: the face speed is a quadratic in t (face_geom_kernel)
-         const double sq = fmax(0.0, a.upw * (fgc[jp][3 * q2] + t_move * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
+         const double sq = fmax(0.0, upw_row * (fgc[jp][3 * q2] + t_move * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
          double jump = 0.0;
 #pragma unroll
          for (int i2 = 0; i2 < D; i2++) { jump += gt[oB + q2 * D + i2] * jr[i2]; }
@@ -1470,15 +1516,23 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       constexpr bool ZS = decltype(zs_)::value;
       constexpr int NQ = ZS ? Q / 3 : Q;
       const int zo1 = ZS ? zt * NQ : 0, zo3 = 3 * zo1, zoD = D * zo1;
-      auto T3 = [&](tabp gt, int o, int qz, int i) { return ZS ? stab[o + qz * 3 + i + zo3] : gt[o + qz * 3 + i]; };
-      auto TD = [&](tabp gt, int o, int qz, int i) { return ZS ? stab[o + qz * D + i + zoD] : gt[o + qz * D + i]; };
-      auto T1 = [&](tabp gt, int o, int qz) { return ZS ? stab[o + qz + zo1] : gt[o + qz]; };
+      // (split form: one opaque base per kind of table row -- the lane part zt is in it, the offsets that remain are the table's)
+      const int sto = (int)(stab - lds);
+      const double *z3 = (ZS && OPQ) ? lds + opaque_lds_offset(sto + zo3) : stab + zo3;
+      const double *zD = (ZS && OPQ) ? lds + opaque_lds_offset(sto + zoD) : stab + zoD;
+      const double *z1 = (ZS && OPQ) ? lds + opaque_lds_offset(sto + zo1) : stab + zo1;
+      auto T3 = [&](tabp gt, int o, int qz, int i) { return ZS ? z3[o + qz * 3 + i] : gt[o + qz * 3 + i]; };
+      auto TD = [&](tabp gt, int o, int qz, int i) { return ZS ? zD[o + qz * D + i] : gt[o + qz * D + i]; };
+      auto T1 = [&](tabp gt, int o, int qz) { return ZS ? z1[o + qz] : gt[o + qz]; };
+      // (RMH_OPAQUE_BASE: row bases as opaque offsets, see opaque_lds_offset)
+      const double *tLy = OPQ ? lds + opaque_lds_offset((int)(stab - lds) + oL + qy * 3) : stab + oL + qy * 3;
+      const double *tLx = OPQ ? lds + opaque_lds_offset((int)(stab - lds) + oL + qx * 3) : stab + oL + qx * 3;
       double Ly[3], dLy[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) { Ly[k] = stab[oL + qy * 3 + k]; dLy[k] = stab[odL + qy * 3 + k]; }
+      for (int k = 0; k < 3; k++) { Ly[k] = tLy[k]; dLy[k] = tLy[odL - oL + k]; }
       double Lx[3], dLx[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) { Lx[k] = stab[oL + qx * 3 + k]; dLx[k] = stab[odL + qx * 3 + k]; }
+      for (int k = 0; k < 3; k++) { Lx[k] = tLx[k]; dLx[k] = tLx[odL - oL + k]; }
       const double wxy = stab[oW + qx] * stab[oW + qy];
       double Dq[3][NQ], wl[NQ];
       {
@@ -1586,13 +1640,17 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          else { wd[qz] = wl[qz]; }
       }
       // pass 2: grad u, D.grad u and the z-leg of the three test contractions
-      const double *U1 = RMH_W(ceb) + oU1;
+      const int u1o = (int)(RMH_W(ceb) - lds) + oU1 + qx * S2;
+      const double *U1b = OPQ ? lds + opaque_lds_offset(u1o) : lds + u1o;                // B.u row of qx
+      const double *U1g = OPQ ? lds + opaque_lds_offset(u1o + Q * S2) : lds + u1o + Q * S2; // G.u row of qx
+      const double *tBy = OPQ ? lds + opaque_lds_offset((int)(stab - lds) + oB + qy * D) : stab + oB + qy * D;
+      const double *tGy = OPQ ? lds + opaque_lds_offset((int)(stab - lds) + oG + qy * D) : stab + oG + qy * D;
       double By[D], Gy[D]; // (rows of qy for the u contractions: read behind the geometry pass, whose registers they would take)
 #pragma unroll
       for (int k = 0; k < D; k++)
       {
-         By[k] = stab[oB + qy * D + k];
-         Gy[k] = stab[oG + qy * D + k];
+         By[k] = tBy[k];
+         Gy[k] = tGy[k];
       }
       double UB[D], UG[D], UU[D];
 #pragma unroll
@@ -1602,8 +1660,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            const double ub = U1[(0 * Q + qx) * S2 + iy + D * iz];
-            const double ug = U1[(1 * Q + qx) * S2 + iy + D * iz];
+            const double ub = U1b[iy + D * iz];
+            const double ug = U1g[iy + D * iz];
             b0 += By[iy] * ug;
             b1 += Gy[iy] * ub;
             b2 += By[iy] * ub;
@@ -2270,7 +2328,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
             for (int qz = 0; qz < Q; qz++) { wq[qz] = wd[qz]; }
          }
-         const double *M1 = RMH_W(ceb) + oM1 + qx * S2;
+         const double *M1 = OPQ ? lds + opaque_lds_offset((int)(RMH_W(ceb) - lds) + oM1 + qx * S2) : RMH_W(ceb) + oM1 + qx * S2;
          double Y[D];
 #pragma unroll
          for (int iz = 0; iz < D; iz++)

@@ -777,28 +777,38 @@ std::string build_case(const CaseConfig &cfg, CaseData &out)
          }
       }
    }
-   // ---- halo-first element order ----------------------------------------------------------------
-   // Owned elements whose 27-stencil reaches a ghost come first (they form the shell of the box), so
+   // ---- element order ----------------------------------------------------------------------------
+   // Halo first: owned elements whose 27-stencil reaches a ghost come first (they form the shell of the box), so
    // that one stage can run as two element ranges: [ne_halo, ne) while the neighbour exchange is in
-   // flight, [0, ne_halo) after it.  Single-rank cases have no ghosts and keep the lattice order.
+   // flight, [0, ne_halo) after it.  Behind that, the lattice order (x, y, z) -- or, with cfg.tile_rows = T > 0, strips of
+   // T lattice rows in y with z running before y inside a strip: a stage kernel works on a few hundred consecutive elements
+   // per XCD at a time, and in that order they contain each other's y- AND z-neighbours (in lattice order the z-neighbour
+   // is a whole layer away, so its traces, extrema and the shared face-table block come from HBM a second time).
    out.ne_halo = 0;
-   if (out.ne_ghost > 0)
+   if (out.ne_ghost > 0 || cfg.tile_rows > 0)
    {
       std::vector<int> new_of_old(ne), old_of_new(ne);
       int nh = 0;
       std::vector<char> halo(ne, 0);
-      for (int e = 0; e < ne; e++)
+      if (out.ne_ghost > 0)
       {
-         for (int s = 0; s < 27; s++) { halo[e] = halo[e] || out.stencil27[(size_t)e * 27 + s] >= ne; }
-         nh += halo[e];
+         for (int e = 0; e < ne; e++)
+         {
+            for (int s = 0; s < 27; s++) { halo[e] = halo[e] || out.stencil27[(size_t)e * 27 + s] >= ne; }
+            nh += halo[e];
+         }
       }
-      int ih = 0, ii = nh;
-      for (int e = 0; e < ne; e++)
+      const int T = cfg.tile_rows > 0 ? cfg.tile_rows : 0;
+      auto key = [&](int e)
       {
-         const int k = halo[e] ? ih++ : ii++;
-         new_of_old[e] = k;
-         old_of_new[k] = e;
-      }
+         // (the order so far is the local lattice order: e = lx + nlx (ly + nly lz))
+         const long long lx = e % nlx, ly = (e / nlx) % nly, lz = e / (nlx * nly);
+         const long long pos = T ? lx + nlx * ((ly % T) + (long long)T * (lz + (long long)nlz * (ly / T))) : (long long)e;
+         return std::make_pair(halo[e] ? 0 : 1, pos);
+      };
+      for (int e = 0; e < ne; e++) { old_of_new[e] = e; }
+      std::sort(old_of_new.begin(), old_of_new.end(), [&](int a, int b) { return key(a) < key(b); });
+      for (int k = 0; k < ne; k++) { new_of_old[old_of_new[k]] = k; }
       out.ne_halo = nh;
       auto permute_rows = [&](auto &v, size_t w)
       {

@@ -27,6 +27,7 @@ struct CaseConfig
    // ghost records, RCCL send / recv to the own rank) runs for real and must reproduce the plain periodic run bit for
    // bit.  Needs a periodic mesh, one block in that direction and at least three elements across it.  0: off.
    int self_wrap = 0;
+   int tile_rows = 0; // element numbering: 0 lattice order; T > 0: y-strips of T rows, z before y inside a strip (rmh_driver.h)
 };
 
 // neighbour rank in the halo exchange: which owned elements it needs, which ghost slots it fills

@@ -47,7 +47,8 @@ struct HoArgs
    const double *subvel;   // [ne][3][D3] sub-mesh node velocity (lo 4) or null
    const double *subx0;    // [ne][3][D3] sub-mesh start positions (set up once by subcell_setup_kernel)
    const double *subvmid;  // [ne][3][P^3] subcell midpoint velocity = mean of the 8 corner values
-   const double *fgeo;     // [ne][Q][3][6 Q] face speed coefficients (face_geom_kernel, rmh_ho2.hpp)
+   const double *fgeo;     // [slots][Q][3][Q] face speed coefficients, one block per face (face_geom_kernel, rmh_ho2.hpp)
+   const int *face_rows;   // [ne][6] block of every element face in fgeo; bit 31: read with the sign flipped
    double *du;             // [ne][D3]
    double *m;              // [ne][D3] lumped mass
    double *xe_min, *xe_max; // [ne]
