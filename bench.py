@@ -176,7 +176,7 @@ def compact_line(out, detail_file="bench_detail.json"):
     line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                     "vs_baseline", "dtype", "data")}
     line["config"] = {"workload": _short_workload(c.get("workload")), "global_dofs": c.get("global_dofs"), "elements": c.get("elements"),
-                      "partition": c.get("partition"), "mass_solve": c.get("mass_solve"), "cg_iters": c.get("mass_cg_max_iters"),
+                      "partition": c.get("partition"), "tile_rows": c.get("tile_rows"), "mass_solve": c.get("mass_solve"), "cg_iters": c.get("mass_cg_max_iters"),
                       "dt": c.get("dt"), "final_mass": c.get("final_mass"), "max_value": c.get("max_value")}
     if c.get("stage_loop"):
         line["config"]["stage_loop"] = c["stage_loop"]
@@ -499,9 +499,9 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
     weak = args.scaling == "weak" and world > 1
     # weak scaling: one -rs block per rank -- the directions that carry two blocks are refined once more
     extra = tuple(1 if (weak and part[d] == 2) else 0 for d in range(3))
-    cfg = make_config(mesh, rs, order, problem, -1.0, 0.5, lo_type=lo, part=part, rank=rank, rs_extra=extra)
+    cfg = make_config(mesh, rs, order, problem, -1.0, 0.5, lo_type=lo, part=part, rank=rank, rs_extra=extra, tile_rows=args.tile)
     t0 = time.perf_counter()
-    key = (mesh, rs, order, problem, lo, part, rank, extra)
+    key = (mesh, rs, order, problem, lo, part, rank, extra, args.tile)
     if key not in _CASES:  # (host-side case set-up, 3-4 s at -rs 5: shared by the blocks of one run)
         _CASES.clear()
         _CASES[key] = Case(lib, cfg)
@@ -611,6 +611,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
             "elements": ne_global,
             "dofs_per_gpu": ne_owned * ndof,
             "partition": "x".join(str(k) for k in part),
+            "tile_rows": args.tile,
             "limiter": "reference call sequence" if args.unfused else ("inside the stage kernel" if one_kernel else "fused (LO avg + bounds + ClipScale + RK update)"),
             "dt": dt,
             "dt_rule": "-dt -1: 0.25 h / |v| (remhos.cpp:538-553)" + (f" x {dt_scale:.6g}" if dt_scale != 1.0 else ""),
@@ -783,7 +784,8 @@ def measure_cpp_loop(args, lib, world, rank, device, comm_file):
     if args.mass_solve not in ("pa", "exact"):
         raise SystemExit("--gpus N > 1 runs the C++ loop: --mass-solve pa or exact")
     cfg = make_config(args.mesh, args.rs, args.order, args.problem, -1.0, 0.5, max_steps=args.warmup + args.steps, lo_type=args.lo,
-                      part=part, rank=rank, rs_extra=extra, pa=1 if args.mass_solve == "pa" else 0, warmup_steps=args.warmup)
+                      part=part, rank=rank, rs_extra=extra, pa=1 if args.mass_solve == "pa" else 0, warmup_steps=args.warmup,
+                      tile_rows=args.tile)
     res = RmhdResult()
     t0 = time.perf_counter()
     rc = lib.rmhd_run_partitioned(C.byref(cfg), comm_file.encode() if comm_file else None, device, C.byref(res))
@@ -807,7 +809,7 @@ def measure_cpp_loop(args, lib, world, rank, device, comm_file):
                         + (" (BASELINE configs[3])" if (args.mesh, order, args.problem, args.lo) == ("periodic-cube", 3, 10, 5) else "")
                         + f"; {ne_global} hex, {res.global_dofs} dofs",
             "global_dofs": res.global_dofs, "elements": ne_global, "dofs_per_gpu": res.global_dofs // world,
-            "partition": "x".join(str(k) for k in part), "limiter": "inside the stage kernel", "dt": res.dt,
+            "partition": "x".join(str(k) for k in part), "tile_rows": args.tile, "limiter": "inside the stage kernel", "dt": res.dt,
             "mass_cg_max_iters": res.cg_iters_max, "mass_solve": args.mass_solve, "mass_tol": mass_tol,
             "final_mass": res.final_mass, "max_value": res.max_value, "mass_loss": res.mass_loss,
             "stage_loop": "C++ (rmhd_run_partitioned)", "setup_and_run_s": total_s,
@@ -820,7 +822,9 @@ def measure_cpp_loop(args, lib, world, rank, device, comm_file):
             "alg_bytes_per_launch": ho_bytes,
             "achieved_is": "ALGORITHMIC bytes of SURVEY 8(d) (matrix-free model) per GPU and stage / stage kernel time (max over ranks)",
         },
-        "fom_reference_style": {"rhs_plus_inv": res.fom_rhs, "total_rhs_lo_fct": res.fom},
+        # (the bucket FOMs of the C++ loop are SAMPLED: events around every timer_every-th step, scaled; `value` is the exact wall clock)
+        "fom_reference_style": {"rhs_plus_inv": res.fom_rhs, "total_rhs_lo_fct": res.fom, "sampled_every_nth_step": res.timer_every,
+                                "sampled_steps": res.timer_steps},
         "exchange": {
             "transport": {1: "RCCL grouped ncclSend/ncclRecv inside the library (rmh_exchange_begin/_end), exchange stream with priority",
                           2: "same-process device copies (all blocks on one GPU: validation mode)"}.get(res.transport, "none"),
@@ -862,6 +866,10 @@ def main():
     ap.add_argument("--no-smi", action="store_true", help=argparse.SUPPRESS)  # (accepted for old recipes: sampling is opt-in now)
     ap.add_argument("--sustained-steps", type=int, default=200)
     ap.add_argument("--two-kernels", action="store_true", help="HO kernel + fused limiter kernel instead of the one-kernel stage")
+    ap.add_argument("--tile", type=int, default=0,
+                    help="element numbering of the case builder (rmhd_config.tile_rows): y-strips of this many lattice rows, z before y "
+                         "inside a strip; 0 = lattice order (default).  The same mesh and results element for element.  Measured "
+                         "(profiles/r05_face_table.txt): 4 rows cut the stage kernel's HBM reads by 12 %% and cost 2.7 %% of its rate")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="N > 1, weak scaling: do not also run the strong-scaling leg (the same -rs mesh partitioned, BASELINE configs[3])")
     ap.add_argument("--py-loop", action="store_true",

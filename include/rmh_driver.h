@@ -112,6 +112,10 @@ typedef struct {
     * reference, problem 0 on the periodic meshes against u0(x - v t) wrapped into the box; has_errors = 0 otherwise */
    int has_errors, pad2_;
    double err_l1, err_l2, err_linf;
+   /* rmhd_run_partitioned: the TimingData buckets above (t_rhs ... fom) are SAMPLED there -- HIP events around the launches of
+    * every timer_every-th step only (RMH_DRIVER_TIMERS, default 4; events around every launch cost small blocks 8 %), scaled by
+    * steps / timer_steps; wall and fom_wall are exact.  0 / 0: every step is timed (rmhd_run, rmhd_run_rank). */
+   int timer_every, timer_steps;
 } rmhd_result;
 
 /* remhos() on one GPU (px = py = pz = 1): setup, time loop (RK3 SSP, or the IDP solvers -s 11 / 12 / 13; with -ps

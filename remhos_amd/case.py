@@ -50,6 +50,7 @@ class RmhdResult(C.Structure):
         ("send_bytes_per_stage", C.c_longlong), ("recv_bytes_per_stage", C.c_longlong),
         ("final_mass_us", C.c_double), ("mass0_us", C.c_double), ("mass_loss_us", C.c_double), ("s_max", C.c_double),
         ("has_errors", C.c_int), ("pad2_", C.c_int), ("err_l1", C.c_double), ("err_l2", C.c_double), ("err_linf", C.c_double),
+        ("timer_every", C.c_int), ("timer_steps", C.c_int),
     ]
 
 

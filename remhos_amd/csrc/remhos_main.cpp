@@ -90,6 +90,7 @@ int main(int argc, char **argv)
                "Total kernel time: %.8g\n---\n", r.t_rhs, r.t_inv, r.t_lo, r.t_fct, r.t_total);
    std::printf("FOM RHS: %.8g\nFOM INV: %.8g\nFOM LO:  %.8g\nFOM FCT: %.8g\nFOM:     %.8g\n"
                "(megadofs x time steps / second)\n---\n", r.fom_rhs, r.fom_inv, r.fom_lo, r.fom_fct, r.fom);
+   if (r.timer_every > 0) { std::printf("(kernel times and FOMs above: sampled on %d of the timed steps, every %d-th, and scaled; the wall-clock FOM below is exact)\n", r.timer_steps, r.timer_every); }
    std::printf("FOM wall (everything included): %.8g\nmax local PCG iterations: %d\n", r.fom_wall, r.cg_iters_max);
    std::printf("Final mass u:  %.10g\nMax value u:   %.10g\nMass loss u:   %.6g\n", r.final_mass, r.max_value, r.mass_loss);
    if (r.has_errors) { std::printf("L1-error: %.10g. (L2 %.10g, Linf %.10g)\n", r.err_l1, r.err_l2, r.err_linf); } // remhos.cpp:1441-1442

@@ -1189,6 +1189,8 @@ extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_
    tk = reduce(tk, 2); // MPI_Reduce MAX of the stopwatches, remhos.cpp:1934
    if (reduce_failed) { g_driver_error = std::string("rmh_allreduce: ") + rmh_last_error(); cleanup(); return -1; }
    std::memset(res, 0, sizeof(*res));
+   res->timer_every = timer_every;
+   res->timer_steps = timed_steps;
    res->final_mass = mass;
    res->max_value = umax;
    res->mass0 = mass0;

@@ -1,0 +1,52 @@
+"""rmhd_config.tile_rows on the MI355X: the stage kernels give the same field bit for bit whatever the element numbering
+(tests/test_tile_order.py has the host side and the emulated kernels), also through the C++ loops and with the halo first."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+
+    assert torch.cuda.is_available()
+    from remhos_amd.capi import load_library
+    from remhos_amd.case import bind_driver
+
+    return bind_driver(load_library())
+
+
+@pytest.mark.parametrize("mesh,rs,p,prob,lo,T", [("periodic-cube", 2, 3, 10, 5, 4), ("periodic-cube", 1, 6, 10, 5, 2), ("cube01_hex", 2, 4, 10, 5, 3),
+                                                 ("periodic-cube", 2, 3, 10, 4, 4), ("periodic-cube", 2, 2, 0, 5, 5), ("cube01_hex", 2, 3, 10, 3, 2)])
+def test_tiled_run_is_bit_identical(lib, mesh, rs, p, prob, lo, T):
+    from tests.test_tile_order import run_steps
+
+    u0, _ = run_steps(lib, "cuda:0", mesh, rs, p, prob, lo, 0, 3)
+    u1, _ = run_steps(lib, "cuda:0", mesh, rs, p, prob, lo, T, 3)
+    assert np.array_equal(u0, u1)
+
+
+def test_tiled_selfloop_keeps_halo_first(lib):
+    from tests.test_tile_order import run_steps
+
+    u0, nh0 = run_steps(lib, "cuda:0", "periodic-cube", 2, 3, 10, 5, 0, 2, self_wrap=1)
+    u1, nh1 = run_steps(lib, "cuda:0", "periodic-cube", 2, 3, 10, 5, 4, 2, self_wrap=1)
+    assert nh0 == nh1 > 0 and np.array_equal(u0, u1)
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_tiled_driver_run_reports_the_same_numbers(lib, fused):
+    """rmhd_run (the solver classes / the one-kernel stage) on the tiled numbering: same final mass and maximum"""
+    from remhos_amd.case import RmhdResult, make_config
+
+    out = []
+    for T in (0, 4):
+        cfg = make_config("cube01_hex", 2, 3, 10, -1.0, 0.5, max_steps=4, fused=fused, pa=1, tile_rows=T)
+        res = RmhdResult()
+        assert lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, lib.rmhd_last_error()
+        out.append((res.final_mass, res.max_value, res.steps))
+    assert out[0][2] == out[1][2] == 4
+    assert abs(out[0][0] - out[1][0]) <= 2e-15 * abs(out[0][0]) and out[0][1] == out[1][1]  # (the mass is a sum over elements: order of the terms)
