@@ -142,6 +142,13 @@ int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, int device, 
  * rmh_allreduce.  Fixed dt or -dtc 1; -lo 3|4|5.  0 on success. */
 int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_file, int device, rmhd_result *res);
 
+/* The rendezvous the two calls above use for the 128-byte ncclUniqueId (the reference gets its communicator from MPI_Init,
+ * remhos.cpp:217-220; here any launcher works): writer != 0 publishes `id` at `path` (written to a temporary and renamed, stamped
+ * with a magic and the launch tag -- $RMH_COMM_NONCE, else the parent pid); writer == 0 polls for up to two minutes for a record
+ * with the SAME tag that is fresh (a file left by an earlier launch on the same path is never taken) and copies it to `id`.
+ * 0 on success.  Exported so that the protocol can be exercised without a GPU (tests/test_id_file.py). */
+int rmhd_id_file_exchange(const char *path, int writer, char id[128]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "librmh_host.so")
 DRIVER_SYMBOLS = [
     "rmhd_case_create", "rmhd_case_destroy", "rmhd_last_error", "rmhd_case_get_info", "rmhd_case_x0",
     "rmhd_case_vel", "rmhd_case_u0", "rmhd_case_s0", "rmhd_case_subcell_vel", "rmhd_case_face_nbr", "rmhd_case_stencil27",
-    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_case_save", "rmhd_run", "rmhd_run_state", "rmhd_run_rank", "rmhd_run_partitioned",
+    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_case_save", "rmhd_run", "rmhd_run_state", "rmhd_run_rank", "rmhd_run_partitioned", "rmhd_id_file_exchange",
 ]
 
 
@@ -93,6 +93,7 @@ def bind_driver(lib: C.CDLL) -> C.CDLL:
         lib.rmhd_run_state.argtypes = [C.POINTER(RmhdConfig), C.POINTER(RmhdResult), p, p]
         lib.rmhd_run_rank.argtypes = [C.POINTER(RmhdConfig), C.c_char_p, C.c_int, C.POINTER(RmhdResult), p, p]
         lib.rmhd_run_partitioned.argtypes = [C.POINTER(RmhdConfig), C.c_char_p, C.c_int, C.POINTER(RmhdResult)]
+        lib.rmhd_id_file_exchange.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
     return lib
 
 

@@ -913,6 +913,13 @@ bool read_or_write_id(const char *path, bool writer, char id[128])
 }
 } // namespace
 
+extern "C" int rmhd_id_file_exchange(const char *path, int writer, char id[128])
+{
+   if (!path || !path[0] || !id) { g_driver_error = "rmhd_id_file_exchange: null argument"; return -1; }
+   if (!read_or_write_id(path, writer != 0, id)) { g_driver_error = std::string("rmhd_id_file_exchange: ") + (writer ? "cannot write " : "no fresh record of this launch at ") + path; return -1; }
+   return 0;
+}
+
 extern "C" int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_file, int device, rmhd_result *res)
 {
    if (!cfg || !res) { g_driver_error = "null argument"; return -1; }
