@@ -93,7 +93,8 @@ def bind_driver(lib: C.CDLL) -> C.CDLL:
         lib.rmhd_run_state.argtypes = [C.POINTER(RmhdConfig), C.POINTER(RmhdResult), p, p]
         lib.rmhd_run_rank.argtypes = [C.POINTER(RmhdConfig), C.c_char_p, C.c_int, C.POINTER(RmhdResult), p, p]
         lib.rmhd_run_partitioned.argtypes = [C.POINTER(RmhdConfig), C.c_char_p, C.c_int, C.POINTER(RmhdResult)]
-        lib.rmhd_id_file_exchange.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        if hasattr(lib, "rmhd_id_file_exchange"):  # (older development builds of the library lack it: tools/kbench.py A/B runs)
+            lib.rmhd_id_file_exchange.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
     return lib
 
 

@@ -169,10 +169,11 @@ struct K2Cfg : TabLayout<P>
    // (p = 4, round 4: four wavefronts per SIMD -- 128 VGPRs, 140 B/lane of scratch -- 20.8 k -> 17.4 k MDOFs*stage/s on cube01_hex -rs 5)
    // (lo 4 at p = 6, round 4: with the slim layout below the kernel's LDS admits a fifth workgroup per CU, i.e. 2.5 wavefronts per
    // SIMD; asking for 3 gives 168 VGPRs + 76 B/lane of scratch and 10.0 k instead of 11.7 k MDOFs*stage/s -- it stays at 2)
-#ifndef RMH_WAVES6_LO4
-#define RMH_WAVES6_LO4 2
-#endif
-   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : ((P == 6 && BOTH) ? RMH_WAVES6_LO4 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0)));
+   // (lo 4 stage at p = 6, round 5: 183 VGPRs, and the LDS admits 5 workgroups = 2.5 wavefronts per SIMD.  A launch bound of 3 is
+   // ignored as long as the compiler sees the 32 KB of static LDS -- it clamps the request to what the LDS admits, rounded down;
+   // with the work region as dynamic LDS the bound is honoured (168 VGPRs, 68 B/lane of scratch, five resident workgroups per CU)
+   // and the stage is 11 % SLOWER: 12.36 k -> 10.98 k MDOFs*stage/s.  It stays at 2, profiles/r05_lo4_split.txt.)
+   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0));
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
