@@ -31,7 +31,8 @@ refined once more in x (N = 2), x and y (N = 4), all three directions (N = 8: ex
 records.  Started without WORLD_SIZE, `--gpus N` launches its N ranks itself (torch.distributed.run as a child
 process, before anything in this process touches the GPU).
 
-The JSON line carries `roofline` for the dominant kernel (ho_kernel2<p, 1>, duration from HIP events
+The LAST stdout line is the record: one compact JSON line (< 6 KB, numbers and short labels only, `compact_line`); the full result with every
+explanatory string goes to bench_detail.json (DESIGN.md 5 explains each field).  The line carries `roofline` for the dominant kernel (ho_kernel2<p, 1>, duration from HIP events
 on the kernel's own stream inside the timed region) and `cpu_baseline` (the C++/OpenMP CPU port of
 oracle/ timed on the host cores on a bounded sample of the same workload; rank 0 at N = 1 only).
 """
@@ -69,7 +70,7 @@ def stage_alg_bytes_per_dof(p, lo=5):
     (SURVEY App. D): the sub-mesh velocities at the 3 p^3 subcell midpoints and at the 3 D^3 sub-mesh nodes (the
     instantaneous velocity field sampled there with the boundary zeroed, remhos.cpp:837-853 -- not the Q2 interpolant).
     NOT counted although the kernel reads them: the sub-mesh start positions (3 D^3: the Q2 map of the 27 nodes at i/p) and
-    the face speed table (3 Q * 6 Q doubles per element: a stored intermediate that replaces recomputation) -- they show
+    the face speed table (3 Q * Q doubles per FACE -- about 3 blocks per element on a periodic lattice -- a stored intermediate that replaces recomputation) -- they show
     in `traffic`, not in the model."""
     D = p + 1
     extra = (3 * p**3 + 3 * D**3) if lo == 4 else 0
