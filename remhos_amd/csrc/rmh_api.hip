@@ -97,7 +97,7 @@ template <int P>
 int create_tables(rmh_ctx *c)
 {
    std::vector<double> tab = make_tables<P>();
-   static_assert(TabLayout<P>::N2 <= RMH_TAB_STRIDE, "constant table too small");
+   static_assert(TabLayout<P>::N3 <= RMH_TAB_STRIDE, "constant table too small");
    RMH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), tab.data(), tab.size() * sizeof(double),
                              (size_t)P * RMH_TAB_STRIDE * sizeof(double), hipMemcpyHostToDevice));
    return upload(&c->d_tab, tab.data(), tab.size());

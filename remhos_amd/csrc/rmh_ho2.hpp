@@ -963,7 +963,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    double *s_wdl = stab + C::N2 + C::PART + C::STI; // [Q2 - 64][Q] w detJ of the split columns (p = 6)
 
    const int tid0 = threadIdx.x;
-   static_assert(C::N2 <= RMH_TAB_STRIDE, "constant table too small");
+   static_assert(C::N3 <= RMH_TAB_STRIDE, "constant table too small");
    constexpr int oB = C::oB, oG = C::oG, oL = C::oL, odL = C::odL, oW = C::oW, oBg = C::oBg, oBg2 = C::oBg2,
                  oCi = C::oCi;
 
@@ -1006,6 +1006,34 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #define RMH_OPAQUE_BASE (P >= 4)
 #endif
    constexpr bool OPQ = RMH_OPAQUE_BASE;
+   // transposed table rows where an output gathers a table column (TabLayoutQ::oBgT ...): from the order on at which the
+   // table is read through views (below that it sits in scalar registers whole, and more of it would spill)
+#ifndef RMH_TAB_TRANSPOSED
+#define RMH_TAB_TRANSPOSED (P >= RMH_VIEW_MINP)
+#endif
+   constexpr bool TT = RMH_TAB_TRANSPOSED;
+   // Outputs per table view in the pencil-type contractions (one output = one table row = one or two wide scalar loads).  With a
+   // view per output the row of output k + 1 was loaded into the registers of row k, i.e. behind its FMAs: a scalar-memory round
+   // trip per output with 4-9 FMAs in between (p = 5 back-transform: 18 exposed waits per task).  A group of rows loaded through
+   // one view arrives together; sized to ~24 doubles (48 scalar registers) in flight.  GD: rows of D entries, GQ: of Q, G2D: two rows of D.
+#ifndef RMH_VIEW_GROUP
+#define RMH_VIEW_GROUP ((P == 5) ? 16 : 24) // (p = 5: 16 +1.2 %, 24 +0.7 %; p = 4, 6: 24 best; 36 loses at p = 5, 6)
+#endif
+   constexpr int GD = (P >= RMH_VIEW_MINP && RMH_VIEW_GROUP / D > 1) ? RMH_VIEW_GROUP / D : 1;
+   constexpr int GQ = (P >= RMH_VIEW_MINP && RMH_VIEW_GROUP / Q > 1) ? RMH_VIEW_GROUP / Q : 1;
+   constexpr int G2D = (P >= RMH_VIEW_MINP && RMH_VIEW_GROUP / (2 * D) > 1) ? RMH_VIEW_GROUP / (2 * D) : 1;
+   // (the geometry pass of the column phase keeps its view per quadrature plane: a view per 2 or 3 planes -- 7 table entries each --
+   // made the compiler keep whole groups of planes in flight: p = 6 22.9 k -> 10.2 k, p = 5 24.4 k -> 20.8 k MDOFs*stage/s)
+   constexpr int G7 = 1;
+#ifndef RMH_FACE_VIEW_GROUP
+#define RMH_FACE_VIEW_GROUP 2 // (1 -> 2: p = 4, 5, 6 +0.7 ... +0.8 %)
+#endif
+   constexpr int GF = (P >= RMH_VIEW_MINP) ? RMH_FACE_VIEW_GROUP : 1;
+   // pencil phases that handle several tensors per task read all their inputs before the first store (y-leg, x-leg)
+#ifndef RMH_PRELOAD_LINES
+#define RMH_PRELOAD_LINES (NB == 1 && NT == 128) // (p = 6 +0.3 %; p = 4, 5 -0.3 ... -0.8 %: one wavefront per workgroup keeps the tensor-by-tensor order)
+#endif
+   constexpr bool PRE = RMH_PRELOAD_LINES;
    typedef tabp_t<P> tabp;
    tabp gtb = (tabp)c_tab[P]; // constant memory: compile-time indices become scalar loads
    tabp gt = gtb;
@@ -1033,10 +1061,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int j = 0; j < D; j++) { in[j] = src[j * sin_]; }
          double *dst = RMH_W(eb) + oout + bout;
          split_outputs<SPL, D>(wv, [&](auto klo, auto khi) {
+tabp gt = gtb;
 #pragma unroll
             for (int kk = klo; kk < khi; kk++)
             {
-               tabp gt = RMH_TABK();
+               if (((kk) - (klo)) % GD == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
                double acc = 0.0;
 #pragma unroll
                for (int j = 0; j < D; j++) { acc += gt[oT + kk * D + j] * in[j]; }
@@ -1261,10 +1290,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       for (int ix = 0; ix < D; ix++) { uu[ix] = src[ix]; }
       double *dst = RMH_W(eb) + oU1 + i2;
       split_outputs<SPL, Q>(wv, [&](auto qlo, auto qhi) {
+tabp gt = gtb;
 #pragma unroll
          for (int q = qlo; q < qhi; q++)
          {
-            tabp gt = RMH_TABK();
+            if (((q) - (qlo)) % G2D == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
             double ub = 0.0, ug = 0.0;
 #pragma unroll
             for (int ix = 0; ix < D; ix++)
@@ -1403,10 +1433,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #pragma unroll
       for (int k2 = 0; k2 < D; k2++) { tq[k2] = 0.0; tq2[k2] = 0.0; }
       const double upw_row = (fri[jp] < 0) ? -a.upw : a.upw; // (the neighbour's block of this face: opposite normal, FaceGeo)
+      tabp gt = gtb;
 #pragma unroll
       for (int q2 = 0; q2 < Q; q2++)
       {
-         tabp gt = RMH_TABK();
+         if (q2 % GF == 0) { gt = RMH_TABK(); } // (rows of B and Bg of GF quadrature points per view)
          // w_q1 w_q2 max(0, upw * v.n_out) at time t: the face speed is a quadratic in t (face_geom_kernel)
          const double sq = fmax(0.0, upw_row * (fgc[jp][3 * q2] + t_move * (fgc[jp][3 * q2 + 1] + a.t * fgc[jp][3 * q2 + 2])));
          double jump = 0.0;
@@ -1456,13 +1487,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int q1 = 0; q1 < Q; q1++) { in[q1] = F[q1 * D]; }
          double *tr = RMH_W(eb) + oNb + f * D2 + D * i2;
          split_outputs<SPL, D>(wv, [&](auto lo_, auto hi_) {
+tabp gt = gtb;
 #pragma unroll
             for (int i1 = lo_; i1 < hi_; i1++)
             {
-               tabp gt = RMH_TABK();
+               if (((i1) - (lo_)) % GQ == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
                double coef = 0.0;
 #pragma unroll
-               for (int q1 = 0; q1 < Q; q1++) { coef += gt[oB + q1 * D + i1] * in[q1]; }
+               for (int q1 = 0; q1 < Q; q1++) { coef += (TT ? gt[C::oBT + i1 * Q + q1] : gt[oB + q1 * D + i1]) * in[q1]; }
                tr[i1] = coef * tr[i1];
             }
          });
@@ -1570,11 +1602,12 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
                A[comp][0][az] = a0; A[comp][1][az] = a1; A[comp][2][az] = a2; A[comp][3][az] = a3;
             }
          }
+tabp gt = gtb;
 #pragma unroll
          for (int qz = 0; qz < NQ; qz++)
          {
             if (ZS) { sched_fence(); }
-            tabp gt = RMH_TABK();
+            if (qz % G7 == 0) { gt = RMH_TABK(); } // (geometry pass: 7 table entries per plane -- a view per group of planes)
             double J[3][3], v[3];
 #pragma unroll
             for (int comp = 0; comp < 3; comp++)
@@ -1757,25 +1790,42 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       if (rem >= Q * D) { continue; }
       const int q = rem / D, iz = rem % D;
       split_outputs<SPL, C::NR>(wv, [&](auto rlo, auto rhi) {
+      // (PRE: the inputs of ALL the tensors of this task are read before the first output is stored.  The compiler cannot tell
+      // that a tensor's stores leave the next tensor's line alone, and with the loads behind the stores the three tensors were
+      // three dependent LDS round trips per task; one-element workgroups only -- p <= 3 has no registers to spare here)
+      double inall[PRE ? C::NR : 1][Q];
+      if (PRE)
+      {
+#pragma unroll
+         for (int r = rlo; r < rhi; r++)
+         {
+            const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
+#pragma unroll
+            for (int jy = 0; jy < Q; jy++) { inall[PRE ? r : 0][jy] = R3[Q * jy * D]; }
+         }
+      }
 #pragma unroll
       for (int r = rlo; r < rhi; r++)
       {
          const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
          double in[Q];
 #pragma unroll
-         for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
+         for (int jy = 0; jy < Q; jy++) { in[jy] = PRE ? inall[PRE ? r : 0][jy] : R3[Q * jy * D]; }
          // [r][qx][iy + D*iz]; in place: [r][qx + Q*iy][iz], the first D entries of the line just read
          double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz;
          constexpr int dstr = C::INPLACE_Y ? Q * D : 1;
+tabp gt = gtb;
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            tabp gt = RMH_TABK();
+            if (((iy) - (0)) % GQ == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
             {
-               const double w = (r == 0) ? gt[(HAS_HO ? oBg : oB) + jy * D + iy] : (r == 2 ? gt[oBg2 + jy * D + iy] : gt[oB + jy * D + iy]);
+               // (TT: the output's table column from the transposed copy -- one wide scalar load instead of Q gathered entries)
+               const double w = TT ? ((r == 0) ? gt[(HAS_HO ? C::oBgT : C::oBT) + iy * Q + jy] : (r == 2 ? gt[C::oBg2T + iy * Q + jy] : gt[C::oBT + iy * Q + jy]))
+                                   : ((r == 0) ? gt[(HAS_HO ? oBg : oB) + jy * D + iy] : (r == 2 ? gt[oBg2 + jy * D + iy] : gt[oB + jy * D + iy]));
                acc += w * in[jy];
             }
             dst[iy * dstr] = acc;
@@ -1796,13 +1846,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          double in[Q];
 #pragma unroll
          for (int q1 = 0; q1 < Q; q1++) { in[q1] = F[q1 * D]; }
+tabp gt = gtb;
 #pragma unroll
          for (int k1 = 0; k1 < D; k1++)
          {
-            tabp gt = RMH_TABK();
+            if (((k1) - (0)) % GQ == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
             double acc = 0.0;
 #pragma unroll
-            for (int q1 = 0; q1 < Q; q1++) { acc += gt[oBg + q1 * D + k1] * in[q1]; }
+            for (int q1 = 0; q1 < Q; q1++) { acc += (TT ? gt[C::oBgT + k1 * Q + q1] : gt[oBg + q1 * D + k1]) * in[q1]; }
             F[k1 * D] = acc;
          }
       }
@@ -1834,26 +1885,36 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       {
          const int iy = k / D, iz = k % D;
          split_outputs<SPL, C::NR>(wv, [&](auto rlo, auto rhi) {
-#pragma unroll
-            for (int r = rlo; r < rhi; r++)
-            {
-               double *line = RMH_W(0) + oR2 + r * rs2 + Q * iy * D + iz;
-               double in[Q];
-#pragma unroll
-               for (int jx = 0; jx < Q; jx++) { in[jx] = line[jx * D]; }
+            double inx[PRE ? C::NR : 1][Q]; // (PRE: every tensor's line is read before the first output is stored, see the y-leg)
+            auto xleg_outputs = [&](const int r, double *line, const double (&in)[Q]) {
+               tabp gt = gtb;
 #pragma unroll
                for (int ix = 0; ix < D; ix++)
                {
-                  tabp gt = RMH_TABK();
+                  if (ix % GQ == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
                   double acc = 0.0;
 #pragma unroll
                   for (int jx = 0; jx < Q; jx++)
                   {
-                     const double w = (r == 0) ? gt[oBg + jx * D + ix] : (r == 2 ? gt[oBg2 + jx * D + ix] : gt[oB + jx * D + ix]);
+                     const double w = TT ? ((r == 0) ? gt[C::oBgT + ix * Q + jx] : (r == 2 ? gt[C::oBg2T + ix * Q + jx] : gt[C::oBT + ix * Q + jx]))
+                                         : ((r == 0) ? gt[oBg + jx * D + ix] : (r == 2 ? gt[oBg2 + jx * D + ix] : gt[oB + jx * D + ix]));
                      acc += w * in[jx];
                   }
                   line[ix * D] = acc;
                }
+            };
+#pragma unroll
+            for (int r = rlo; r < rhi; r++)
+            {
+               double *line = RMH_W(0) + oR2 + r * rs2 + Q * iy * D + iz;
+#pragma unroll
+               for (int jx = 0; jx < Q; jx++) { inx[PRE ? r : 0][jx] = line[jx * D]; }
+               if (!PRE) { xleg_outputs(r, line, inx[0]); }
+            }
+            if (PRE)
+            {
+#pragma unroll
+               for (int r = rlo; r < rhi; r++) { xleg_outputs(r, RMH_W(0) + oR2 + r * rs2 + Q * iy * D + iz, inx[PRE ? r : 0]); }
             }
          });
       }
@@ -2301,10 +2362,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int ix = 0; ix < D; ix++) { in[ix] = src[ix]; }
          double *dst = RMH_W(eb) + oM1 + i2;
          split_outputs<SPL, Q>(wv, [&](auto qlo, auto qhi) {
+tabp gt = gtb;
 #pragma unroll
             for (int q = qlo; q < qhi; q++)
             {
-               tabp gt = RMH_TABK();
+               if (((q) - (qlo)) % GD == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
                double acc = 0.0;
 #pragma unroll
                for (int ix = 0; ix < D; ix++) { acc += gt[oBg + q * D + ix] * in[ix]; }
@@ -2339,10 +2401,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
             for (int iy = 0; iy < D; iy++) { acc += Bgy[iy] * M1[iy + D * iz]; }
             Y[iz] = acc;
          }
+tabp gt = gtb;
 #pragma unroll
          for (int qz = 0; qz < Q; qz++)
          {
-            tabp gt = RMH_TABK();
+            if (((qz) - (0)) % GD == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
             double acc = 0.0;
 #pragma unroll
             for (int iz = 0; iz < D; iz++) { acc += gt[oBg + qz * D + iz] * Y[iz]; }
@@ -2368,13 +2431,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          for (int jy = 0; jy < Q; jy++) { in[jy] = R3[Q * jy * D]; }
          double *dst = RMH_W(eb) + oM1 + q * S2 + D * iz;
          split_outputs<SPL, D>(wv, [&](auto ylo, auto yhi) {
+tabp gt = gtb;
 #pragma unroll
             for (int iy = ylo; iy < yhi; iy++)
             {
-               tabp gt = RMH_TABK();
+               if (((iy) - (ylo)) % GQ == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
                double acc = 0.0;
 #pragma unroll
-               for (int jy = 0; jy < Q; jy++) { acc += gt[oBg + jy * D + iy] * in[jy]; }
+               for (int jy = 0; jy < Q; jy++) { acc += (TT ? gt[C::oBgT + iy * Q + jy] : gt[oBg + jy * D + iy]) * in[jy]; }
                dst[iy] = acc;
             }
          });

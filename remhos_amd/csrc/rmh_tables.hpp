@@ -35,7 +35,15 @@ struct TabLayoutQ
    static constexpr int oBgE = N;           // BgE[side*D+k] GL nodal basis at xi = 0 / 1
    static constexpr int oLcu = oBgE + 2 * D; // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
    static constexpr int oCf = oLcu + 3 * D; // Cf[i*D+k] = C[k][i]: GL-tested -> Bernstein-tested moments (phi^B_i = sum_k C[k][i] l_k)
-   static constexpr int N2 = oCf + D * D;   // extended table
+   static constexpr int N2 = oCf + D * D;   // extended table (what the kernels copy to LDS)
+   // Transposed copies for the contractions that form ONE output per table COLUMN (y-leg of the test tensors, y-back leg of the
+   // mass apply, q1-contraction of the face rows: sum over q of T[q*D+k] x[q] for fixed k).  With the q-major table each output
+   // gathers Q separate entries through scalar loads -- 2 x 4 s_load_dwordx2 and two exposed waits per output at p = 5; from
+   // the transposed rows it is one or two wide loads.  Constant-memory only: not part of the LDS copy.
+   static constexpr int oBgT = N2;            // BgT[k*Q+q]  = Bg[q*D+k]
+   static constexpr int oBT = oBgT + D * Q;   // BT[i*Q+q]   = B[q*D+i]
+   static constexpr int oBg2T = oBT + D * Q;  // Bg2T[k*Q+q] = Bg2[q*D+k]
+   static constexpr int N3 = oBg2T + D * Q;   // everything in constant memory / the global copy
 };
 // dim = 3: Q = p + 3 (order 2p + 2*3 - 1); dim = 2: Q = p + 2 (order 2p + 2*2 - 1) -- SURVEY A.2
 template <int P>
@@ -158,7 +166,7 @@ inline std::vector<double> make_tables_q()
 {
    using T = TabLayoutQ<P, NQ>;
    constexpr int D = T::D, Q = T::Q;
-   std::vector<double> tab(T::N2, 0.0);
+   std::vector<double> tab(T::N3, 0.0);
    std::vector<double> xq, wq, xg, wg;
    gauss_legendre_01(Q, xq, wq);
    gauss_legendre_01(D, xg, wg);
@@ -209,6 +217,15 @@ inline std::vector<double> make_tables_q()
    for (int i = 0; i < D; i++)
    {
       for (int k = 0; k < D; k++) { tab[T::oCi + i * D + k] = C[i * D + k]; }
+   }
+   for (int q = 0; q < Q; q++)
+   {
+      for (int k = 0; k < D; k++)
+      {
+         tab[T::oBgT + k * Q + q] = tab[T::oBg + q * D + k];
+         tab[T::oBT + k * Q + q] = tab[T::oB + q * D + k];
+         tab[T::oBg2T + k * Q + q] = tab[T::oBg2 + q * D + k];
+      }
    }
    return tab;
 }
