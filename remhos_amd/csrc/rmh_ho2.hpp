@@ -499,6 +499,15 @@ __device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double
 #pragma unroll
       for (int r = 0; r < C::DR; r++) { x += (tid + r * C::NT < C::D3) ? v[r] : 0.0; }
       x = wave_sum(x);
+      if (NW == 1)
+      {
+         // (p = 4, 5: the workgroup IS the wavefront -- the total goes from lane 63 to all lanes through two v_readlane, not
+         // through an LDS word and a barrier: the same bits, ~150 cycles less per reduction, eight reductions per stage)
+         const double tot1 = wave_bcast<63>(x);
+#pragma unroll
+         for (int r = 0; r < C::DR; r++) { out[r] = (tid + r * C::NT < C::D3) ? tot1 : 0.0; }
+         return;
+      }
       if ((tid & 63) == 63) { slot[tid >> 6] = x; }
       __syncthreads();
       double tot = slot[0];
@@ -642,6 +651,18 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
       }
       x = wave_sum(x);
       y = wave_sum(y);
+      if (NW == 1)
+      {
+         const double tv1 = wave_bcast<63>(x), tw1 = wave_bcast<63>(y); // (one wavefront: see batch_dot)
+#pragma unroll
+         for (int r = 0; r < C::DR; r++)
+         {
+            const bool in = tid + r * C::NT < C::D3;
+            outv[r] = in ? tv1 : 0.0;
+            outw[r] = in ? tw1 : 0.0;
+         }
+         return;
+      }
       if ((tid & 63) == 63) { slotv[tid >> 6] = x; slotw[tid >> 6] = y; }
       __syncthreads();
       double totv = slotv[0], totw = slotw[0];
@@ -739,6 +760,15 @@ __device__ inline void batch_dot_keep2(const int tid, const double (&v)[C::DR], 
       x = wave_sum(x);
       y = wave_sum(y);
       q = wave_sum(q);
+      if (NW == 1)
+      {
+         // (one wavefront: see batch_dot; lane 63 holds the totals and parks the two kept ones -- their readers are behind barriers)
+         if (tid == 63) { lds[C::oKeep] = y; lds[C::oKeep + 1] = q; }
+         const double tv1 = wave_bcast<63>(x);
+#pragma unroll
+         for (int r = 0; r < C::DR; r++) { outv[r] = (tid + r * C::NT < C::D3) ? tv1 : 0.0; }
+         return;
+      }
       if ((tid & 63) == 63) { sv[tid >> 6] = x; sw[tid >> 6] = y; sz[tid >> 6] = q; }
       __syncthreads();
       double totv = sv[0];
@@ -976,8 +1006,14 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    double gx0[NLX], gv[NLX], gu[NLU];
    int itmax = 0, cg_known = 0;
    int blk = blockIdx.x;
+#ifndef RMH_EARLY_EXIT
+   // (every launch uses exactly one workgroup per batch, rmh_api.hip.  No early exit for blockIdx.x >= nblk: the test made the
+   // kernel wait for e_begin / e_end -- a scalar round trip to the kernarg segment -- before it loaded any other argument; a
+   // surplus workgroup would only redo the last batch, every store is guarded by e < e_end)
+#else
    if (blk >= nblk) { return; }
    if (gridDim.x == (unsigned)nblk)
+#endif
    {
       // workgroups are handed to the 8 XCDs round-robin (blockIdx.x % 8): give every XCD -- every L2 -- one contiguous
       // eighth of the element batches, so that the x- and y-neighbours whose traces and extrema an element reads were
