@@ -1042,6 +1042,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #define RMH_OPAQUE_BASE (P >= 4)
 #endif
    constexpr bool OPQ = RMH_OPAQUE_BASE;
+#ifndef RMH_FACE_OPAQUE
+#define RMH_FACE_OPAQUE (P != 5) // (p = 4, 6 +0.4 %, lo 4 at p = 6 +0.6 %; p = 5 -0.4 %: 8 B/lane more scratch)
+#endif
+   constexpr bool FOPQ = OPQ && RMH_FACE_OPAQUE; // (the same in the face rows)
    // transposed table rows where an output gathers a table column (TabLayoutQ::oBgT ...): from the order on at which the
    // table is read through views (below that it sits in scalar registers whole, and more of it would spill)
 #ifndef RMH_TAB_TRANSPOSED
@@ -1455,14 +1459,16 @@ tabp gt = gtb;
       const int eb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q);
       const int f = FMJ ? fr / (NB * Q) : (fr % (6 * Q)) / Q, q1 = fr % Q;
       // traces: contraction of the jumps u_nbr - u_own along i1
-      const double *un = RMH_W(eb) + oNb + f * D2;
+      // (OPQ: the lane-dependent bases of the trace block, the table row and the output rows as opaque offsets, opaque_lds_offset)
+      const double *un = FOPQ ? lds + opaque_lds_offset((int)(RMH_W(eb) - lds) + oNb + f * D2) : RMH_W(eb) + oNb + f * D2;
+      const double *tb1 = FOPQ ? lds + opaque_lds_offset((int)(stab - lds) + oB + q1 * D) : stab + oB + q1 * D;
       double jr[D];
 #pragma unroll
       for (int i2 = 0; i2 < D; i2++)
       {
          double acc = 0.0;
 #pragma unroll
-         for (int i1 = 0; i1 < D; i1++) { acc += stab[oB + q1 * D + i1] * un[i1 + D * i2]; }
+         for (int i1 = 0; i1 < D; i1++) { acc += tb1[i1] * un[i1 + D * i2]; }
          jr[i2] = acc;
       }
       double tq[D], tq2[D];
@@ -1491,15 +1497,16 @@ tabp gt = gtb;
             for (int k2 = 0; k2 < D; k2++) { tq2[k2] += gt[oB + q2 * D + k2] * sq; }
          }
       }
+      double *frow_out = FOPQ ? lds + opaque_lds_offset((int)(RMH_W(eb) - lds) + (f * Q + q1) * D) : RMH_W(eb) + (f * Q + q1) * D;
       if (HAS_HO)
       {
 #pragma unroll
-         for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[oF + (f * Q + q1) * D + k2] = tq[k2]; }
+         for (int k2 = 0; k2 < D; k2++) { frow_out[oF + k2] = tq[k2]; }
       }
       if (LO4)
       {
 #pragma unroll
-         for (int k2 = 0; k2 < D; k2++) { RMH_W(eb)[C::oF2 + (f * Q + q1) * D + k2] = tq2[k2]; }
+         for (int k2 = 0; k2 < D; k2++) { frow_out[C::oF2 + k2] = tq2[k2]; }
       }
    }
    RMH_STAMP(26);
