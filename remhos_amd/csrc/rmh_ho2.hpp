@@ -1046,6 +1046,10 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 #define RMH_FACE_OPAQUE (P != 5) // (p = 4, 6 +0.4 %, lo 4 at p = 6 +0.6 %; p = 5 -0.4 %: 8 B/lane more scratch)
 #endif
    constexpr bool FOPQ = OPQ && RMH_FACE_OPAQUE; // (the same in the face rows)
+#ifndef RMH_UNIFORM_SCALARS
+#define RMH_UNIFORM_SCALARS 1
+#endif
+   constexpr bool UNI = NB == 1 && RMH_UNIFORM_SCALARS; // element scalars formed once per lane instead of once per dof round
    // transposed table rows where an output gathers a table column (TabLayoutQ::oBgT ...): from the order on at which the
    // table is read through views (below that it sits in scalar registers whole, and more of it would spill)
 #ifndef RMH_TAB_TRANSPOSED
@@ -2510,11 +2514,15 @@ tabp gt = gtb;
       }
       RMH_STAMP(8);
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // den = d.Ad
+      // (UNI -- one element per workgroup: every in-range round of every lane holds the same element scalars, round 0 is always in
+      // range; the quotient is formed once instead of once per round behind its own branch: the same value, DR - 1 dependent
+      // division chains less per use)
+      const double al_uni = UNI ? fdiv(nom[0], red[0]) : 0.0;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
          const bool ok = act[r] && red[r] > 0.0;
-         const double al = ok ? fdiv(nom[r], red[r]) : 0.0;
+         const double al = ok ? (UNI ? al_uni : fdiv(nom[r], red[r])) : 0.0;
          if (act[r] && !ok) { tol[r] = INFINITY; } // breakdown: freeze this element
          xg[r] += al * dd[r];
          rg[r] -= al * Ad[r];
@@ -2532,13 +2540,14 @@ tabp gt = gtb;
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // betanom = r.z
       RMH_STAMP(15);
       bool any = false;
+      const double be_uni = UNI ? fdiv(red[0], nom[0]) : 0.0;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
          const double z = rg[r] * dg[r];
          if (act[r])
          {
-            dd[r] = z + fdiv(red[r], nom[r]) * dd[r];
+            dd[r] = z + (UNI ? be_uni : fdiv(red[r], nom[r])) * dd[r];
             nom[r] = red[r];
             its[r]++;
          }
@@ -2707,13 +2716,15 @@ tabp gt = gtb;
       }
       if ((tid & 63) == 0 && itmax > cg_known) { atomicMax(L.cg_iters, itmax); }
       batch_dot2<C>(tid, tmp, red, mass, vol, lds, s_acc, ring);
+      double fix_uni = 0.0;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
          const int t = tid + r * NT;
          const double sb = (t < NB * D3) ? RMH_W(t / D3)[C::oKeep] : 0.0, ev = (t < NB * D3) ? RMH_W(t / D3)[C::oKeep + 1] : 1.0;
          const double rate = L.mass_fix ? sb : vol[r]; // integral of du_HO over the element
-         xg[r] += L.mass_fix ? fdiv(sb - vol[r], ev) : 0.0;
+         if (UNI) { if (r == 0) { fix_uni = fdiv(sb - vol[0], ev); } }
+         xg[r] += L.mass_fix ? ((UNI && t < NB * D3) ? fix_uni : fdiv(sb - vol[r], ev)) : 0.0;
          mass[r] += L.dt * rate;
          vol[r] = ev;
       }
@@ -2721,6 +2732,7 @@ tabp gt = gtb;
       RMH_STAMP(17);
       double fcl[DR], pos[DR], neg[DR];
       double dtc = INFINITY; // UpdateTimeStepEstimate(u, du_LO, u_min, u_max), remhos.cpp:1839-1842
+      const double ubar_uni = UNI ? fdiv(mass[0], vol[0]) : 0.0; // (element average: one division per element, see UNI in the PCG loop)
       const bool want_dt = L.dt_est != nullptr; // (uniform: without -dtc the candidates -- two IEEE divisions per dof -- are not formed)
       const double r_dt = fdiv_rcp(L.dt);
 #pragma unroll
@@ -2734,7 +2746,7 @@ tabp gt = gtb;
             const int bx = i % D, by = (i / D) % D, bz = i / D2;
             const int s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
             const double lo = RMH_W(eb)[C::oLim + s3], hi = RMH_W(eb)[C::oLim + 27 + s3];
-            const double ubar = fdiv(mass[r], vol[r]);
+            const double ubar = UNI ? ubar_uni : fdiv(mass[r], vol[r]);
             if (!BOTH) { dlo[r] = fdiv_by(ubar - uu[r], L.dt, r_dt); } // MassBasedAvg; with RD dlo is already there
             if (want_dt) { dtc = fmin(dtc, dt_candidate(uu[r], dlo[r], lo, hi)); }
             const double u_new_lo = uu[r] + L.dt * dlo[r];
@@ -2758,6 +2770,7 @@ tabp gt = gtb;
       batch_dot2<C>(tid, pos, neg, sumPos, sumNeg, lds, s_acc, ring);
       RMH_STAMP(19);
       double ynew[DR];
+      const double rden_uni = UNI ? fdiv_rcp((sumNeg[0] + sumPos[0] > eps) ? sumPos[0] : sumNeg[0]) : 0.0;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -2771,7 +2784,9 @@ tabp gt = gtb;
                // the two rescale branches (remhos_fct.cpp:523-532) exclude each other: one division, operands selected first
                const bool up = new_mass > eps, dn = new_mass < -eps;
                const double fpos = fmax(0.0, fc), fneg = fmin(0.0, fc);
-               const double q = fdiv(up ? fpos * sumNeg[r] : fneg * sumPos[r], up ? sumPos[r] : sumNeg[r]);
+               const double den = up ? sumPos[r] : sumNeg[r];
+               // (UNI: the denominator is an element sum -- its reciprocal is refined once per lane, fdiv_rcp / fdiv_by = fdiv bit for bit)
+               const double q = UNI ? fdiv_by(up ? fpos * sumNeg[r] : fneg * sumPos[r], den, rden_uni) : fdiv(up ? fpos * sumNeg[r] : fneg * sumPos[r], den);
                if (up) { fc = fneg - q; }
                else if (dn) { fc = fpos - q; }
             }
