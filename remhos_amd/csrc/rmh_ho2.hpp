@@ -2226,6 +2226,7 @@ tabp gt = gtb;
       }
       if (!WD) { __syncthreads(); }
       RMH_STAMP(30);
+      double rd_auxP = 0, rd_invP = 0, rd_auxN = 0, rd_invN = 0, rd_rWP = 0, rd_rWN = 0; // (element scalars of the weights, see UNI below)
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -2291,14 +2292,24 @@ tabp gt = gtb;
             }
             const double sumWeightsP = D3 * xe_max - xSum[r] + eps;
             const double sumWeightsN = D3 * xe_min - xSum[r] - eps;
-            double weightP = fdiv(xe_max - ui, sumWeightsP);
-            double weightN = fdiv(xe_min - ui, sumWeightsN);
-            double aux = fdiv(gamma, rhoP[r] + eps);
+            // (UNI: four of the seven divisions of a dof have element sums on both sides, two more an element sum below the line --
+            // formed, or their reciprocal refined, once per lane instead of once per dof round; the same bits)
+            if (!UNI || r == 0)
+            {
+               rd_auxP = fdiv(gamma, rhoP[r] + eps);
+               rd_invP = fdiv(1., sumFluctP + eps);
+               rd_auxN = fdiv(gamma, rhoN[r] - eps);
+               rd_invN = fdiv(1., sumFluctN - eps);
+               if (UNI) { rd_rWP = fdiv_rcp(sumWeightsP); rd_rWN = fdiv_rcp(sumWeightsN); }
+            }
+            double weightP = UNI ? fdiv_by(xe_max - ui, sumWeightsP, rd_rWP) : fdiv(xe_max - ui, sumWeightsP);
+            double weightN = UNI ? fdiv_by(xe_min - ui, sumWeightsN, rd_rWN) : fdiv(xe_min - ui, sumWeightsN);
+            double aux = rd_auxP;
             weightP *= 1. - fmin(aux * sumFluctP, 1.);
-            weightP += fmin(aux, fdiv(1., sumFluctP + eps)) * nwP;
-            aux = fdiv(gamma, rhoN[r] - eps);
+            weightP += fmin(aux, rd_invP) * nwP;
+            aux = rd_auxN;
             weightN *= 1. - fmin(aux * sumFluctN, 1.);
-            weightN += fmax(aux, fdiv(1., sumFluctN - eps)) * nwN;
+            weightN += fmax(aux, rd_invN) * nwN;
             const double duf = RMH_W(eb)[C::oDuf + i];
             dlo[r] = fdiv(duf + weightP * rhoP[r] + weightN * rhoN[r], mm[r]);
             if (!BOTH && e0 + eb < a.e_end)
@@ -2665,11 +2676,12 @@ tabp gt = gtb;
 #pragma unroll
          for (int r = 0; r < DR; r++) { tmp[r] = mm[r] * xg[r]; }
          batch_dot<C>(tid, tmp, red, lds, s_acc, ring);
+         const double fix0_uni = UNI ? fdiv(RMH_W(0)[C::oKeep] - red[0], RMH_W(0)[C::oKeep + 1]) : 0.0; // (see UNI in the PCG loop)
 #pragma unroll
          for (int r = 0; r < DR; r++)
          {
             const int t = tid + r * NT;
-            if (t < NB * D3) { xg[r] += fdiv(RMH_W(t / D3)[C::oKeep] - red[r], RMH_W(t / D3)[C::oKeep + 1]); }
+            if (t < NB * D3) { xg[r] += UNI ? fix0_uni : fdiv(RMH_W(t / D3)[C::oKeep] - red[r], RMH_W(t / D3)[C::oKeep + 1]); }
          }
       }
 #pragma unroll
