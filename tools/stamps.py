@@ -34,6 +34,6 @@ lib.rmh_debug_stamps(buf, 0)
 names = {10: "I: sA write+barrier+flag", 11: "I: x-leg", 12: "I: column", 13: "I: y-back", 14: "I: dot1+update", 15: "I: dot2", 0: "A loads", 1: "B T1+U1 pencils", 2: "B face rows", 3: "C column", 4: "F y-leg", 5: "G dof x-leg+faces", 6: "I PCG total(excl. split)", 7: "J back+stores", 8: "I: x-back", 9: "I: tail update/loop", 16: "J: back-transform", 21: "K: stencil -> LDS", 22: "K: mass dot", 17: "K: vol dot", 18: "K: bounds + clip", 19: "K: pos/neg dots", 20: "K: scale + stores", 7: "K: extrema + end", 24: "B: subcell pass", 25: "B: traces -> LDS + barrier", 26: "B: face rows (only)", 27: "G: x-leg + faces (only)", 28: "G: z GL -> Bernstein", 29: "G: RD element sums", 30: "G: RD extrema + chunk sums", 31: "C: column pass (before the combine of split columns)"}
 tot = sum(buf[k] for k in range(32))
 nblk = 12 * ((st.case.ne_owned + nb - 1) // nb)
-for k in [k for k in range(32) if k in names and buf[k]]:
-    print(f"{names[k]:28s} {buf[k]/nblk:10.0f} cycles/WG  {100.0*buf[k]/tot:5.1f}%")
+for k in [k for k in range(32) if buf[k]]:
+    print(f"{names.get(k, 'stamp ' + str(k)):28s} {buf[k]/nblk:10.0f} cycles/WG  {100.0*buf[k]/tot:5.1f}%")
 print("total per WG", tot / nblk)
