@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -91,6 +92,20 @@ int upload(T **dst, const T *src, size_t n)
    RMH_HIP(hipMalloc((void **)dst, n * sizeof(T)));
    RMH_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
    return 0;
+}
+
+// Chunk of the XCD-aware batch order of ho_kernel2 for a launch of nblk batches of NB elements (HoArgs::xcd_chunk): the
+// batches of one lattice layer, adjusted so that whole rounds of 8 chunks cover the launch as evenly as possible; 0 (contiguous
+// eighths) where the element numbering shows no layers, or a layer is too small for the x / y neighbours to stay inside a chunk.
+static int xcd_chunk_for(const rmh_ctx *c, int nblk, int NB)
+{
+   if (c->xcd_chunk_env >= 0) { return c->xcd_chunk_env; }
+   if (c->layer_stride <= 0) { return 0; }
+   const double layer = (double)c->layer_stride / NB;
+   const int q8 = nblk >> 3;
+   const int rounds = (int)(q8 / layer + 0.5);
+   if (rounds < 2 || layer < 256.0) { return 0; }
+   return q8 / rounds;
 }
 
 template <int P>
@@ -176,6 +191,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.fgeo = c->d_fgeo;
          a.face_rows = c->d_face_rows;
       }
+      a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB);
       hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
    else
@@ -187,6 +203,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.fgeo = c->d_fgeo;
          a.face_rows = c->d_face_rows;
       }
+      a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB);
       hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
@@ -250,6 +267,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P4, true, true>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
+      a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB);
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P4>(c)) { return rc; }
@@ -263,6 +281,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
+      a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB);
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
@@ -533,6 +552,20 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
             if (L->stencil27[(size_t)e * nst + k] >= c->ne) { c->ghost_readers_end = e + 1; break; }
          }
       }
+   }
+   if (c->dim == 3)
+   {
+      // the usual distance of an element to its +z neighbour (lattice numberings: the elements of one layer), for xcd_chunk_for
+      std::unordered_map<int, int> hist;
+      for (int e = 0; e < c->ne; e++)
+      {
+         const int nb = L->face_nbr[(size_t)e * 6 + 5];
+         if (nb > e && nb < c->ne) { hist[nb - e]++; }
+      }
+      int best = 0, cnt = 0;
+      for (const auto &kv : hist) { if (kv.second > cnt || (kv.second == cnt && kv.first < best)) { best = kv.first; cnt = kv.second; } }
+      c->layer_stride = 2 * (long long)cnt > c->ne ? best : 0; // (only where most elements agree)
+      if (const char *s = std::getenv("RMH_XCD_CHUNK")) { c->xcd_chunk_env = std::max(0, std::atoi(s)); }
    }
    // every failure past this point releases the context and whatever it already owns
    const int rc = c->dim == 3 ? create_device_state(c, L) : create_device_state_2d(c, L);

@@ -1019,7 +1019,23 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       // eighth of the element batches, so that the x- and y-neighbours whose traces and extrema an element reads were
       // touched by workgroups of the same XCD a few batches earlier (p = 3: HBM traffic per launch 3.71 -> 2.50 GB)
       const int xcd = blk & 7, j8 = blk >> 3, q8 = nblk >> 3, r8 = nblk & 7;
-      blk = xcd * q8 + min(xcd, r8) + j8;
+      // On a lattice (a.xcd_chunk = the batches of one z-layer) the eighths are cut into layers dealt round-robin: XCD k works
+      // on layer 8 r + k in round r, so the +-z neighbours of its elements are in flight on XCD k +- 1 at the same time and the
+      // second reader of a shared face-speed block / trace / extremum finds it in the Infinity Cache instead of HBM -- inside
+      // a contiguous eighth it comes a whole layer (~55 MB of traffic at p = 3) later, far beyond the 4 MB L2.  Measured
+      // (profiles/r05_xcd_layers.txt): p = 3 +2 %, p = 6 +3 %.  The batches behind the last whole round keep contiguous eighths.
+      const int C_ = a.xcd_chunk;
+      if (C_ > 0 && q8 >= C_)
+      {
+         const int rounds = q8 / C_, jr = j8 / C_, covered = rounds * 8 * C_;
+         if (jr < rounds) { blk = jr * 8 * C_ + xcd * C_ + (j8 - jr * C_); }
+         else
+         {
+            const int nt = nblk - covered, qt = nt >> 3, rt = nt & 7;
+            blk = covered + xcd * qt + min(xcd, rt) + (j8 - rounds * C_);
+         }
+      }
+      else { blk = xcd * q8 + min(xcd, r8) + j8; }
    }
    const int e0 = a.e_begin + blk * NB;
    const int tid = tid0;

@@ -55,6 +55,7 @@ struct HoArgs
    int *cg_iters;          // [1] max over elements (atomicMax)
    int ne_owned;
    int e_begin, e_end;     // elements this launch works on (ho_kernel2; the whole rank: 0, ne_owned)
+   int xcd_chunk;          // batches per chunk of the XCD-aware batch order (ho_kernel2): chunks are dealt round-robin to the 8 XCDs; 0: one contiguous eighth each
    double t;               // pseudo-time (remap) -- X = x0 + t*vel
    int move;               // 1: remap (mesh moves), 0: transport (static mesh)
    double alpha;           // ConvectionIntegrator alpha: -1 transport, +1 remap (remhos.cpp:648-657)

@@ -375,3 +375,30 @@ def test_extrema_tokens(lib):
     ctx.stage_fused(y1, cfg.dt, ref)
     assert np.array_equal(ref, z2)
     ctx.close()
+
+
+@pytest.mark.parametrize("p,rs,chunks", [(4, 0, (1, 2, 3)), (3, 1, (1, 2))])
+def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, p, rs, chunks, monkeypatch):
+    """The XCD-aware batch order of the stage kernel (ho_kernel2: blockIdx.x -> batch; HoArgs::xcd_chunk, chunks of a lattice
+    layer dealt round-robin to the 8 XCDs, the rest in contiguous eighths): every chunk size must visit every batch exactly
+    once -- the one-kernel stage then gives the same numbers bit by bit as with contiguous eighths (RMH_XCD_CHUNK = 0; that
+    order is the one every other test of this file runs against the oracle).  27 and 31 batches: whole rounds plus a tail."""
+    from remhos_amd.capi import Context
+
+    cfg = Config(mesh="periodic-cube", rs=rs, order=p, problem=10, dt=0.01, t_final=0.7, lo=5)
+    r = Remhos(cfg)
+    r.refine_steps = 2
+    x0, vel, nbr, st = layout_from_oracle(r)
+    u = perturbed(r.u)
+    out = {}
+    for chunk in (0,) + chunks:
+        monkeypatch.setenv("RMH_XCD_CHUNK", str(chunk))
+        ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
+        ctx.setup(0.3)
+        y, du = np.full_like(u, np.nan), np.full_like(u, np.nan)
+        ctx.stage_fused(u, cfg.dt, y, dt_rk=cfg.dt, du=du)
+        ctx.close()
+        out[chunk] = (y, du)
+    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    for chunk in chunks:
+        assert np.array_equal(out[chunk][0], out[0][0]) and np.array_equal(out[chunk][1], out[0][1]), chunk
