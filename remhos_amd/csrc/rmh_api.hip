@@ -7,6 +7,7 @@
 #include "rmh_2d.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -94,18 +95,31 @@ int upload(T **dst, const T *src, size_t n)
    return 0;
 }
 
-// Chunk of the XCD-aware batch order of ho_kernel2 for a launch of nblk batches of NB elements (HoArgs::xcd_chunk): the
-// batches of one lattice layer, adjusted so that whole rounds of 8 chunks cover the launch as evenly as possible; 0 (contiguous
-// eighths) where the element numbering shows no layers, or a layer is too small for the x / y neighbours to stay inside a chunk.
-static int xcd_chunk_for(const rmh_ctx *c, int nblk, int NB)
+// Chunk of the XCD-aware batch order of ho_kernel2 for a launch of nblk batches of NB elements (HoArgs::xcd_chunk, xcd_weave):
+// 2^weave lattice layers, woven batch by batch, so that +-z neighbours run at the same time -- inside one XCD (one L2) between
+// the woven layers, on the neighbouring XCD (through the Infinity Cache) at the chunk ends.  The layer is taken a little short
+// or long where that makes whole rounds of 8 chunks cover the launch.  0 (contiguous eighths) where the element numbering
+// shows no layers, a layer is too small to keep an XCD's workgroups inside it, or the launch holds less than one round.
+static int xcd_chunk_for(const rmh_ctx *c, int nblk, int NB, int *weave)
 {
-   if (c->xcd_chunk_env >= 0) { return c->xcd_chunk_env; }
+   *weave = 0;
+   if (c->xcd_chunk_env >= 0) { *weave = c->xcd_weave; return (c->xcd_chunk_env >> c->xcd_weave) << c->xcd_weave; }
    if (c->layer_stride <= 0) { return 0; }
    const double layer = (double)c->layer_stride / NB;
    const int q8 = nblk >> 3;
-   const int rounds = (int)(q8 / layer + 0.5);
-   if (rounds < 2 || layer < 256.0) { return 0; }
-   return q8 / rounds;
+   if (layer < 256.0 || q8 < 2 * layer) { return 0; }
+   for (int w = c->xcd_weave; w >= 0; w--)
+   {
+      const double chunk = layer * (1 << w);
+      const int rounds = (int)(q8 / chunk + 0.5);
+      if (rounds < 1) { continue; }
+      int sub = (int)((q8 / rounds) >> w);                                          // whole rounds cover the launch ...
+      if (std::fabs(sub - layer) > 0.005 * layer + 1.0) { sub = (int)(layer + 0.5); } // ... unless that bends the layer by more than 0.5 %
+      if (((long long)sub << w) > q8) { continue; }
+      *weave = w;
+      return sub << w;
+   }
+   return 0;
 }
 
 template <int P>
@@ -191,7 +205,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.fgeo = c->d_fgeo;
          a.face_rows = c->d_face_rows;
       }
-      a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB);
+      a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB, &a.xcd_weave);
       hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
    else
@@ -203,7 +217,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.fgeo = c->d_fgeo;
          a.face_rows = c->d_face_rows;
       }
-      a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB);
+      a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB, &a.xcd_weave);
       hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
@@ -267,7 +281,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P4, true, true>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
-      a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB);
+      a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB, &a.xcd_weave);
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P4>(c)) { return rc; }
@@ -281,7 +295,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       using C = K2Cfg<P>;
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
-      a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB);
+      a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB, &a.xcd_weave);
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
@@ -566,6 +580,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
       for (const auto &kv : hist) { if (kv.second > cnt || (kv.second == cnt && kv.first < best)) { best = kv.first; cnt = kv.second; } }
       c->layer_stride = 2 * (long long)cnt > c->ne ? best : 0; // (only where most elements agree)
       if (const char *s = std::getenv("RMH_XCD_CHUNK")) { c->xcd_chunk_env = std::max(0, std::atoi(s)); }
+      if (const char *s = std::getenv("RMH_XCD_WEAVE")) { c->xcd_weave = std::min(4, std::max(0, std::atoi(s))); }
    }
    // every failure past this point releases the context and whatever it already owns
    const int rc = c->dim == 3 ? create_device_state(c, L) : create_device_state_2d(c, L);

@@ -1028,7 +1028,11 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       if (C_ > 0 && q8 >= C_)
       {
          const int rounds = q8 / C_, jr = j8 / C_, covered = rounds * 8 * C_;
-         if (jr < rounds) { blk = jr * 8 * C_ + xcd * C_ + (j8 - jr * C_); }
+         if (jr < rounds)
+         {
+            const int jj = j8 - jr * C_, w = a.xcd_weave;
+            blk = jr * 8 * C_ + xcd * C_ + (jj & ((1 << w) - 1)) * (C_ >> w) + (jj >> w); // (C_ is a multiple of 2^w)
+         }
          else
          {
             const int nt = nblk - covered, qt = nt >> 3, rt = nt & 7;

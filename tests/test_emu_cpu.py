@@ -377,11 +377,11 @@ def test_extrema_tokens(lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("p,rs,chunks", [(4, 0, (1, 2, 3)), (3, 1, (1, 2))])
+@pytest.mark.parametrize("p,rs,chunks", [(4, 0, ((1, 0), (2, 0), (3, 0), (2, 1))), (3, 1, ((1, 0), (2, 1)))])
 def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, p, rs, chunks, monkeypatch):
     """The XCD-aware batch order of the stage kernel (ho_kernel2: blockIdx.x -> batch; HoArgs::xcd_chunk, chunks of a lattice
-    layer dealt round-robin to the 8 XCDs, the rest in contiguous eighths): every chunk size must visit every batch exactly
-    once -- the one-kernel stage then gives the same numbers bit by bit as with contiguous eighths (RMH_XCD_CHUNK = 0; that
+    layer -- or of 2^weave layers woven batch by batch, xcd_weave -- dealt round-robin to the 8 XCDs, the rest in contiguous eighths):
+    every (chunk, weave) must visit every batch exactly once -- the one-kernel stage then gives the same numbers bit by bit as with contiguous eighths (RMH_XCD_CHUNK = 0; that
     order is the one every other test of this file runs against the oracle).  27 and 31 batches: whole rounds plus a tail."""
     from remhos_amd.capi import Context
 
@@ -391,14 +391,16 @@ def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, p, rs, chunks, mon
     x0, vel, nbr, st = layout_from_oracle(r)
     u = perturbed(r.u)
     out = {}
-    for chunk in (0,) + chunks:
-        monkeypatch.setenv("RMH_XCD_CHUNK", str(chunk))
+    for chunk in ((0, 0),) + chunks:
+        monkeypatch.setenv("RMH_XCD_CHUNK", str(chunk[0]))
+        monkeypatch.setenv("RMH_XCD_WEAVE", str(chunk[1]))
         ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
         ctx.setup(0.3)
         y, du = np.full_like(u, np.nan), np.full_like(u, np.nan)
         ctx.stage_fused(u, cfg.dt, y, dt_rk=cfg.dt, du=du)
         ctx.close()
         out[chunk] = (y, du)
-    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    ref = out[(0, 0)]
+    assert np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all()
     for chunk in chunks:
-        assert np.array_equal(out[chunk][0], out[0][0]) and np.array_equal(out[chunk][1], out[0][1]), chunk
+        assert np.array_equal(out[chunk][0], ref[0]) and np.array_equal(out[chunk][1], ref[1]), chunk

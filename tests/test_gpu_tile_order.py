@@ -50,3 +50,24 @@ def test_tiled_driver_run_reports_the_same_numbers(lib, fused):
         out.append((res.final_mass, res.max_value, res.steps))
     assert out[0][2] == out[1][2] == 4
     assert abs(out[0][0] - out[1][0]) <= 2e-15 * abs(out[0][0]) and out[0][1] == out[1][1]  # (the mass is a sum over elements: order of the terms)
+
+
+@pytest.mark.parametrize("mesh,rs,p,lo,self_wrap", [("periodic-cube", 4, 3, 5, 0), ("periodic-cube", 4, 3, 4, 0), ("periodic-cube", 3, 6, 5, 0),
+                                                   ("cube01_hex", 5, 4, 5, 0), ("periodic-cube", 4, 3, 5, 1)])
+def test_xcd_batch_order_is_bit_identical(lib, mesh, rs, p, lo, self_wrap, monkeypatch):
+    """The stage kernel's blockIdx -> batch map (HoArgs::xcd_chunk / xcd_weave: lattice layers woven and dealt round-robin to the
+    XCDs, chosen by xcd_chunk_for from the element numbering) against contiguous eighths (RMH_XCD_CHUNK=0) and against other
+    weaves, on meshes large enough for the layered order to be chosen (>= 256 batches per layer): same field bit for bit."""
+    from tests.test_tile_order import run_steps
+
+    out = []
+    for env in ({"RMH_XCD_CHUNK": "0"}, {}, {"RMH_XCD_WEAVE": "0"}, {"RMH_XCD_WEAVE": "2"}):
+        monkeypatch.delenv("RMH_XCD_CHUNK", raising=False)
+        monkeypatch.delenv("RMH_XCD_WEAVE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        u, _ = run_steps(lib, "cuda:0", mesh, rs, p, 10, lo, 0, 2, self_wrap=self_wrap)
+        assert np.isfinite(u).all()
+        out.append(u)
+    for u in out[1:]:
+        assert np.array_equal(out[0], u)
