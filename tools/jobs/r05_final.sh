@@ -3,6 +3,6 @@
 set -u
 export TMPDIR=/tmp
 o=gpurun_out/r05; mkdir -p $o
-bash tools/jobs/r05_profile.sh > $o/job23_profile.txt 2>&1; tail -2 $o/job23_profile.txt
-timeout 3000 python3 -m pytest tests -m gpu -q > $o/job23_pytest.txt 2>&1; grep -E "passed|failed" $o/job23_pytest.txt | tail -2
+bash tools/jobs/r05_profile.sh > $o/final_profile.txt 2>&1; tail -2 $o/final_profile.txt
+timeout 3000 python3 -m pytest tests -m gpu -q > $o/final_pytest.txt 2>&1; grep -E "passed|failed" $o/final_pytest.txt | tail -2
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -1
