@@ -206,6 +206,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.face_rows = c->d_face_rows;
       }
       a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB, &a.xcd_weave);
+      a.reverse = 0;
       hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
    else
@@ -218,6 +219,7 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.face_rows = c->d_face_rows;
       }
       a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB, &a.xcd_weave);
+      a.reverse = 0;
       hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
    RMH_HIP(hipGetLastError());
@@ -282,6 +284,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
       a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB, &a.xcd_weave);
+      a.reverse = c->alt_order ? (int)(c->xe_counter & 1) : 0;
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P4>(c)) { return rc; }
@@ -296,6 +299,7 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
       a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB, &a.xcd_weave);
+      a.reverse = c->alt_order ? (int)(c->xe_counter & 1) : 0;
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
          if (int rc = ensure_face_table<P>(c)) { return rc; }
@@ -580,6 +584,7 @@ int rmh_create(const rmh_layout *L, rmh_ctx **out)
       for (const auto &kv : hist) { if (kv.second > cnt || (kv.second == cnt && kv.first < best)) { best = kv.first; cnt = kv.second; } }
       c->layer_stride = 2 * (long long)cnt > c->ne ? best : 0; // (only where most elements agree)
       if (const char *s = std::getenv("RMH_XCD_CHUNK")) { c->xcd_chunk_env = std::max(0, std::atoi(s)); }
+      if (const char *s = std::getenv("RMH_ALT_ORDER")) { c->alt_order = std::atoi(s) != 0; }
       if (const char *s = std::getenv("RMH_XCD_WEAVE")) { c->xcd_weave = std::min(4, std::max(0, std::atoi(s))); }
    }
    // every failure past this point releases the context and whatever it already owns

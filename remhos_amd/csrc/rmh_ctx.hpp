@@ -61,6 +61,8 @@ struct rmh_ctx
                               // 0: no such structure -- the stage kernel then keeps contiguous eighths per XCD (xcd_chunk_for, rmh_api.hip)
    int xcd_chunk_env = -1;    // RMH_XCD_CHUNK: -1 unset; 0: contiguous eighths; n: chunks of n batches (experiments)
    int xcd_weave = 1;         // log2 of the layers woven into one chunk (HoArgs::xcd_weave); RMH_XCD_WEAVE overrides (experiments)
+   int alt_order = 1;         // every other stage launch walks its batches backwards: the end of the last stage's output -- this stage's input --
+                              // is what the L2s and the Infinity Cache still hold (p = 4, 5 +0.5 %, 48^3 meshes +2 %; RMH_ALT_ORDER=0 switches it off)
    int ghost_readers_end = 0; // 1 + the last owned element whose stencil reaches a ghost: ranges from here on read no ghost data
    bool gh_foreign = false; // ghost extrema overwritten by rmh_exchange_minmax_* (another field's) since the last exchange of u
    int gh_ustride = 0, gh_mstride = 1; // element strides of the ghost arrays (0: ndof)

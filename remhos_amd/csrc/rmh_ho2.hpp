@@ -1040,6 +1040,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
          }
       }
       else { blk = xcd * q8 + min(xcd, r8) + j8; }
+      if (a.reverse) { blk = nblk - 1 - blk; }
    }
    const int e0 = a.e_begin + blk * NB;
    const int tid = tid0;

@@ -377,15 +377,16 @@ def test_extrema_tokens(lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("p,rs,chunks", [(4, 0, ((1, 0), (2, 0), (3, 0), (2, 1))), (3, 1, ((1, 0), (2, 1)))])
-def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, p, rs, chunks, monkeypatch):
+@pytest.mark.parametrize("mesh,p,rs,chunks", [("periodic-cube", 4, 0, ((1, 0), (3, 0), (2, 1))), ("cube01_hex", 3, 1, ((1, 0),))])
+def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, mesh, p, rs, chunks, monkeypatch):
     """The XCD-aware batch order of the stage kernel (ho_kernel2: blockIdx.x -> batch; HoArgs::xcd_chunk, chunks of a lattice
     layer -- or of 2^weave layers woven batch by batch, xcd_weave -- dealt round-robin to the 8 XCDs, the rest in contiguous eighths):
     every (chunk, weave) must visit every batch exactly once -- the one-kernel stage then gives the same numbers bit by bit as with contiguous eighths (RMH_XCD_CHUNK = 0; that
-    order is the one every other test of this file runs against the oracle).  27 and 31 batches: whole rounds plus a tail."""
+    order is the one every other test of this file runs against the oracle).  27 one-element and 10 seven-element batches: whole
+    rounds plus a tail; the full-size twins are tests/test_gpu_tile_order.py."""
     from remhos_amd.capi import Context
 
-    cfg = Config(mesh="periodic-cube", rs=rs, order=p, problem=10, dt=0.01, t_final=0.7, lo=5)
+    cfg = Config(mesh=mesh, rs=rs, order=p, problem=10, dt=0.01, t_final=0.7, lo=5)
     r = Remhos(cfg)
     r.refine_steps = 2
     x0, vel, nbr, st = layout_from_oracle(r)
@@ -394,12 +395,16 @@ def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, p, rs, chunks, mon
     for chunk in ((0, 0),) + chunks:
         monkeypatch.setenv("RMH_XCD_CHUNK", str(chunk[0]))
         monkeypatch.setenv("RMH_XCD_WEAVE", str(chunk[1]))
+        monkeypatch.setenv("RMH_ALT_ORDER", "0" if chunk == (0, 0) else "1")
         ctx = Context(lib, order=p, exec_mode=1, x0=x0, vel=vel, face_nbr=nbr, stencil27=st)
         ctx.setup(0.3)
         y, du = np.full_like(u, np.nan), np.full_like(u, np.nan)
         ctx.stage_fused(u, cfg.dt, y, dt_rk=cfg.dt, du=du)
+        # (a second stage: with RMH_ALT_ORDER every other launch walks the batches backwards)
+        y2, du2 = np.full_like(u, np.nan), np.full_like(u, np.nan)
+        ctx.stage_fused(y, cfg.dt, y2, dt_rk=cfg.dt, du=du2)
         ctx.close()
-        out[chunk] = (y, du)
+        out[chunk] = (np.concatenate([y, y2]), np.concatenate([du, du2]))
     ref = out[(0, 0)]
     assert np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all()
     for chunk in chunks:

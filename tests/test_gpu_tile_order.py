@@ -57,13 +57,14 @@ def test_tiled_driver_run_reports_the_same_numbers(lib, fused):
 def test_xcd_batch_order_is_bit_identical(lib, mesh, rs, p, lo, self_wrap, monkeypatch):
     """The stage kernel's blockIdx -> batch map (HoArgs::xcd_chunk / xcd_weave: lattice layers woven and dealt round-robin to the
     XCDs, chosen by xcd_chunk_for from the element numbering) against contiguous eighths (RMH_XCD_CHUNK=0) and against other
-    weaves, on meshes large enough for the layered order to be chosen (>= 256 batches per layer): same field bit for bit."""
+    weaves, and with / without every other stage walking the batches backwards (RMH_ALT_ORDER), on meshes large enough for the
+    layered order to be chosen (>= 256 batches per layer): same field bit for bit."""
     from tests.test_tile_order import run_steps
 
     out = []
-    for env in ({"RMH_XCD_CHUNK": "0"}, {}, {"RMH_XCD_WEAVE": "0"}, {"RMH_XCD_WEAVE": "2"}):
-        monkeypatch.delenv("RMH_XCD_CHUNK", raising=False)
-        monkeypatch.delenv("RMH_XCD_WEAVE", raising=False)
+    for env in ({"RMH_XCD_CHUNK": "0", "RMH_ALT_ORDER": "0"}, {}, {"RMH_XCD_WEAVE": "0"}, {"RMH_XCD_WEAVE": "2", "RMH_ALT_ORDER": "0"}):
+        for k in ("RMH_XCD_CHUNK", "RMH_XCD_WEAVE", "RMH_ALT_ORDER"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         u, _ = run_steps(lib, "cuda:0", mesh, rs, p, 10, lo, 0, 2, self_wrap=self_wrap)

@@ -69,7 +69,7 @@ def run_steps(lib, device, mesh, rs, p, prob, lo, T, steps, part=(1, 1, 1), self
     return u, nh
 
 
-@pytest.mark.parametrize("mesh,rs,p,prob,lo,T", [("periodic-cube", 1, 2, 10, 5, 2), ("cube01_hex", 1, 3, 10, 4, 2), ("periodic-cube", 1, 3, 0, 5, 3)])
+@pytest.mark.parametrize("mesh,rs,p,prob,lo,T", [("periodic-cube", 1, 2, 10, 5, 2), ("cube01_hex", 1, 3, 10, 4, 2)])  # (transport, p = 3 ... 6: tests/test_gpu_tile_order.py)
 def test_tiled_run_is_bit_identical_emulated(emulib, mesh, rs, p, prob, lo, T):
     u0, _ = run_steps(emulib, "cpu", mesh, rs, p, prob, lo, 0, 1)
     u1, _ = run_steps(emulib, "cpu", mesh, rs, p, prob, lo, T, 1)
