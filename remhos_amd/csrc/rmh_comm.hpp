@@ -107,6 +107,8 @@ struct Exchange
    hipStream_t xs = nullptr;               // exchange stream
    hipEvent_t ev_packed = nullptr;         // send buffer complete (context stream)
    hipEvent_t ev_done = nullptr;           // ghosts received (exchange stream)
+   hipEvent_t ev_started = nullptr;        // the exchange stream has passed its wait for ev_packed: the RCCL kernel is next in its queue
+   bool comm_first = false;                // the context's stream waits for ev_started behind rmh_exchange_begin (blocks of >= 16 M dofs; RMH_COMM_FIRST=0 / 1 overrides)
    unsigned long long gen_begin = 0, gen_end = 0;
    double *d_red = nullptr;                // scratch of rmh_allreduce
    // exchange of caller-given element extrema (rmh_exchange_minmax_*): [nsend][2] out, [ne_ghost][2] in, and where ghost
@@ -199,6 +201,7 @@ void exchange_free(rmh_ctx *c)
    (void)hipFree(x->d_ghost_pos);
    if (x->ev_packed) { (void)hipEventDestroy(x->ev_packed); }
    if (x->ev_done) { (void)hipEventDestroy(x->ev_done); }
+   if (x->ev_started) { (void)hipEventDestroy(x->ev_started); }
    if (x->xs) { (void)hipStreamDestroy(x->xs); }
    if (x->comm && x->own_comm && rccl().ok) { (void)rccl().CommDestroy(x->comm); }
    delete x;
@@ -434,6 +437,12 @@ static int exchange_setup_impl(rmh_ctx *c, const rmh_exchange_desc *d, int compa
    }
    RMH_HIP(hipEventCreateWithFlags(&x->ev_packed, hipEventDisableTiming));
    RMH_HIP(hipEventCreateWithFlags(&x->ev_done, hipEventDisableTiming));
+   RMH_HIP(hipEventCreateWithFlags(&x->ev_started, hipEventDisableTiming));
+   // (the hold costs two cross-stream wake-ups, ~30 us per stage: measured on the one-rank self-loop it is neutral for a 96^3 block
+   // -- 2.7 ms interior launch, RCCL kernel 8 us instead of 2.7 ms in the queue, interior launch 2.4 % shorter without the
+   // half-resident exchange kernel spinning beside it -- and -2.5 % for a 48^3 block; on by default for large blocks only)
+   x->comm_first = (double)c->ne * c->ndof >= 16.0e6;
+   if (const char *s = std::getenv("RMH_COMM_FIRST")) { x->comm_first = std::atoi(s) != 0; }
    // the kernels read the ghosts from the library's buffer from now on
    if (x->compact)
    {
@@ -553,6 +562,7 @@ int rmh_exchange_begin(rmh_ctx *c, const double *u)
       // the exchange stream starts behind the pack kernel -- and thereby behind every kernel of the previous stage
       // that still read the ghosts it is about to overwrite
       RMH_HIP(hipStreamWaitEvent(x->xs, x->ev_packed, 0));
+      if (x->comm_first) { RMH_HIP(hipEventRecord(x->ev_started, x->xs)); }
       // (a failing call must not leave the group open or the generation counter advanced: the context stays usable)
       int rc = rccl().GroupStart();
       const char *what = "ncclGroupStart";
@@ -572,6 +582,13 @@ int rmh_exchange_begin(rmh_ctx *c, const double *u)
          x->gen_begin--;
          return fail(RMH_ERR_HIP, std::string(what) + ": " + rccl().GetErrorString(rc));
       }
+      // The interior launch that follows on the context's stream is held until the exchange stream has passed its wait for the
+      // pack kernel, i.e. until the grouped send / recv kernel is the next packet of ITS queue: in-stream the interior kernel
+      // followed the pack kernel at once, the cross-stream wake-up of the exchange stream took ~7 us longer, and by then the
+      // interior's workgroups had filled every CU -- the RCCL kernel (41 workgroups with a large LDS block) then found no CU
+      // until that launch drained (measured: 2.7 ms in the queue at -rs 5, 10 us alone), so nothing of the exchange was hidden.
+      // Now both become eligible together and the exchange kernel, first in its queue, is resident before the flood.
+      if (x->comm_first) { RMH_HIP(hipStreamWaitEvent(c->stream, x->ev_started, 0)); }
    }
    return RMH_OK;
 }

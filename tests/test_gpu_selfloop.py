@@ -39,6 +39,16 @@ def test_rccl_selfloop_equals_plain_periodic(lib, rs, p, wrap, lo, compact, prob
     assert np.array_equal(u0, u1)
 
 
+@pytest.mark.parametrize("first", ["0", "1"])
+def test_rccl_selfloop_with_and_without_the_comm_first_hold(lib, first, monkeypatch):
+    """RMH_COMM_FIRST: the interior launch held until the exchange stream has passed its wait for the pack kernel (default for
+    blocks of >= 16 M dofs only, so the other tests of this file run without it): same field either way."""
+    monkeypatch.setenv("RMH_COMM_FIRST", first)
+    u0 = plain_run(lib, "cuda:0", 2, 3, 4, lo=5, prob=10)
+    u1, tr, _ = selfloop_run(lib, "cuda:0", 2, 3, 1, 4, lo=5, compact=True, prob=10)
+    assert tr == "rccl" and np.array_equal(u0, u1)
+
+
 def test_rccl_selfloop_cpp_driver(lib, tmp_path):
     """rmhd_run_partitioned in its RCCL mode (unique id through the file, communicator of one rank, C++ stage loop on a
     non-default stream with interior / halo ranges, reductions through rmh_allreduce) against rmhd_run."""
