@@ -123,6 +123,16 @@ int rmh_set_stream(rmh_ctx *ctx, void *hip_stream);
 int rmh_stream_create_reserving(int device, int reserve_cus, void **hip_stream);
 int rmh_stream_destroy(void *hip_stream);
 
+/* Diagnostic: the batch order the one-kernel stage (rmh_stage_fused*) uses for a launch over `n_elements` elements of this
+ * context.  The kernel maps its workgroups to element batches XCD-aware (each of the MI355X's eight XCDs has its own L2): where
+ * the element numbering shows lattice layers -- most owned elements find their +z face neighbour the same distance e' - e away --
+ * the launch is cut into chunks of 2^(*weave) layers, woven batch by batch, and the chunks are dealt round-robin to the XCDs, so
+ * that z-neighbours run at the same time in one L2 or meet in the Infinity Cache; otherwise (*chunk = 0) every XCD takes one
+ * contiguous eighth.  Outputs: *layer_elements (0: no layers found), *batch_elements (elements per workgroup at this order and
+ * LO solver), *chunk (batches per chunk), *weave.  Results never depend on the order.  No reference
+ * counterpart: MFEM's forall leaves the mapping to the back-end. */
+int rmh_batch_order(rmh_ctx *ctx, int n_elements, int *layer_elements, int *batch_elements, int *chunk, int *weave);
+
 /* Remap re-setup: AdvectionOperator::MultUnlimited moves the mesh to pseudo-time t and
  * re-assembles M_HO, K_HO and the lumped mass (remhos.cpp:1598-1637).  Here the geometry is
  * recomputed inside the kernels from x0 + t*vel (matrix-free), so this call only records t. */

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librmh.so")
 
 # every symbol include/rmh.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
-    "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_stream_create_reserving", "rmh_stream_destroy", "rmh_setup",
+    "rmh_create", "rmh_destroy", "rmh_last_error", "rmh_version", "rmh_set_stream", "rmh_stream_create_reserving", "rmh_stream_destroy", "rmh_batch_order", "rmh_setup",
     "rmh_set_ghost_u", "rmh_set_ghost_minmax", "rmh_halo_pack", "rmh_ho_apply", "rmh_lumped_mass",
     "rmh_compute_lumped_mass", "rmh_lo_massavg", "rmh_lo_rdsubcell", "rmh_lo_rd", "rmh_elem_minmax", "rmh_bounds",
     "rmh_fct_clipscale", "rmh_limit_fused", "rmh_limit_fused_lo", "rmh_stage_fused", "rmh_stage_fused_range", "rmh_stage_fused_chain",
@@ -81,6 +81,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_version.restype = C.c_char_p
     lib.rmh_set_stream.argtypes = [p, p]
     lib.rmh_stream_create_reserving.argtypes = [i, i, C.POINTER(p)]
+    if hasattr(lib, "rmh_batch_order"):  # (older development builds of the library lack it: tools/kbench.py A/B runs)
+        lib.rmh_batch_order.argtypes = [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.rmh_stream_destroy.argtypes = [p]
     lib.rmh_setup.argtypes = [p, d]
     lib.rmh_set_ghost_u.argtypes = [p, p]
@@ -287,6 +289,12 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.rmh_last_cg_iters(self.h, C.byref(n)))
         return n.value
+
+    def batch_order(self, n_elements):
+        """(layer_elements, batch_elements, chunk, weave) of a stage launch over n_elements elements: rmh_batch_order"""
+        v = [C.c_int(0) for _ in range(4)]
+        self._check(self.lib.rmh_batch_order(self.h, int(n_elements), *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def set_lo_type(self, lo_type):
         self._check(self.lib.rmh_set_lo_type(self.h, int(lo_type)))

@@ -95,6 +95,14 @@ int upload(T **dst, const T *src, size_t n)
    return 0;
 }
 
+// elements per workgroup of the one-kernel stage at this order and LO solver (rmh_batch_order)
+template <int P>
+static int stage_batch_elements(const rmh_ctx *c)
+{
+   if (c->lo_type == 4 || c->lo_type == 3) { return K2Cfg<(P >= 2 ? P : 2), true, true>::NB; }
+   return K2Cfg<P>::NB;
+}
+
 // Chunk of the XCD-aware batch order of ho_kernel2 for a launch of nblk batches of NB elements (HoArgs::xcd_chunk, xcd_weave):
 // 2^weave lattice layers, woven batch by batch, so that +-z neighbours run at the same time -- inside one XCD (one L2) between
 // the woven layers, on the neighbouring XCD (through the Infinity Cache) at the chunk ends.  The layer is taken a little short
@@ -613,6 +621,18 @@ int rmh_set_stream(rmh_ctx *c, void *s)
 {
    if (!c) { return fail(RMH_ERR_INVALID, "null ctx"); }
    c->stream = (hipStream_t)s;
+   return RMH_OK;
+}
+
+int rmh_batch_order(rmh_ctx *c, int n_elements, int *layer_elements, int *batch_elements, int *chunk, int *weave)
+{
+   if (!c || !layer_elements || !batch_elements || !chunk || !weave || n_elements < 0) { return fail(RMH_ERR_INVALID, "rmh_batch_order: bad argument"); }
+   RMH_3D_ONLY(c, "rmh_batch_order");
+   int nb = 1;
+   RMH_DISPATCH(c, nb = stage_batch_elements<P>(c));
+   *layer_elements = c->layer_stride;
+   *batch_elements = nb;
+   *chunk = xcd_chunk_for(c, (n_elements + nb - 1) / nb, nb, weave);
    return RMH_OK;
 }
 

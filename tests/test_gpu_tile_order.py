@@ -72,3 +72,18 @@ def test_xcd_batch_order_is_bit_identical(lib, mesh, rs, p, lo, self_wrap, monke
         out.append(u)
     for u in out[1:]:
         assert np.array_equal(out[0], u)
+
+
+@pytest.mark.parametrize("mesh,rs,p,expect", [("periodic-cube", 5, 3, (9216, 7, 2632, 1)), ("periodic-cube", 4, 6, (2304, 1, 4608, 1)),
+                                              ("cube01_hex", 5, 4, (4096, 1, 8192, 1))])
+def test_batch_order_of_the_bench_meshes(lib, mesh, rs, p, expect):
+    """the XCD-aware batch order bench.py's headline, p6 and cube01_p4 blocks run with (profiles/r05_xcd_layers.txt)"""
+    from remhos_amd.capi import Context
+    from remhos_amd.case import Case, make_config
+
+    case = Case(lib, make_config(mesh, rs, p, 10, -1.0, 0.5, pa=1))
+    ctx = Context(lib, order=p, exec_mode=case.exec_mode, x0=case.x0, vel=case.vel, face_nbr=case.face_nbr, stencil27=case.stencil27)
+    try:
+        assert ctx.batch_order(case.ne_owned) == expect
+    finally:
+        ctx.close()

@@ -81,3 +81,27 @@ def test_tiled_order_keeps_the_halo_first_emulated(emulib):
     u0, nh0 = run_steps(emulib, "cpu", "periodic-cube", 1, 2, 10, 5, 0, 1, self_wrap=1)
     u1, nh1 = run_steps(emulib, "cpu", "periodic-cube", 1, 2, 10, 5, 2, 1, self_wrap=1)
     assert nh0 == nh1 > 0 and np.array_equal(u0, u1)
+
+
+@pytest.mark.parametrize("mesh,rs,p,lo,T,expect", [
+    ("periodic-cube", 4, 3, 5, 0, (2304, 7, 658, 1)),   # 48^3, seven elements per workgroup: 329 batches per layer, two layers woven, three rounds
+    ("periodic-cube", 3, 6, 5, 0, (576, 1, 1152, 1)),   # 24^3, one element per workgroup: one round of 8 chunks + a tail in contiguous eighths
+    ("periodic-cube", 3, 4, 4, 0, (576, 1, 1152, 1)),   # the subcell-RD stage kernel batches alike at p >= 4
+    ("periodic-cube", 4, 3, 5, 4, (192, 7, 0, 0)),      # y-strips of 4 rows: "layers" of 27 batches are too small to hold an XCD's workgroups
+    ("periodic-cube", 1, 3, 5, 0, (36, 7, 0, 0)),       # 6^3: contiguous eighths
+    ("cube01_hex", 3, 4, 5, 0, (256, 1, 512, 1)),       # 16^3 non-periodic
+])
+def test_batch_order_chosen_from_the_numbering(emulib, mesh, rs, p, lo, T, expect):
+    """rmh_batch_order: the layer length read off face_nbr, and the chunk / weave of the XCD-aware batch order it leads to
+    (xcd_chunk_for, remhos_amd/csrc/rmh_api.hip); the bench meshes' values are asserted on the GPU (tests/test_gpu_tile_order.py)."""
+    from remhos_amd.capi import Context
+
+    case = Case(emulib, make_config(mesh, rs, p, 10, -1.0, 0.5, lo_type=lo, tile_rows=T, pa=1))
+    ctx = Context(emulib, order=p, exec_mode=case.exec_mode, x0=case.x0, vel=case.vel, face_nbr=case.face_nbr, stencil27=case.stencil27,
+                  subcell_vel=case.subcell_vel)
+    ctx.set_lo_type(lo)
+    try:
+        assert ctx.batch_order(case.ne_owned) == expect
+        assert ctx.batch_order(0)[2] == 0 and ctx.batch_order(64)[2] == 0  # (short launches -- a halo shell -- keep contiguous eighths)
+    finally:
+        ctx.close()
