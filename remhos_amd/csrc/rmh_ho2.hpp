@@ -2362,6 +2362,14 @@ tabp gt = gtb;
    double uu[DR], xb[DR], slo[NLS], shi[NLS];
    if (FUSED)
    {
+      // (late arguments read ONCE and together, in front of the exec-masked blocks: inside them each was a scalar load with its
+      // own exposed wait -- three dependent round trips here, one per dof round below; p = 5 +1.2 %, p = 3, 4, 6 +0.6 ... +0.8 %)
+      int ne_ownL = L.ne_owned, gh_mstrL = L.gh_mstride, e_lastL = L.e_end - 1;
+      const double *pminL = L.xe_min, *pmaxL = L.xe_max, *gminL = L.gh_min, *gmaxL = L.gh_max, *x_baseL = L.x_base;
+#if defined(__HIP_DEVICE_COMPILE__)
+      // (pinned here: the compiler otherwise sinks each load back into the block of its first use)
+      asm volatile("" : "+s"(ne_ownL), "+s"(gh_mstrL), "+s"(e_lastL), "+s"(pminL), "+s"(pmaxL), "+s"(gminL), "+s"(gmaxL), "+s"(x_baseL));
+#endif
 #pragma unroll
       for (int j = 0; j < NLS; j++)
       {
@@ -2371,11 +2379,10 @@ tabp gt = gtb;
          if (nb >= 0)
          {
             // (owned or ghost: the two base pointers are scalars, the select happens on the per-lane address)
-            const bool own = nb < L.ne_owned;
-            const size_t off = own ? (size_t)nb : (size_t)(nb - L.ne_owned) * L.gh_mstride;
-            const double *pmin = L.xe_min, *pmax = L.xe_max, *gmin = L.gh_min, *gmax = L.gh_max;
-            slo[j] = (own ? pmin : gmin)[off];
-            shi[j] = (own ? pmax : gmax)[off];
+            const bool own = nb < ne_ownL;
+            const size_t off = own ? (size_t)nb : (size_t)(nb - ne_ownL) * gh_mstrL;
+            slo[j] = (own ? pminL : gminL)[off];
+            shi[j] = (own ? pmaxL : gmaxL)[off];
          }
       }
 #pragma unroll
@@ -2385,9 +2392,9 @@ tabp gt = gtb;
          uu[r] = 0.0; xb[r] = 0.0;
          if (t < NB * D3)
          {
-            const size_t g = (size_t)min(e0 + t / D3, L.e_end - 1) * D3 + t % D3;
+            const size_t g = (size_t)min(e0 + t / D3, e_lastL) * D3 + t % D3;
             uu[r] = BOTH ? uu4[r] : a.u[g]; // (HO + RD: already reloaded for the RD solver)
-            if (L.x_base) { xb[r] = L.x_base[g]; }
+            if (x_baseL) { xb[r] = x_baseL[g]; }
          }
       }
    }
@@ -2804,6 +2811,11 @@ tabp gt = gtb;
       RMH_STAMP(19);
       double ynew[DR];
       const double rden_uni = UNI ? fdiv_rcp((sumNeg[0] + sumPos[0] > eps) ? sumPos[0] : sumNeg[0]) : 0.0;
+      // (late arguments of the rounds below, read once: see the PCG prelude)
+      const bool has_xb = L.x_base != nullptr;
+      const double rk_aL = L.rk_a, rk_bL = L.rk_b, dt_rkL = L.dt_rk;
+      const int e_endL = L.e_end;
+      double *const y_outL = L.y_out, *const duL = L.du;
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
@@ -2824,11 +2836,11 @@ tabp gt = gtb;
                else if (dn) { fc = fpos - q; }
             }
             const double dui = dlo[r] + fdiv(fc, mm[r]);
-            ynew[r] = (L.x_base ? L.rk_a * xb[r] : 0.0) + L.rk_b * (uu[r] + L.dt_rk * dui);
-            if (e0 + t / D3 < L.e_end)
+            ynew[r] = (has_xb ? rk_aL * xb[r] : 0.0) + rk_bL * (uu[r] + dt_rkL * dui);
+            if (e0 + t / D3 < e_endL)
             {
-               L.y_out[(size_t)e0 * D3 + t] = ynew[r];
-               if (L.du) { L.du[(size_t)e0 * D3 + t] = dui; }
+               y_outL[(size_t)e0 * D3 + t] = ynew[r];
+               if (duL) { duL[(size_t)e0 * D3 + t] = dui; }
             }
          }
       }
