@@ -214,6 +214,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.face_rows = c->d_face_rows;
       }
       a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB, &a.xcd_weave);
+      a.xcd_rounds = a.xcd_chunk > 0 ? (((c->ne + NB - 1) / NB) >> 3) / a.xcd_chunk : 0;
+      a.xcd_inv = a.xcd_chunk > 1 ? (unsigned)(0x100000000ull / (unsigned)a.xcd_chunk) : 0xffffffffu;
       a.reverse = 0;
       hipLaunchKernelGGL((ho_kernel2<P2, 2>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P2, true>::NT), 0, c->stream, a);
    }
@@ -227,6 +229,8 @@ int launch_ho(rmh_ctx *c, const double *u, double *du, double *m, double t)
          a.face_rows = c->d_face_rows;
       }
       a.xcd_chunk = xcd_chunk_for(c, (c->ne + NB - 1) / NB, NB, &a.xcd_weave);
+      a.xcd_rounds = a.xcd_chunk > 0 ? (((c->ne + NB - 1) / NB) >> 3) / a.xcd_chunk : 0;
+      a.xcd_inv = a.xcd_chunk > 1 ? (unsigned)(0x100000000ull / (unsigned)a.xcd_chunk) : 0xffffffffu;
       a.reverse = 0;
       hipLaunchKernelGGL((ho_kernel2<P, 0>), dim3((c->ne + NB - 1) / NB), dim3(K2Cfg<P>::NT), 0, c->stream, a);
    }
@@ -292,6 +296,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
       a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB, &a.xcd_weave);
+      a.xcd_rounds = a.xcd_chunk > 0 ? ((nblk) >> 3) / a.xcd_chunk : 0;
+      a.xcd_inv = a.xcd_chunk > 1 ? (unsigned)(0x100000000ull / (unsigned)a.xcd_chunk) : 0xffffffffu;
       a.reverse = c->alt_order ? (int)(c->xe_counter & 1) : 0;
       // (the face speed table is made the first time a kernel that reads it is launched)
       {
@@ -307,6 +313,8 @@ int launch_stage_fused(rmh_ctx *c, const double *u, double dt, const double *x_b
       const int nblk = (e_end - e_begin + C::NB - 1) / C::NB;
       const int grid = nblk;
       a.xcd_chunk = xcd_chunk_for(c, nblk, C::NB, &a.xcd_weave);
+      a.xcd_rounds = a.xcd_chunk > 0 ? ((nblk) >> 3) / a.xcd_chunk : 0;
+      a.xcd_inv = a.xcd_chunk > 1 ? (unsigned)(0x100000000ull / (unsigned)a.xcd_chunk) : 0xffffffffu;
       a.reverse = c->alt_order ? (int)(c->xe_counter & 1) : 0;
       // (the face speed table is made the first time a kernel that reads it is launched)
       {

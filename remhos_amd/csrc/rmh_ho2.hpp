@@ -1025,22 +1025,20 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
       // a contiguous eighth it comes a whole layer (~55 MB of traffic at p = 3) later, far beyond the 4 MB L2.  Measured
       // (profiles/r05_xcd_layers.txt): p = 3 +2 %, p = 6 +3 %.  The batches behind the last whole round keep contiguous eighths.
       const int C_ = a.xcd_chunk;
-      if (C_ > 0 && q8 >= C_)
-      {
-         const int rounds = q8 / C_, jr = j8 / C_, covered = rounds * 8 * C_;
-         if (jr < rounds)
-         {
-            const int jj = j8 - jr * C_, w = a.xcd_weave;
-            blk = jr * 8 * C_ + xcd * C_ + (jj & ((1 << w) - 1)) * (C_ >> w) + (jj >> w); // (C_ is a multiple of 2^w)
-         }
-         else
-         {
-            const int nt = nblk - covered, qt = nt >> 3, rt = nt & 7;
-            blk = covered + xcd * qt + min(xcd, rt) + (j8 - rounds * C_);
-         }
-      }
-      else { blk = xcd * q8 + min(xcd, r8) + j8; }
-      if (a.reverse) { blk = nblk - 1 - blk; }
+      // (straight-line: with branches here the kernel-argument loads behind them waited for the branch -- two more scalar-memory
+      // round trips in front of the first global load.  rounds = q8 / C_ and floor(2^32 / C_) come from the host: j8 / C_ by
+      // multiplication, at most one below the quotient)
+      const bool chunked = C_ > 0 && q8 >= C_;
+      const int rounds = a.xcd_rounds, covered = rounds * 8 * C_;
+      int jr = (int)__umulhi((unsigned)j8, a.xcd_inv);
+      jr += ((jr + 1) * C_ <= j8) ? 1 : 0;
+      const int jj = j8 - jr * C_, w = a.xcd_weave;
+      const int woven = jr * 8 * C_ + xcd * C_ + (jj & ((1 << w) - 1)) * (C_ >> w) + (jj >> w); // (C_ is a multiple of 2^w)
+      const int nt = nblk - covered, qt = nt >> 3, rt = nt & 7;
+      const int tail = covered + xcd * qt + min(xcd, rt) + (j8 - rounds * C_);
+      const int eighth = xcd * q8 + min(xcd, r8) + j8;
+      blk = chunked ? (jr < rounds ? woven : tail) : eighth;
+      blk = a.reverse ? nblk - 1 - blk : blk;
    }
    const int e0 = a.e_begin + blk * NB;
    const int tid = tid0;

@@ -57,6 +57,8 @@ struct HoArgs
    int e_begin, e_end;     // elements this launch works on (ho_kernel2; the whole rank: 0, ne_owned)
    int xcd_chunk;          // batches per chunk of the XCD-aware batch order (ho_kernel2): chunks are dealt round-robin to the 8 XCDs; 0: one contiguous eighth each
    int xcd_weave;          // log2 of the lattice layers woven into one chunk (batch j of a chunk: layer j % 2^w, position j >> w); 0: none
+   int xcd_rounds;         // whole rounds of 8 chunks in this launch = (n_batches / 8) / xcd_chunk, and floor(2^32 / xcd_chunk): the kernel divides by multiplication
+   unsigned xcd_inv;
    int reverse;            // 1: the batches of this launch are taken from the last to the first (alternating stages: rmh_ctx::alt_order)
    double t;               // pseudo-time (remap) -- X = x0 + t*vel
    int move;               // 1: remap (mesh moves), 0: transport (static mesh)

@@ -73,6 +73,7 @@ inline double __shfl_xor(double v, int off)
 }
 
 // value of lane `src` of the caller's wavefront (ds_bpermute)
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline double __shfl(double v, int src)
 {
    const unsigned t = threadIdx.x, base = t - (t & 63u);
