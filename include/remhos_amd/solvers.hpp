@@ -16,6 +16,7 @@
 #include "../rmh.h"
 
 #include <cstddef>
+#include <string>
 #include <vector>
 
 namespace remhos
@@ -267,6 +268,15 @@ void ComputeBoolIndicators(ParFiniteElementSpace &pfes, const Vector &u, Array<b
 void ComputeRatio(ParFiniteElementSpace &pfes, const Vector &us, const Vector &u, Vector &s, Array<bool> &bool_el,
                   Array<bool> &bool_dof);
 
+// -vb (remhos.cpp:1557-1594): abort with the reference's message when a dof of u_new (first overload) or of u + dt * du_new
+// (second) lies outside [u_min - tol, u_max + tol]; active_dofs restricts the check like the reference's.  One streaming
+// kernel (rmh_check_violation) instead of a host loop; the space is the first argument because a device vector does not know
+// its context.
+void check_violation(ParFiniteElementSpace &pfes, const Vector &u_new, const Vector &u_min, const Vector &u_max, std::string info,
+                     double tol, const Array<bool> *active_dofs);
+void check_violation(ParFiniteElementSpace &pfes, const Vector &u, double dt, const Vector &du_new, const Vector &u_min,
+                     const Vector &u_max, std::string info, double tol, const Array<bool> *active_dofs);
+
 // remhos_solvers.hpp:25-63
 class LimitedTimeDependentOperator
 {
@@ -309,6 +319,10 @@ class AdvectionOperator : public LimitedTimeDependentOperator
    const bool product; // block vector [u | us]
 
 public:
+   // -vb (remhos.cpp:195, 1115): LimitMult checks the LO and the limited update against the dof bounds (:1824-1837).  With
+   // the fused limiter the bounds and the LO rate are formed a second time by the granular kernels for the check.
+   bool verify_bounds = false;
+
    AdvectionOperator(ParFiniteElementSpace &space, DofInfo &dofs_, HOSolver *hos, LOSolver *los, FCTSolver *fct,
                      bool fused_limiter, bool product_sync = false);
    ~AdvectionOperator();

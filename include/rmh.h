@@ -347,6 +347,25 @@ int rmh_dt_estimate_reset(rmh_ctx *ctx);
 int rmh_dt_estimate_update(rmh_ctx *ctx, const double *x, const double *dx, const double *x_min, const double *x_max);
 int rmh_dt_estimate_get(rmh_ctx *ctx, double *dt);
 
+/* check_violation (-vb, remhos.cpp:1557-1594; called around the limiter at remhos.cpp:1824-1837 and at the end of
+ * FCTSolver::CalcFCTProduct, remhos_fct.cpp:568-610): the reference's only in-loop correctness guard on this path.  One
+ * streaming pass over the rank's dofs tests
+ *      u_new + tol < lo   ||   u_new > hi + tol,      u_new = u + dt * du   (du == NULL: u_new = u, the first overload)
+ * with (lo, hi) = (u_min, u_max), or (u_min * bound_scale, u_max * bound_scale) when bound_scale != NULL -- the bounds
+ * ScaleProductBounds forms from (s_min, s_max) and u_new for the product field (remhos_fct.cpp:117-153); active_dofs (device
+ * bytes, may be NULL) selects the dofs like the reference's Array<bool>.  The reference aborts at the first violating dof and
+ * prints its index and three values; here the verdict comes back (synchronises the stream) and the caller decides --
+ * remhos::check_violation of include/remhos_amd/solvers.hpp aborts with the reference's message.
+ *   count: violating dofs; first: the smallest violating index (-1: none) and u_min / u_new / u_max there;
+ *   over / under: the largest u_new - hi and lo - u_new among the violating dofs (0 if none). */
+typedef struct {
+   long long count, first;
+   double over, under;
+   double first_min, first_value, first_max;
+} rmh_violation;
+int rmh_check_violation(rmh_ctx *ctx, const double *u, double dt, const double *du, const double *u_min, const double *u_max,
+                        const double *bound_scale, double tol, const unsigned char *active_dofs, rmh_violation *out);
+
 /* Stopwatch buckets of TimingData (remhos_tools.hpp:52-64; printed by
  * AdvectionOperator::PrintTimingData, remhos.cpp:1918-1966): seconds in
  * t[0]=RHS (K u), t[1]=L2inv (mass solve), t[2]=LO, t[3]=FCT since the last reset, measured

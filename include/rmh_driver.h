@@ -51,6 +51,11 @@ typedef struct {
                          time then hold each other's face neighbours in all three directions (L2 hits instead of HBM reads of
                          the neighbour traces, extrema and shared face-table blocks).  The same mesh and the same results,
                          element for element (owned_gid maps the numbering); halo elements still come first.               */
+   int verify_bounds; /* -vb : the reference's debug guards (remhos.cpp:324): check_violation on the LO and the limited update of
+                         every stage (remhos.cpp:1824-1837), on the limited product field (remhos_fct.cpp:568-610), and the
+                         monotonicity check of the global extrema at the top of every step (remhos.cpp:1218-1262).  A violation
+                         prints the reference's message and aborts.  rmhd_run / rmhd_run_rank; costs the granular bounds + LO
+                         kernels beside a fused stage.                                                                       */
 } rmhd_config;
 
 typedef struct {

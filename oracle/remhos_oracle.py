@@ -1288,3 +1288,26 @@ def fct_product(us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt,
     d_us = np.where(~active_el[:, None] & ~active_dofs, 0.0, d_us)  # ZeroOutEmptyDofs
     return d_us, s_min, s_max
 
+
+
+def check_violation(u, u_min, u_max, dt=0.0, du=None, tol=1e-12, scale=None, active_dofs=None):
+    """check_violation, both overloads (remhos.cpp:1557-1594): the dofs with u_new + tol < u_min or u_new > u_max + tol,
+    u_new = u + dt * du (du None: u itself).  The reference aborts at the first of them; the checker returns the verdict
+    rmh_check_violation returns (include/rmh.h): count, first index (flat, -1: none), largest over- / undershoot among the
+    violating dofs and the three values the reference prints.  scale: bounds (u_min * scale, u_max * scale) -- the
+    ScaleProductBounds form (remhos_fct.cpp:117-153) the check at the end of CalcFCTProduct (:568-610) compares with."""
+    un = (u if du is None else u + dt * du).ravel()
+    lo, hi = u_min.ravel(), u_max.ravel()
+    if scale is not None:
+        lo, hi = lo * scale.ravel(), hi * scale.ravel()
+    with np.errstate(invalid="ignore"):
+        bad = (un + tol < lo) | (un > hi + tol)
+    if active_dofs is not None:
+        bad &= active_dofs.ravel().astype(bool)
+    idx = np.flatnonzero(bad)
+    out = dict(count=int(idx.size), first=-1, over=0.0, under=0.0, first_min=0.0, first_value=0.0, first_max=0.0)
+    if idx.size:
+        i = int(idx[0])
+        out.update(first=i, over=float(max(0.0, (un[idx] - hi[idx]).max())), under=float(max(0.0, (lo[idx] - un[idx]).max())),
+                   first_min=float(lo[i]), first_value=float(un[i]), first_max=float(hi[i]))
+    return out

@@ -23,6 +23,7 @@ SYMBOLS = [
     "rmh_exchange_setup", "rmh_comm_unique_id", "rmh_comm_init", "rmh_comm_attach", "rmh_comm_connect_local",
     "rmh_exchange_begin", "rmh_exchange_end", "rmh_exchange_minmax_begin", "rmh_exchange_minmax_end", "rmh_exchange_buffers", "rmh_exchange_peer", "rmh_allreduce", "rmh_comm_count",
     "rmh_build_tables", "rmh_build_tables_2d", "rmh_product_ratio", "rmh_elem_minmax_masked", "rmh_fct_product",
+    "rmh_check_violation",
 ]
 
 
@@ -51,6 +52,19 @@ class RmhExchangeDesc(C.Structure):
         ("send_elems", C.POINTER(C.POINTER(C.c_int))),
         ("recv_first", C.POINTER(C.c_int)),
         ("recv_count", C.POINTER(C.c_int)),
+    ]
+
+
+class RmhViolation(C.Structure):
+    """rmh_violation (include/rmh.h): verdict of rmh_check_violation"""
+    _fields_ = [
+        ("count", C.c_longlong),
+        ("first", C.c_longlong),
+        ("over", C.c_double),
+        ("under", C.c_double),
+        ("first_min", C.c_double),
+        ("first_value", C.c_double),
+        ("first_max", C.c_double),
     ]
 
 
@@ -137,6 +151,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rmh_product_ratio.argtypes = [p, p, p, p, p, p]
     lib.rmh_elem_minmax_masked.argtypes = [p, p, p, p, p, p]
     lib.rmh_fct_product.argtypes = [p, p, p, p, p, p, p, p, p, d, p]
+    lib.rmh_check_violation.argtypes = [p, p, d, p, p, p, p, d, p, C.POINTER(RmhViolation)]
     return lib
 
 
@@ -393,6 +408,13 @@ class Context:
     def fct_product(self, us, m, d_us_ho, s_min, s_max, u_new, active_el, active_dofs, dt, d_us):
         self._check(self.lib.rmh_fct_product(self.h, _ptr(us), _ptr(m), _ptr(d_us_ho), _ptr(s_min), _ptr(s_max), _ptr(u_new),
                                              _ptr(active_el), _ptr(active_dofs), float(dt), _ptr(d_us)))
+
+    def check_violation(self, u, u_min, u_max, dt=0.0, du=None, tol=1e-12, bound_scale=None, active_dofs=None):
+        """check_violation of remhos.cpp:1557-1594 (-vb) on u + dt * du (du None: on u itself); returns the verdict as a dict"""
+        v = RmhViolation()
+        self._check(self.lib.rmh_check_violation(self.h, _ptr(u), float(dt), _ptr(du), _ptr(u_min), _ptr(u_max), _ptr(bound_scale),
+                                                 float(tol), _ptr(active_dofs), C.byref(v)))
+        return {k: getattr(v, k) for k, _ in RmhViolation._fields_}
 
     def set_mass_tol(self, rel_tol, abs_tol=0.0, max_iter=100):
         self._check(self.lib.rmh_set_mass_tol(self.h, float(rel_tol), float(abs_tol), int(max_iter)))

@@ -25,7 +25,7 @@ class RmhdConfig(C.Structure):
         ("fused", C.c_int), ("px", C.c_int), ("py", C.c_int), ("pz", C.c_int), ("rank", C.c_int),
         ("bounds_type", C.c_int), ("dt_control", C.c_int), ("ho_type", C.c_int), ("save", C.c_int),
         ("rs_extra", C.c_int * 3), ("pa", C.c_int), ("self_wrap", C.c_int), ("warmup_steps", C.c_int),
-        ("ps", C.c_int), ("ode_solver", C.c_int), ("tile_rows", C.c_int),
+        ("ps", C.c_int), ("ode_solver", C.c_int), ("tile_rows", C.c_int), ("verify_bounds", C.c_int),
     ]
 
 
@@ -56,7 +56,7 @@ class RmhdResult(C.Structure):
 
 def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_final=0.5, max_steps=-1, lo_type=5,
                 fused=1, part=(1, 1, 1), rank=0, bounds_type=0, dt_control=0, ho_type=3, save=0,
-                rs_extra=(0, 0, 0), pa=0, self_wrap=0, warmup_steps=0, ps=0, ode_solver=3, tile_rows=0) -> RmhdConfig:
+                rs_extra=(0, 0, 0), pa=0, self_wrap=0, warmup_steps=0, ps=0, ode_solver=3, tile_rows=0, verify_bounds=0) -> RmhdConfig:
     c = RmhdConfig()
     c.mesh = mesh.encode()
     c.rs, c.order, c.problem = rs, order, problem
@@ -70,6 +70,7 @@ def make_config(mesh="periodic-cube", rs=1, order=3, problem=10, dt=-1.0, t_fina
     c.warmup_steps = int(warmup_steps)
     c.ps, c.ode_solver = int(ps), int(ode_solver)
     c.tile_rows = int(tile_rows)
+    c.verify_bounds = int(verify_bounds)
     return c
 
 

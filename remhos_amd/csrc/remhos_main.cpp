@@ -57,6 +57,8 @@ int main(int argc, char **argv)
       else if (a == "-no-vis" || a == "-d") { if (a == "-d") { next(); } }
       else if (a == "-s") { c.ode_solver = std::atoi(next()); }
       else if (a == "-ps") { c.ps = 1; }
+      else if (a == "-vb") { c.verify_bounds = 1; } // remhos.cpp:324
+      else if (a == "-no-vb") { c.verify_bounds = 0; }
       else if (a == "-tile") { c.tile_rows = std::atoi(next()); } // element numbering of the case builder (rmh_driver.h)
       else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
    }
@@ -74,6 +76,11 @@ int main(int argc, char **argv)
    // block per process: rmhd_run_rank
    const bool classes = c.ps || c.ode_solver > 10 || !c.fused;
    int rc;
+   if (c.verify_bounds && partitioned && !(classes && !comm_file.empty()))
+   {
+      std::fprintf(stderr, "remhos_amd: -vb runs with the solver classes (one block, or one block per process with -unfused / -ps / -s 11|12|13)\n");
+      return 1;
+   }
    if (partitioned && classes && !comm_file.empty()) { rc = rmhd_run_rank(&c, comm_file.c_str(), device, &r, nullptr, nullptr); }
    else if (partitioned) { rc = rmhd_run_partitioned(&c, comm_file.empty() ? nullptr : comm_file.c_str(), device, &r); }
    else { rc = rmhd_run(&c, &r); }

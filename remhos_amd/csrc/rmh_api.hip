@@ -615,7 +615,7 @@ void rmh_destroy(rmh_ctx *c)
    if (!c) { return; }
    (void)hipSetDevice(c->device);
    exchange_free(c);
-   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_face_rows, c->d_m, c->d_scr_ho, c->d_scr_lo, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est};
+   void *bufs[] = {c->d_x0, c->d_vel, c->d_x0h, c->d_velh, c->d_tab, c->d_subvel, c->d_subx0, c->d_subvmid, c->d_fgeo, c->d_face_rows, c->d_m, c->d_scr_ho, c->d_scr_lo, c->d_xe_min, c->d_xe_max, c->d_xe_min2, c->d_xe_max2, c->d_nbr, c->d_st27, c->d_cg, c->d_dt_est, c->d_viol};
    for (void *b : bufs) { (void)hipFree(b); }
    for (int b = 0; b < 4; b++)
    {
@@ -1208,6 +1208,55 @@ int rmh_dt_estimate_get(rmh_ctx *c, double *dt)
    if (!c->d_dt_est) { return fail(RMH_ERR_STATE, "dt control is off"); }
    RMH_HIP(hipStreamSynchronize(c->stream));
    RMH_HIP(hipMemcpy(dt, c->d_dt_est, sizeof(double), hipMemcpyDeviceToHost));
+   return RMH_OK;
+}
+
+namespace
+{
+__global__ void violation_reset_kernel(unsigned long long *v)
+{
+   v[0] = 0;
+   v[1] = ~0ull;
+   v[2] = 0;
+   v[3] = 0;
+}
+} // namespace
+
+int rmh_check_violation(rmh_ctx *c, const double *u, double dt, const double *du, const double *u_min, const double *u_max,
+                        const double *bound_scale, double tol, const unsigned char *active_dofs, rmh_violation *out)
+{
+   if (!c || !u || !u_min || !u_max || !out) { return fail(RMH_ERR_INVALID, "null argument"); }
+   if (!(tol >= 0.0)) { return fail(RMH_ERR_INVALID, "rmh_check_violation: the tolerance must not be negative"); }
+   RMH_ENTER(c);
+   if (!c->d_viol) { RMH_HIP(hipMalloc((void **)&c->d_viol, 4 * sizeof(unsigned long long))); }
+   const size_t n = (size_t)c->ne * c->ndof;
+   const int nblk = (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096));
+   hipLaunchKernelGGL(violation_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->d_viol);
+   hipLaunchKernelGGL(check_violation_kernel, dim3(nblk), dim3(256), 0, c->stream, u, dt, du, u_min, u_max, bound_scale, tol,
+                      active_dofs, n, c->d_viol);
+   RMH_HIP(hipGetLastError());
+   RMH_HIP(hipStreamSynchronize(c->stream));
+   unsigned long long v[4];
+   RMH_HIP(hipMemcpy(v, c->d_viol, sizeof(v), hipMemcpyDeviceToHost));
+   std::memset(out, 0, sizeof(*out));
+   out->count = (long long)v[0];
+   out->first = v[0] ? (long long)v[1] : -1;
+   std::memcpy(&out->over, &v[2], 8);
+   std::memcpy(&out->under, &v[3], 8);
+   if (v[0])
+   {
+      // the three numbers the reference prints for that dof (remhos.cpp:1567-1569, 1587-1589)
+      const size_t i = (size_t)v[1];
+      double ui = 0.0, dui = 0.0, lo = 0.0, hi = 0.0, s = 1.0;
+      RMH_HIP(hipMemcpy(&ui, u + i, 8, hipMemcpyDeviceToHost));
+      if (du) { RMH_HIP(hipMemcpy(&dui, du + i, 8, hipMemcpyDeviceToHost)); }
+      RMH_HIP(hipMemcpy(&lo, u_min + i, 8, hipMemcpyDeviceToHost));
+      RMH_HIP(hipMemcpy(&hi, u_max + i, 8, hipMemcpyDeviceToHost));
+      if (bound_scale) { RMH_HIP(hipMemcpy(&s, bound_scale + i, 8, hipMemcpyDeviceToHost)); }
+      out->first_min = bound_scale ? lo * s : lo;
+      out->first_max = bound_scale ? hi * s : hi;
+      out->first_value = du ? ui + dt * dui : ui;
+   }
    return RMH_OK;
 }
 

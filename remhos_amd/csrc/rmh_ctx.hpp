@@ -74,6 +74,7 @@ struct rmh_ctx
    int bounds_type = 0; // DofInfo bounds type (-bt): 0 overlap, 1 face neighbours
    double *d_dt_est = nullptr; // running minimum of UpdateTimeStepEstimate; null while dt control is off
    bool dt_control = false;
+   unsigned long long *d_viol = nullptr; // verdict words of rmh_check_violation (made on first use)
    int lo_type = 5;    // LO solver inside rmh_stage_fused: 5 mass-based average, 4 subcell residual distribution
    // stopwatches (TimingData, remhos_tools.hpp:52-64)
    bool timers_on = false;

@@ -198,6 +198,48 @@ void ClipScaleSolver::CalcFCTProduct(const ParGridFunction &us, const Vector &m,
    static_assert(sizeof(bool) == 1, "Array<bool> is handed to the kernels as a byte array");
    RMH_CALL(rmh_fct_product(pfes.Ctx(), us.Read(), m.Read(), d_us_HO.Read(), s_min.ReadWrite(), s_max.ReadWrite(), u_new.Read(),
                             (const unsigned char *)active_el.Read(), (const unsigned char *)active_dofs.Read(), dt, d_us.Write()));
+   if (verify_bounds)
+   {
+      // Check the bounds of the final solution (remhos_fct.cpp:568-610): us + dt d_us against the scaled bounds
+      // (s_min u_new, s_max u_new) of ScaleProductBounds on the active dofs, eps = 1e-12.  (The kernel keeps the scaled
+      // bounds in registers; s_min / s_max come back updated like the reference's, so the product below IS us_min / us_max.)
+      rmh_violation v;
+      RMH_CALL(rmh_check_violation(pfes.Ctx(), us.Read(), dt, d_us.Read(), s_min.Read(), s_max.Read(), u_new.Read(), 1e-12,
+                                   (const unsigned char *)active_dofs.Read(), &v));
+      if (v.count > 0)
+      {
+         const int nd = pfes.GetNDofs();
+         std::printf("Final us %lld %lld %.17g %.17g %.17g\n---\n", v.first % nd, v.first / nd, v.first_min, v.first_value, v.first_max);
+         RMH_VERIFY(false, "Bounds violation FCT us.");
+      }
+   }
+}
+
+// remhos.cpp:1557-1594
+static void report_violation(const rmh_violation &v, const std::string &info)
+{
+   if (v.count == 0) { return; }
+   std::printf("%s bounds violation: %lld %.17g %.17g %.17g\n%.17g %.17g\n(%lld dofs out of bounds; largest overshoot %.3e, undershoot %.3e)\n",
+               info.c_str(), v.first, v.first_min, v.first_value, v.first_max, v.first_max - v.first_value,
+               v.first_value - v.first_min, v.count, v.over, v.under);
+   std::fflush(stdout);
+   RMH_VERIFY(false, "Aborted due to bounds violation.");
+}
+void check_violation(ParFiniteElementSpace &pfes, const Vector &u_new, const Vector &u_min, const Vector &u_max, std::string info,
+                     double tol, const Array<bool> *active_dofs)
+{
+   rmh_violation v;
+   RMH_CALL(rmh_check_violation(pfes.Ctx(), u_new.Read(), 0.0, nullptr, u_min.Read(), u_max.Read(), nullptr, tol,
+                                active_dofs ? (const unsigned char *)active_dofs->Read() : nullptr, &v));
+   report_violation(v, info);
+}
+void check_violation(ParFiniteElementSpace &pfes, const Vector &u, double dt, const Vector &du_new, const Vector &u_min,
+                     const Vector &u_max, std::string info, double tol, const Array<bool> *active_dofs)
+{
+   rmh_violation v;
+   RMH_CALL(rmh_check_violation(pfes.Ctx(), u.Read(), dt, du_new.Read(), u_min.Read(), u_max.Read(), nullptr, tol,
+                                active_dofs ? (const unsigned char *)active_dofs->Read() : nullptr, &v));
+   report_violation(v, info);
 }
 
 // remhos_sync.cpp:23-96
@@ -294,8 +336,22 @@ void AdvectionOperator::LimitMult(const Vector &X, Vector &Y) const
    Vector d_u(Y.Write(), n);
    if (fused)
    {
+      if (verify_bounds) { du_HO = d_u; } // (the fused kernel overwrites the HO rate; the check re-forms the LO rate from it)
       // d_u holds du_HO on entry; the fused kernel reads du_HO and writes d_u element by element
       RMH_CALL(rmh_limit_fused(pfes.Ctx(), u.Read(), d_u.Read(), dt, d_u.Write(), nullptr, 0.0, 1.0, 0.0, nullptr));
+      if (verify_bounds)
+      {
+         // remhos.cpp:1824-1837 for the fused limiter: it keeps du_LO and the dof bounds in registers, so the granular
+         // kernels form them once more for the check
+         if (du_LO.Size() != n) { du_LO.SetSize(n); }
+         auto mba = dynamic_cast<MassBasedAvg *>(lo_solver);
+         if (mba) { mba->SetHOSolution(du_HO); }
+         lo_solver->CalcLOSolution(u, du_LO);
+         dofs.ComputeElementsMinMax(u, dofs.xe_min, dofs.xe_max);
+         dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
+         check_violation(pfes, u, dt, du_LO, dofs.xi_min, dofs.xi_max, "LimitMult LO u", 1e-12, nullptr);
+         check_violation(pfes, u, dt, d_u, dofs.xi_min, dofs.xi_max, "LimitMult FCT solution u", 1e-12, nullptr);
+      }
    }
    else
    {
@@ -307,7 +363,9 @@ void AdvectionOperator::LimitMult(const Vector &X, Vector &Y) const
       lo_solver->CalcLOSolution(u, du_LO);
       dofs.ComputeElementsMinMax(u, dofs.xe_min, dofs.xe_max);
       dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
+      if (verify_bounds) { check_violation(pfes, u, dt, du_LO, dofs.xi_min, dofs.xi_max, "LimitMult LO u", 1e-12, nullptr); } // :1824-1828
       fct_solver->CalcFCTSolution(u, lumpedM, du_HO, du_LO, dofs.xi_min, dofs.xi_max, d_u);
+      if (verify_bounds) { check_violation(pfes, u, dt, d_u, dofs.xi_min, dofs.xi_max, "LimitMult FCT solution u", 1e-12, nullptr); } // :1833-1837
       UpdateTimeStepEstimate(u, du_LO, dofs.xi_min, dofs.xi_max); // remhos.cpp:1839-1842 (no-op with a fixed dt)
    }
    if (!product) { return; }
@@ -623,6 +681,9 @@ extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, i
          if (cfg->ho_type == 2) { RMH_CALL(rmh_set_mass_tol(ctx, 1e-12, 0.0, 500)); }
       }
       AdvectionOperator adv(pfes, dofs, ho_solver, lo_solver, fct_solver, (ps || idp) && cfg->fused != 0 && cc.lo_type == 5, ps);
+      const bool vb = cfg->verify_bounds != 0;
+      adv.verify_bounds = vb;         // remhos.cpp:1115-1116
+      fct_solver->verify_bounds = vb;
 
       // Primary scalar field is u; for product remap we also evolve us (remhos.cpp:875-904): S = [u | us]
       Vector S((ps ? 2 : 1) * vsize);
@@ -693,8 +754,59 @@ extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, i
       unsigned long long tok_u = 0;
       Vector Sold(dtc ? vsize : 0);
       int repeats = 0;
+      // -vb: global extrema of u (GetMinMax, remhos.cpp:1124) and of s = us / u on its active dofs (ComputeMinMaxS,
+      // remhos_sync.cpp:116-140) -- element extrema on the device, the ne values reduced on the host (a debug mode)
+      Vector vb_du(vb && fused ? vsize : 0), vb_s(vb && ps ? vsize : 0);
+      bool *vb_flags = nullptr;
+      if (vb && ps) { HIP_CALL(hipMalloc((void **)&vb_flags, (size_t)cd.ne_owned + vsize)); }
+      std::vector<double> h_emin(vb ? cd.ne_owned : 0), h_emax(vb ? cd.ne_owned : 0);
+      auto global_minmax = [&](const Vector &v, Array<bool> *el, Array<bool> *df, double &lo, double &hi)
+      {
+         dofs.ComputeElementsMinMax(v, dofs.xe_min, dofs.xe_max, el, df);
+         dofs.xe_min.CopyToHost(h_emin.data());
+         dofs.xe_max.CopyToHost(h_emax.data());
+         lo = INFINITY;
+         hi = -INFINITY;
+         for (int e = 0; e < cd.ne_owned; e++) { lo = std::fmin(lo, h_emin[e]); hi = std::fmax(hi, h_emax[e]); }
+         lo = reduce(lo, 1);
+         hi = reduce(hi, 2);
+      };
+      auto s_minmax = [&](double &lo, double &hi)
+      {
+         Vector us(S.ReadWrite() + vsize, vsize);
+         Array<bool> el(vb_flags, cd.ne_owned), df(vb_flags + cd.ne_owned, vsize);
+         ComputeRatio(pfes, us, u, vb_s, el, df);
+         global_minmax(vb_s, &el, &df, lo, hi);
+      };
+      double u_min_glob = 0., u_max_glob = 0., s_min_glob = 0., s_max_glob = 0.;
+      if (vb)
+      {
+         global_minmax(u, nullptr, nullptr, u_min_glob, u_max_glob);
+         if (ps) { s_minmax(s_min_glob, s_max_glob); }
+      }
       while (!done)
       {
+         // Monotonicity check for debug purposes mainly (remhos.cpp:1218-1262; forced_bounds holds for every LO solver here)
+         if (vb)
+         {
+            const double eps = 1e-10;
+            double u_min_new, u_max_new, s_min_new = s_min_glob, s_max_new = s_max_glob;
+            global_minmax(u, nullptr, nullptr, u_min_new, u_max_new);
+            if (ps) { s_minmax(s_min_new, s_max_new); }
+            const bool unit_range = cc.problem % 10 == 6 || cc.problem % 10 == 7;
+            const double ulo = unit_range ? 0.0 : u_min_glob, uhi = unit_range ? 1.0 : u_max_glob;
+            const double slo = unit_range ? 0.0 : s_min_glob, shi = unit_range ? 1.0 : s_max_glob;
+            char msg[96];
+            std::snprintf(msg, sizeof(msg), "Undershoot of %.6e", ulo - u_min_new);
+            RMH_VERIFY(u_min_new > ulo - eps, msg);
+            std::snprintf(msg, sizeof(msg), "Overshoot of %.6e", u_max_new - uhi);
+            RMH_VERIFY(u_max_new < uhi + eps, msg);
+            std::snprintf(msg, sizeof(msg), "Undershoot in s of %.6e", slo - s_min_new);
+            RMH_VERIFY(s_min_new > slo - eps, msg);
+            std::snprintf(msg, sizeof(msg), "Overshoot in s of %.6e", s_max_new - shi);
+            RMH_VERIFY(s_max_new < shi + eps, msg);
+            if (!unit_range) { u_min_glob = u_min_new; u_max_glob = u_max_new; } // (s_min / s_max stay the initial ones, like the reference's)
+         }
          double dt_real = std::min(dt, t_final - t);
          // This also resets the time step estimate when automatic dt is on (remhos.cpp:1150-1152)
          adv.SetDt(dt_real);
@@ -703,7 +815,27 @@ extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, i
             adv.ResetTimeStepRatio();
             Sold = u;
          }
-         if (fused)
+         if (fused && vb)
+         {
+            // the one-kernel stage under -vb: the kernel also hands out the limited rate, and the granular kernels form the
+            // dof bounds of the stage input for the check of remhos.cpp:1833-1837 (the LO rate never leaves the kernel:
+            // its check, :1824-1828, is the granular sequence's -- rmhd_config.fused = 0)
+            const int ne = cd.ne_owned;
+            auto stage = [&](const Vector &in, double ts, const double *xb, double a, double b, Vector &out)
+            {
+               RMH_CALL(rmh_setup(ctx, ts));
+               RMH_CALL(rmh_stage_fused_chain(ctx, in.Read(), dt_real, xb, a, b, dt_real, out.Write(), vb_du.Write(), 0, ne, 1, 0, nullptr));
+               dofs.ComputeElementsMinMax(in, dofs.xe_min, dofs.xe_max);
+               dofs.ComputeBounds(dofs.xe_min, dofs.xe_max, dofs.xi_min, dofs.xi_max);
+               check_violation(pfes, in, dt_real, vb_du, dofs.xi_min, dofs.xi_max, "LimitMult FCT solution u", 1e-12, nullptr);
+            };
+            stage(u, t, nullptr, 0.0, 1.0, y1);
+            stage(y1, t + dt_real, u.Read(), 3. / 4, 1. / 4, y2);
+            stage(y2, t + dt_real / 2, u.Read(), 1. / 3, 2. / 3, u); // (y_out may alias x_base)
+            tok_u = 0;
+            t += dt_real;
+         }
+         else if (fused)
          {
             // one kernel per RK stage (rmh_stage_fused): same stage times and combinations as
             // RK3SSPSolver::Step; input and output vectors of a stage differ
@@ -745,6 +877,7 @@ extern "C" int rmhd_run_rank(const rmhd_config *cfg, const char *comm_id_file, i
       }
       HIP_CALL(hipDeviceSynchronize());
       const auto w1 = std::chrono::steady_clock::now();
+      if (vb_flags) { (void)hipFree(vb_flags); }
 
       // final mass: remap uses the lumped mass at the final position (remhos.cpp:1382-1413)
       if (cd.exec_mode == 1)

@@ -640,4 +640,39 @@ __global__ void __launch_bounds__(256) dt_estimate_kernel(const double *x, const
 }
 
 
+// check_violation (remhos.cpp:1557-1594; -vb): the reference walks the dofs on the host and aborts at the FIRST one outside
+// [u_min - tol, u_max + tol].  Here every dof is tested in one streaming pass and the verdict is four device words:
+//   v[0] number of violating dofs, v[1] the smallest violating index (what the reference reports), v[2] / v[3] the largest
+//   over- / undershoot u_new - u_max, u_min - u_new among them (bit patterns of non-negative doubles order like the values).
+// du == null: u holds u_new itself (first overload); scale != null: the bounds are (u_min * scale, u_max * scale), the
+// ScaleProductBounds form of CalcFCTProduct's check (remhos_fct.cpp:117-153, 568-610); active: the dofs to look at, or null.
+__global__ void __launch_bounds__(256) check_violation_kernel(const double *u, double dt, const double *du, const double *umin,
+                                                              const double *umax, const double *scale, double tol,
+                                                              const unsigned char *active, size_t n, unsigned long long *v)
+{
+   unsigned long long cnt = 0, first = ~0ull;
+   double over = 0.0, under = 0.0;
+   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+   {
+      if (active && !active[i]) { continue; }
+      const double un = du ? u[i] + dt * du[i] : u[i];
+      const double s = scale ? scale[i] : 1.0;
+      const double lo = scale ? umin[i] * s : umin[i], hi = scale ? umax[i] * s : umax[i];
+      if (un + tol < lo || un > hi + tol)
+      {
+         cnt++;
+         first = first < i ? first : (unsigned long long)i;
+         over = fmax(over, un - hi);
+         under = fmax(under, lo - un);
+      }
+   }
+   if (cnt) // (a violation is the exception: no block-wide reduction on the path every launch takes)
+   {
+      atomicAdd(&v[0], cnt);
+      atomicMin(&v[1], first);
+      atomicMax(&v[2], (unsigned long long)__double_as_longlong(over));
+      atomicMax(&v[3], (unsigned long long)__double_as_longlong(under));
+   }
+}
+
 } // namespace rmh

@@ -173,6 +173,15 @@ inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
    return old;
 }
 
+inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v)
+{
+   unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+   while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+   return old;
+}
+
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
 inline int atomicMax(int *p, int v)
 {
    int old = __atomic_load_n(p, __ATOMIC_RELAXED);

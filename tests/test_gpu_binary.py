@@ -70,6 +70,16 @@ def test_binary_autotest_line():
     assert printed(out, "Max value u:") == e["max"]
 
 
+def test_binary_verify_bounds():
+    """-vb (remhos.cpp:324): the same run with the reference's in-loop guards on -- same printed numbers, exit code 0 -- through the
+    one-kernel stage, the reference's call sequence, and product remap with an IDP solver."""
+    base = ["-m", "data/cube01_hex.mesh", "-p", 10, "-rs", 2, "-o", 3, "-dt", -1, "-tf", 0.5, "-ms", 3, "-ho", 3, "-lo", 5, "-fct", 2]
+    for extra in ([], ["-unfused"], ["-ps", "-s", 13, "-dt", 0.01]):
+        a, b = run_binary(base + extra), run_binary(base + extra + ["-vb"])
+        for label in ("Final mass u:", "Max value u:"):
+            assert printed(a, label) == printed(b, label), (extra, label)
+
+
 def test_binary_rejects_what_it_does_not_implement():
     p = subprocess.run([EXE, "-ho", "1"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "implements" in p.stderr
