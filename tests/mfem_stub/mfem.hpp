@@ -19,6 +19,7 @@ class Array
 {
 public:
    Array();
+   Array(const Array &);
    explicit Array(int n);
    void SetSize(int n);
    int Size() const;
@@ -86,11 +87,14 @@ public:
 class GridFunction : public Vector
 {
 public:
+   GridFunction();
    FiniteElementSpace *FESpace() const;
 };
 class ParGridFunction : public GridFunction
 {
 public:
+   ParGridFunction();
+   explicit ParGridFunction(ParFiniteElementSpace *pf);
    ParFiniteElementSpace *ParFESpace() const;
    void ExchangeFaceNbrData();
    Vector &FaceNbrData();
@@ -100,5 +104,64 @@ class Device
 {
 public:
    static int GetId();
+};
+
+// ---- names that only the reference's OWN headers use (remhos_ho.hpp, remhos_lo.hpp, remhos_fct.hpp, remhos_tools.hpp), so that
+// tests/test_binding_compiles.py can put those headers themselves -- read from /root/reference where it exists -- in front of
+// the binding.  Complete types where the headers hold them by value or derive from them, forward declarations otherwise.
+typedef int HYPRE_Int;
+enum class FaceType : bool { Interior, Boundary };
+struct Geometry
+{
+   enum Type { INVALID = -1, POINT = 0, SEGMENT, TRIANGLE, SQUARE, TETRAHEDRON, CUBE, PRISM, PYRAMID };
+};
+class DenseMatrix
+{
+public:
+   DenseMatrix();
+};
+class DenseTensor
+{
+public:
+   DenseTensor();
+};
+class SparseMatrix
+{
+public:
+   SparseMatrix();
+   SparseMatrix(const SparseMatrix &);
+};
+class StopWatch
+{
+public:
+   StopWatch();
+};
+class socketstream;
+class IntegrationRule;
+class VectorCoefficient;
+class FiniteElement;
+class ElementTransformation;
+class FaceElementTransformations;
+class H1_FECollection
+{
+public:
+   H1_FECollection(int p, int dim);
+};
+class ParBilinearForm
+{
+public:
+   explicit ParBilinearForm(ParFiniteElementSpace *pf);
+};
+class DGMassInverse
+{
+public:
+   ~DGMassInverse();
+};
+class BilinearFormIntegrator
+{
+public:
+   virtual void AssembleElementMatrix(const FiniteElement &, ElementTransformation &, DenseMatrix &);
+   virtual void AssembleElementMatrix2(const FiniteElement &, const FiniteElement &, ElementTransformation &, DenseMatrix &);
+   virtual ~BilinearFormIntegrator();
 };
 } // namespace mfem

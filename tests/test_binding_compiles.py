@@ -3,9 +3,14 @@ must at least type-check: it is compiled (-fsyntax-only) against stub declaratio
 it uses (tests/mfem_stub/) -- MFEM itself is not in this image.  Also: the in-repo mirror of the interfaces keeps the
 reference's constructor signatures and members."""
 import os
+import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"  # present in the build container only; nothing of it travels
+needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "remhos_fct.hpp")), reason="no reference checkout on this box")
 
 
 def test_binding_header_compiles_against_stub():
@@ -39,3 +44,100 @@ void f(ParFiniteElementSpace &pfes, HOSolver &hos, const GridFunction *mv, Vecto
     cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+@needs_reference
+def test_binding_header_compiles_against_the_reference_headers():
+    """The same binding behind the reference's REAL remhos_ho.hpp / remhos_lo.hpp / remhos_fct.hpp / remhos_tools.hpp (included
+    from the checkout, only mfem.hpp and general/forall.hpp stubbed): the base classes, the virtual functions the plugins
+    override, TimingData, DofInfo and SmoothnessIndicator are then the reference's own declarations."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", REF,
+           "-I", os.path.join(ROOT, "tests", "mfem_stub"), os.path.join(ROOT, "tests", "mfem_stub", "compile_binding_ref.cpp")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+
+
+def _class_body(text, name):
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    m = re.search(r"\bclass\s+%s\b[^;{]*\{" % name, text)
+    assert m, name
+    depth, i = 1, m.end()
+    while depth:
+        depth += {"{": 1, "}": -1}.get(text[i], 0)
+        i += 1
+    return text[m.end():i - 1]
+
+
+def _signatures(text, name):
+    """{function name: normalised signature} of the member functions and constructors a class DECLARES at its top level:
+    return type, parameter TYPES (names dropped) and cv-qualifier -- what an override has to repeat."""
+    body = _class_body(text, name)
+    flat, depth = [], 0
+    for ch in body:  # bodies of inline functions removed
+        if ch == "{":
+            depth += 1
+            flat.append(";")
+        elif ch == "}":
+            depth -= 1
+        elif depth == 0:
+            flat.append(ch)
+    out = {}
+    for stmt in "".join(flat).split(";"):
+        stmt = re.sub(r"\b(public|protected|private)\s*:", " ", stmt)
+        stmt = " ".join(stmt.split())
+        m = re.match(r"(.*?)(~?\b\w+)\s*\(", stmt)
+        if not m or m.group(2) in ("MFEM_ABORT", "MFEM_VERIFY", "RMH_VERIFY"):
+            continue
+        ret, fn = m.group(1).strip(), m.group(2)
+        depth, j = 1, m.end()
+        while depth and j < len(stmt):  # the parameter list: up to the parenthesis that closes the first one
+            depth += {"(": 1, ")": -1}.get(stmt[j], 0)
+            j += 1
+        params, tail = stmt[m.end():j - 1], stmt[j:]
+        types = []
+        for prm in (params.split(",") if params.strip() else []):
+            prm = re.sub(r"=.*$", "", prm).strip()                                               # default value
+            prm = re.sub(r"\s*\b\w+$", "", prm) if re.search(r"[\s&*]\w+$", prm) else prm   # parameter name
+            types.append(prm.replace(" ", "").replace("double", "real_t"))
+        out[fn] = (ret.replace("virtual", "").replace(" ", "").replace("double", "real_t"), tuple(types),
+                   bool(re.match(r"\s*const\b", tail)))
+    return out
+
+
+@needs_reference
+def test_mirror_signatures_equal_the_reference_headers():
+    """include/remhos_amd/solvers.hpp against the reference's headers, declaration by declaration: every virtual function and
+    constructor of the abstract HOSolver / LOSolver / FCTSolver (remhos_ho.hpp:29-42, remhos_lo.hpp:28-44, remhos_fct.hpp:31-90)
+    and of the concrete MassBasedAvg / ClipScaleSolver (remhos_lo.hpp:87-109, remhos_fct.hpp:137-155) has the same return type,
+    parameter types and constness in the mirror -- so a drift of the stub restatement (tests/mfem_stub/remhos_interfaces.hpp) or
+    of the mirror from the reference cannot go unseen.  The stub restatement itself is held to the same comparison."""
+    mirror = open(os.path.join(ROOT, "include", "remhos_amd", "solvers.hpp")).read()
+    stub = open(os.path.join(ROOT, "tests", "mfem_stub", "remhos_interfaces.hpp")).read()
+    checked = 0
+    for header, classes in (("remhos_ho.hpp", ["HOSolver"]), ("remhos_lo.hpp", ["LOSolver", "MassBasedAvg"]),
+                            ("remhos_fct.hpp", ["FCTSolver", "ClipScaleSolver"])):
+        ref = open(os.path.join(REF, header)).read()
+        for cls in classes:
+            want = _signatures(ref, cls)
+            assert want, cls
+            for other, label in ((mirror, "solvers.hpp"), (stub, "remhos_interfaces.hpp")):
+                if label == "remhos_interfaces.hpp" and cls == "ClipScaleSolver":
+                    continue  # (the stub restates the abstract classes and MassBasedAvg only)
+                got = _signatures(other, cls)
+                for fn, sig in want.items():
+                    # (non-virtual helpers of the reference's implementation, folded into kernels here: rmh_lo_massavg,
+                    # rmh_fct_product)
+                    if fn.startswith("~") or fn in ("MassesAndVolumesAtPosition", "CalcCompatibleLOProduct", "ScaleProductBounds"):
+                        continue
+                    assert fn in got, (label, cls, fn, sorted(got))
+                    assert got[fn] == sig, (label, cls, fn, got[fn], sig)
+                    checked += 1
+    assert checked >= 20
+    # the data members a caller sets through the base classes (remhos.cpp:1115-1116, 1550-1552)
+    for cls, members in (("HOSolver", ["TimingData *timer"]), ("LOSolver", ["TimingData *timer"]),
+                         ("FCTSolver", ["TimingData *timer", "bool verify_bounds"])):
+        for text in (mirror, stub):
+            body = " ".join(_class_body(text, cls).split())
+            for mem in members:
+                assert mem in body, (cls, mem)
