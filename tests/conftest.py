@@ -22,3 +22,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "sanitizer" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """worst stage-vector error per order of this session (tests/helpers.py::check_rel) -> gpurun_out/rel_measured.json"""
+    import json
+
+    from tests.helpers import REL, REL_MEASURED
+
+    if not REL_MEASURED:
+        return
+    out = {str(p): {"worst": v[0], "where": v[1], "tolerance": REL[p]} for p, v in sorted(REL_MEASURED.items())}
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "rel_measured.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    print("\nworst stage-vector error per order:", {k: f"{v['worst']:.2e}" for k, v in out.items()})

@@ -45,3 +45,22 @@ def layout_from_oracle(r):
 def perturbed(u):
     """make the field generic (keeps it deterministic: no RNG)"""
     return u + 0.01 * np.sin(np.arange(u.size, dtype=np.float64).reshape(u.shape))
+
+
+# ---- the ONE per-order tolerance of a stage vector (du_HO, du_LO, du, y) against the oracle, relative to the vector's max norm --------
+# The oracle solves the element mass systems by dense factorisation + extended-precision refinement (exact to FP64 round-off); the HIP
+# path -- like the reference's DGMassInverse -- solves in the Gauss-Legendre nodal basis and maps back to Bernstein coefficients, which
+# amplifies round-off by cond(C_1d)^3.  The table is ~3 x the worst value measured over EVERY case of the -m gpu suite (each comparison
+# reports through check_rel; the session's worst per order is written to gpurun_out/rel_measured.json, the numbers of record are in
+# DESIGN.md section 4).  What this slack cannot hide is held tight elsewhere: K u through the oracle's dense M (5e-14), bounds
+# bit-exact, the limiter on the device's own du_HO (1e-12: tests/test_gpu_parity.py::test_limiter_tight).
+REL = {1: 1e-12, 2: 1e-12, 3: 5e-10, 4: 5e-9, 5: 1e-7, 6: 5e-7}
+REL_MEASURED = {}  # order -> (worst error seen this session, where)
+
+
+def check_rel(p, err, where, scale=1.0):
+    """assert err < scale * REL[p]; remembers the session's worst err / scale per order"""
+    worst = REL_MEASURED.get(p, (0.0, ""))
+    if err / scale > worst[0]:
+        REL_MEASURED[p] = (float(err / scale), where)
+    assert err < scale * REL[p], (where, p, err, scale * REL[p])

@@ -364,3 +364,23 @@ def test_2d_cpp_driver_bounds_type_1_and_dt_control_gpu(dev, mesh, prob, lo, dt,
     assert (res.steps, res.repeats) == (out["steps"], r.repeats), (res.steps, res.repeats, out["steps"], r.repeats)
     assert abs(res.dt - out["dt"]) <= 1e-12 * out["dt"]
     assert abs(res.final_mass - out["mass"]) <= 1e-12 * abs(out["mass"]) and abs(res.max_value - out["max"]) <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [1, 0])
+def test_2d_configs0_order_2_as_worded_gpu(dev, fused):
+    """BASELINE.json configs[0] exactly as worded -- "2D periodic-square transport, p=2, RK3": `-m data/periodic-square.mesh -p 5
+    -rs 3 -o 2 -dt 0.004 -tf 0.8 -ho 3 -lo 4 -fct 2`, 200 steps -- through rmhd_run on the MI355X: the ten digits of SURVEY.md
+    Appendix E's cross-check table (tests/golden/reference_kat.json "survey_cross_checks"; the oracle reproduces them in
+    tests/test_oracle_kat.py).  The autotest line of the same mesh (-o 3, out_baseline.dat:61-64) is
+    test_2d_cpp_driver_reference_autotest_gpu."""
+    import ctypes as C
+
+    from remhos_amd.case import RmhdResult, make_config
+
+    e = next(x for x in KAT["survey_cross_checks"] if x["mesh"] == "periodic-square" and x["order"] == 2)
+    cfg = make_config(e["mesh"], e["rs"], e["order"], e["problem"], e["dt"], e["t_final"], lo_type=e["lo"], fused=fused)
+    res = RmhdResult()
+    assert dev.lib.rmhd_run(C.byref(cfg), C.byref(res)) == 0, dev.lib.rmhd_last_error()
+    assert res.steps == 200
+    assert float(f"{res.final_mass:.10g}") == e["mass"] and float(f"{res.max_value:.10g}") == e["max"], (res.final_mass, res.max_value)

@@ -70,14 +70,44 @@ def test_binary_autotest_line():
     assert printed(out, "Max value u:") == e["max"]
 
 
-def test_binary_verify_bounds():
+def test_binary_verify_bounds_passes():
     """-vb (remhos.cpp:324): the same run with the reference's in-loop guards on -- same printed numbers, exit code 0 -- through the
-    one-kernel stage, the reference's call sequence, and product remap with an IDP solver."""
-    base = ["-m", "data/cube01_hex.mesh", "-p", 10, "-rs", 2, "-o", 3, "-dt", -1, "-tf", 0.5, "-ms", 3, "-ho", 3, "-lo", 5, "-fct", 2]
-    for extra in ([], ["-unfused"], ["-ps", "-s", 13, "-dt", 0.01]):
-        a, b = run_binary(base + extra), run_binary(base + extra + ["-vb"])
+    one-kernel stage, the reference's call sequence (-lo 4 at a step inside its CFL limit), and product remap with an IDP solver."""
+    lo4 = ["-m", "data/cube01_hex.mesh", "-p", 10, "-rs", 2, "-o", 3, "-dt", 0.01, "-tf", 0.5, "-ms", 3, "-ho", 3, "-lo", 4, "-fct", 2]
+    ps = ["-m", "data/cube01_hex.mesh", "-p", 10, "-rs", 0, "-o", 2, "-dt", 0.02, "-tf", 0.5, "-ms", 3, "-ho", 3, "-lo", 5, "-fct", 2, "-ps", "-s", 13]
+    for args in (lo4, lo4 + ["-unfused"], ps, ps + ["-unfused"]):
+        a, b = run_binary(args), run_binary(args + ["-vb"])
         for label in ("Final mass u:", "Max value u:"):
-            assert printed(a, label) == printed(b, label), (extra, label)
+            assert printed(a, label) == printed(b, label), (args, label)
+
+
+@pytest.mark.parametrize("extra,lo,info", [(["-unfused"], 4, "LimitMult LO u"), ([], 4, "LimitMult FCT solution u"), (["-unfused"], 5, "LimitMult LO u")],
+                         ids=["sequence-lo4", "one-kernel-lo4", "sequence-lo5"])
+def test_binary_verify_bounds_aborts_like_the_reference(extra, lo, info):
+    """-vb has to FAIL where the reference's would: on cube01_hex -rs 2 -o 3 the CFL step of -dt -1 is too long for the LO solvers on
+    the second RK stage of the first step -- the CPU oracle's LO update leaves the dof bounds there (-lo 4: dof 1322 by 7.27e-05;
+    -lo 5: dof 3204 by 2.82e-07), and with an LO update out of bounds ClipScale's rescaling step cannot hold them either.  The run
+    aborts like MFEM_ABORT (remhos.cpp:1570, 1590) with the reference's message, naming the dof the ORACLE finds."""
+    from oracle.remhos_oracle import Config, Remhos, check_violation
+
+    r = Remhos(Config(mesh="cube01_hex", rs=2, order=3, problem=10, dt=-1.0, t_final=0.5, lo=lo, max_steps=1))
+    keep = {}
+    k = r.stage(r.u, 0.0, r.dt, keep)
+    assert check_violation(r.u, keep["umin"], keep["umax"], dt=r.dt, du=keep["du_lo"])["count"] == 0  # (the first stage is clean)
+    y = r.u + r.dt * k
+    r.stage(y, r.dt, r.dt, keep)
+    want = check_violation(y, keep["umin"], keep["umax"], dt=r.dt, du=keep["du_lo" if "LO" in info else "du"])
+    assert want["count"] > 0 and want["over"] > 1e-7
+    p = subprocess.run([EXE, "-m", "data/cube01_hex.mesh", "-p", "10", "-rs", "2", "-o", "3", "-dt", "-1", "-tf", "0.5", "-ms", "3", "-ho", "3",
+                        "-lo", str(lo), "-fct", "2", "-vb"] + extra, capture_output=True, text=True, timeout=600)
+    assert p.returncode == -6, (p.returncode, p.stdout[-1000:], p.stderr[-1000:])  # SIGABRT
+    assert "Aborted due to bounds violation." in p.stderr
+    m = re.search(rf"{info} bounds violation: (\d+) (\S+) (\S+) (\S+)", p.stdout)
+    assert m, p.stdout[-1000:]
+    assert int(m.group(1)) == want["first"]
+    assert abs(float(m.group(3)) - want["first_value"]) < 1e-9 and abs(float(m.group(4)) - want["first_max"]) < 1e-12
+    n = re.search(r"\((\d+) dofs out of bounds; largest overshoot (\S+),", p.stdout)
+    assert int(n.group(1)) == want["count"] and abs(float(n.group(2)) - want["over"]) < 1e-3 * want["over"]
 
 
 def test_binary_rejects_what_it_does_not_implement():

@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-REL = {5: 5e-9, 6: 1e-7}  # per-stage tolerance of du_HO against the oracle (tests/test_gpu_parity.py)
+from tests.helpers import REL, check_rel  # noqa: E402  (the one per-order tolerance table: tests/helpers.py)
 
 
 @pytest.fixture(scope="module")
@@ -61,6 +61,6 @@ def test_stable_step_run_vs_oracle(lib, mesh, rs, p, prob, steps, pa):
           f"{(mass - out['mass']) / out['mass']:+.2e}, field max dev {err:.2e}, cg iterations {st.ctx.last_cg_iters()}")
     assert abs(mass - out["mass"]) <= 1e-12 * abs(out["mass"])
     # every stage contributes an error of the size of the per-stage tolerance times dt * |du|; bounded by REL[p] * steps
-    assert err < REL[p] * steps
+    check_rel(p, err, f"whole run {mesh} rs{rs} prob{prob} {steps} steps", scale=steps)
     assert abs(umax - out["max"]) <= REL[p] * steps
     st.close()

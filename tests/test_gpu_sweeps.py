@@ -7,7 +7,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-REL = {1: 1e-12, 2: 1e-12, 3: 5e-10, 4: 5e-9, 5: 1e-7, 6: 2e-7}  # per-stage tolerance: cond-limited local mass solve
+from tests.helpers import check_rel  # noqa: E402  (the one per-order tolerance table: tests/helpers.py)
+
 MESHES = {"remap-cube01": ("cube01_hex", 10, 1), "transport-periodic": ("periodic-cube", 0, 0), "remap-periodic": ("periodic-cube", 10, 0)}
 
 
@@ -88,7 +89,7 @@ def test_sweep_one_kernel_stage(lib, p, lo, bt, mesh_key):
     if lo != 5 and p < 2:
         pytest.skip("residual-distribution LO solvers need order >= 2 (remhos.cpp:748-760)")
     for name, err in one_stage(lib, p, lo, bt, mesh_key, granular=False).items():
-        assert err < REL[p], (name, err)
+        check_rel(p, err, f"sweeps {name}")
 
 
 @pytest.mark.parametrize("mesh_key", ["remap-cube01", "transport-periodic"])
@@ -99,14 +100,14 @@ def test_sweep_granular_entry_points(lib, p, lo, bt, mesh_key):
     """the same stage through rmh_ho_apply + LO solver + rmh_limit_fused(_lo), and through the reference's call sequence
     (elem_minmax, bounds, fct_clipscale): 48 combinations"""
     for name, err in one_stage(lib, p, lo, bt, mesh_key, granular=True).items():
-        assert err < REL[p], (name, err)
+        check_rel(p, err, f"sweeps {name}")
 
 
 @pytest.mark.parametrize("p,lo", [(3, 5), (6, 5), (3, 4)])
 def test_sweep_with_mass_completion(lib, p, lo):
     """converged solve + Jacobi step + constant mode (rmh_set_mass_completion): the same tolerances hold"""
     for name, err in one_stage(lib, p, lo, 0, "remap-cube01", granular=False, completion=True).items():
-        assert err < REL[p], (name, err)
+        check_rel(p, err, f"sweeps {name}")
 
 
 @pytest.mark.parametrize("order,rs,lo", [(3, 3, 5), (2, 3, 5), (4, 2, 5), (6, 2, 5), (3, 2, 4)])
