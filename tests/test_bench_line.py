@@ -68,3 +68,33 @@ def test_multi_gpu_line_is_compact_too():
         full.pop(k)
     line = json.loads(bench.compact_line(full, "bench_detail_n8.json"))
     assert line["rccl_ranks"] == 8 and line["exchange"]["neighbour_ranks"] == 7 and line["detail"] == "bench_detail_n8.json"
+
+
+def test_compact_and_detail_agree_on_what_bounds_the_kernel():
+    """the compact record copies `bound` / `binds` from the full result (advisor, round 5: the two outputs contradicted each other):
+    `bound` is the roof the contract's achieved / peak / frac are priced against, `binds` the resource that limits the kernel"""
+    full = canned()
+    r = dict(full["roofline"])
+    r.pop("model", None)
+    r.update(bound="hbm", binds="fp64-valu", dram_frac=0.25, of_bound=0.36)  # this round's keys
+    full["roofline"] = r
+    line = json.loads(bench.compact_line(full))
+    assert line["roofline"]["bound"] == r["bound"] == "hbm" and line["roofline"]["binds"] == r["binds"] == "fp64-valu"
+    assert line["roofline"]["dram_frac"] == 0.25 and line["roofline"]["of_bound"] == 0.36
+    # a result of the earlier rounds (model / bound) reads the same way
+    old = json.loads(bench.compact_line(canned()))
+    assert old["roofline"]["bound"] == "hbm" and old["roofline"]["binds"] == "fp64-valu"
+
+
+def test_compact_line_never_exceeds_the_limit(capsys):
+    """after the optional blocks are gone the record is cut to the contract's fields -- and says so on stderr"""
+    full = canned()
+    full["strong"] = {f"leg{k}": {"value": 1.0, "note": "x" * 150} for k in range(60)}
+    full["cpu_baseline"]["sample_short"] = "y" * 5000
+    full["lo4"]["empty"] = None  # (an empty sub-block must not raise)
+    txt = bench.compact_line(full)
+    assert len(txt) < bench.COMPACT_LIMIT
+    line = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert "cutting it to the contract's fields" in capsys.readouterr().err
