@@ -215,6 +215,8 @@ def compact_line(out, detail_file="bench_detail.json"):
                             "ho_kernel_ms": g["ho_kernel"]["avg_launch_ms"],
                             "streaming": {k.replace("_kernel", ""): {"ms": v["avg_launch_ms"], "frac": v["frac"]}
                                           for k, v in g["streaming_kernels"].items()}}
+    if out.get("cpp_loop"):
+        line["cpp_loop"] = {k: out["cpp_loop"].get(k) for k in ("value", "ms_per_step", "avg_launch_ms", "vs_python_loop", "pass")}
     if out.get("configs0_2d"):
         line["configs0_2d"] = {k: {kk: v.get(kk) for kk in ("final_mass", "max_value", "value", "pass", "error") if kk in v}
                                for k, v in out["configs0_2d"].items() if isinstance(v, dict)}
@@ -226,7 +228,7 @@ def compact_line(out, detail_file="bench_detail.json"):
     line = _num(line)
     txt = json.dumps(line, separators=(",", ":"))
     if len(txt) >= COMPACT_LIMIT:  # never let the record outgrow the driver's tail again: drop the optional blocks, last first
-        for k in ("configs0_2d", "granular", "sustained", "lo4", "cube01_p4", "transport", "mass_check", "exchange"):
+        for k in ("configs0_2d", "granular", "sustained", "cpp_loop", "lo4", "cube01_p4", "transport", "mass_check", "exchange"):
             line.pop(k, None)
             txt = json.dumps(line, separators=(",", ":"))
             if len(txt) < COMPACT_LIMIT:
@@ -789,7 +791,7 @@ def config0_block(lib):
     return out
 
 
-def measure_cpp_loop(args, lib, world, rank, device, comm_file):
+def measure_cpp_loop(args, lib, world, rank, device, comm_file, extra_override=None):
     """N > 1: the C++ stage loop (rmhd_run_partitioned, remhos_amd/csrc/rmh_driver.hip) -- one process per GPU, the
     halo exchange as grouped RCCL send/recv inside the library, no Python between the launches (at N = 8 strong
     scaling a block's stage takes ~0.5 ms).  W warm-up steps, then K timed steps between two barriers (one-double
@@ -802,6 +804,8 @@ def measure_cpp_loop(args, lib, world, rank, device, comm_file):
     part = PART[world]
     weak = args.scaling == "weak" and world > 1
     extra = tuple(1 if (weak and part[d] == 2) else 0 for d in range(3))
+    if extra_override is not None:  # (the one-block reference run of a weak-scaling lattice: mass_check of the N > 1 line)
+        extra = tuple(extra_override)
     (rel, ab, mit, jac, fix), mass_tol = MASS_SOLVE[args.mass_solve]
     if args.mass_solve not in ("pa", "exact"):
         raise SystemExit("--gpus N > 1 runs the C++ loop: --mass-solve pa or exact")
@@ -834,12 +838,12 @@ def measure_cpp_loop(args, lib, world, rank, device, comm_file):
             "partition": "x".join(str(k) for k in part), "tile_rows": args.tile, "limiter": "inside the stage kernel", "dt": res.dt,
             "mass_cg_max_iters": res.cg_iters_max, "mass_solve": args.mass_solve, "mass_tol": mass_tol,
             "final_mass": res.final_mass, "max_value": res.max_value, "mass_loss": res.mass_loss,
-            "stage_loop": "C++ (rmhd_run_partitioned)", "setup_and_run_s": total_s,
+            "stage_loop": "C++ (rmhd_run_partitioned)", "setup_and_run_s": total_s, "rs_extra": list(extra),
             "comm_ranks": res.comm_ranks if comm_file else None,  # ncclCommCount of the library's communicator (None: no RCCL, one-GPU validation mode)
         },
         "roofline": {
             "kernel": f"rmh::ho_kernel2<{order}, {3 if args.lo in (3, 4) else 1}> (whole RK stage; interior + halo-shell launch)",
-            "bound": "fp64-valu", "model": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bound": "hbm", "binds": "fp64-valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_source": "PMC passes are single-GPU (profiles/)", "avg_launch_ms": 1e3 * ho_avg_s,
             "alg_bytes_per_launch": ho_bytes,
             "achieved_is": "ALGORITHMIC bytes of SURVEY 8(d) (matrix-free model) per GPU and stage / stage kernel time (max over ranks)",
@@ -894,6 +898,9 @@ def main():
                          "(profiles/r05_face_table.txt): 4 rows cut the stage kernel's HBM reads by 12 %% and cost 2.7 %% of its rate")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="N > 1, weak scaling: do not also run the strong-scaling leg (the same -rs mesh partitioned, BASELINE configs[3])")
+    ap.add_argument("--cpp-loop", action="store_true",
+                    help="N = 1: also time the C++ stage loop of the N > 1 runs (rmhd_run_partitioned) on the 1 x 1 x 1 partition "
+                         "(block `cpp_loop`; on by default in the full default run)")
     ap.add_argument("--py-loop", action="store_true",
                     help="N > 1: drive the stages from Python (remhos_amd/stepper.py over torch.distributed) instead of the C++ loop")
     args = ap.parse_args()
@@ -963,6 +970,27 @@ def main():
                     "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                     "rccl_ranks": out["config"].get("comm_ranks")}
             line.update({k: v for k, v in out.items() if k not in ("value", "ms_per_step")})
+            # mass_check of an N > 1 line: the result of a partitioned run does not depend on the partition (tests/test_dist_gloo.py,
+            # tests/test_gpu_exchange.py: bit-identical to one block), so rank 0 repeats a leg as ONE block with the same C++ loop and
+            # compares the final masses -- the strong leg's mesh (the -rs mesh: always fits one GPU); the weak leg's too where it is
+            # small enough to be set up on one GPU in seconds (validation runs; a full -rs 5 block per rank is not repeated)
+            checks = {}
+            for leg_name, leg, leg_args in (("strong", strong, None), (args.scaling, out, args)):
+                if leg is None or leg_name in checks or leg["config"]["global_dofs"] > 80e6:
+                    continue
+                a1 = copy.copy(args)
+                a1.scaling = "strong"
+                ref = measure_cpp_loop(a1, lib, 1, 0, 0 if one_gpu else local_rank, None, extra_override=leg["config"]["rs_extra"])
+                if ref is None:
+                    continue
+                m1, mn = ref["config"]["final_mass"], leg["config"]["final_mass"]
+                checks[leg_name] = {"one_block_final_mass": m1, "final_mass": mn, "mass_rel_dev": (mn - m1) / m1, "identical": bool(mn == m1),
+                                    "pass": bool(abs(mn - m1) <= 1e-12 * abs(m1))}
+            if checks:
+                first = checks.get(args.scaling) or next(iter(checks.values()))
+                line["mass_check"] = {"mass_rel_dev": first["mass_rel_dev"], "field_max_dev": None, "pass": all(c["pass"] for c in checks.values()),
+                                      "against": "the same leg run as ONE block by the same C++ loop on rank 0 (final mass; partition independence)",
+                                      "legs": checks}
             if strong is not None:
                 line["strong_detail"] = strong
                 line["strong"] = {"workload": _short_workload(strong["config"]["workload"]), "value": strong["value"],
@@ -1102,6 +1130,18 @@ def main():
 
     config0 = config0_block(lib) if (extras and default_case and world == 1) else None
 
+    cpp_loop = None
+    if world == 1 and rank == 0 and (args.cpp_loop or (extras and default_case)) and args.mass_solve in ("pa", "exact"):
+        # the stage loop `--gpus N > 1` runs (rmhd_run_partitioned, C++) on the 1 x 1 x 1 partition of the same workload: the N = 1 point
+        # of a scaling curve measured by ONE driver end to end (the headline above is the Python Stepper's loop around the same kernel)
+        c1 = measure_cpp_loop(args, lib, 1, 0, local_rank, None)
+        if c1 is not None:
+            cpp_loop = {"value": c1["value"], "ms_per_step": c1["ms_per_step"], "avg_launch_ms": c1["roofline"]["avg_launch_ms"],
+                        "final_mass": c1["config"]["final_mass"], "stage_loop": c1["config"]["stage_loop"],
+                        "vs_python_loop": c1["value"] / main_res["value"],
+                        # the two loops launch the same kernels in the same order on the same data: the same final mass
+                        "pass": bool(abs(c1["config"]["final_mass"] - main_res["config"]["final_mass"]) <= 1e-13 * abs(main_res["config"]["final_mass"]))}
+
     lo4 = None
     if extras and default_case and args.lo == 5:
         # the LO solver BASELINE.json's north_star names: subcell residual distribution (-lo 4) in the one-kernel stage
@@ -1155,6 +1195,8 @@ def main():
             out["granular"] = granular
         if config0 is not None:
             out["configs0_2d"] = config0
+        if cpp_loop is not None:
+            out["cpp_loop"] = cpp_loop
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, args.order, args.rs, args.mass_solve)
         emit(out, args.gpus)
