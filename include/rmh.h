@@ -111,8 +111,11 @@ const char *rmh_version(void);
 /* All work of ctx is enqueued on `hip_stream` (a hipStream_t; NULL = default stream). */
 int rmh_set_stream(rmh_ctx *ctx, void *hip_stream);
 
-/* A non-blocking stream for a context whose kernels leave `reserve_cus` compute units of `device` alone
- * (hipExtStreamCreateWithCUMask; 0 = an ordinary non-blocking stream).  Why: the halo exchange of a partitioned stage
+/* A stream for a context whose kernels leave `reserve_cus` compute units of `device` alone.  reserve_cus = 0: an ordinary
+ * NON-BLOCKING stream (hipStreamNonBlocking).  reserve_cus > 0: hipExtStreamCreateWithCUMask, which has no flags argument and
+ * makes a default-flag, i.e. BLOCKING stream: work on it synchronises implicitly with the NULL stream (synchronous hipMemcpy,
+ * kernels a caller launches on stream 0) -- an ordering and performance property only, results are the same; the library itself
+ * launches nothing on the NULL stream after rmh_create (tests/test_gpu_stream.py asserts both flag values).  Why: the halo exchange of a partitioned stage
  * (rmh_exchange_begin, RCCL send / recv kernels on the library's exchange stream -- the reference's
  * ParGridFunction::ExchangeFaceNbrData inside K.Mult, remhos_ho.cpp:122) is launched microseconds AFTER the interior
  * stage kernel has taken every workgroup slot of the chip, and then only finds a CU as that kernel drains

@@ -526,6 +526,15 @@ extern "C" int rmh_debug_stamps(unsigned long long *out, int reset)
 }
 #endif
 
+// Ghost data (neighbour traces, ghost element extrema) is valid between rmh_exchange_end and the next rmh_exchange_begin,
+// and -- for the fused limiter and the one-kernel stage, which take the extrema of u from the ghost slots -- only if no
+// rmh_exchange_minmax_* has put another field's extrema there since.  Only element ranges that reach a ghost reader are held to
+// that: the interior range of a split stage is launched while the exchange is in flight.  The granular ghost readers
+// (rmh_ho_apply, rmh_lo_rd*: neighbour traces; rmh_bounds: whatever extrema the caller exchanged last, incl. another field's)
+// are refused while an exchange of u is in flight only.
+static const char *ghosts_not_ready(const rmh_ctx *c, int e_begin); // (both defined behind rmh_comm.hpp, which has struct Exchange)
+static const char *ghosts_in_flight(const rmh_ctx *c);
+
 extern "C" {
 
 const char *rmh_last_error(void) { return g_last_error.c_str(); }
@@ -726,6 +735,7 @@ int rmh_ho_apply(rmh_ctx *c, const double *u, double *du)
    if (!c || !u || !du) { return fail(RMH_ERR_INVALID, "null argument"); }
    RMH_ENTER(c);
    if (c->ng > 0 && !c->u_ghost) { return fail(RMH_ERR_STATE, "ghost values of u not set"); }
+   if (const char *why = ghosts_in_flight(c)) { return fail(RMH_ERR_STATE, why); }
    EventPair ep;
    int rc = timer_begin(c, 0, ep);
    if (rc) { return rc; }
@@ -841,6 +851,7 @@ int rmh_bounds(rmh_ctx *c, const double *xe_min, const double *xe_max, double *u
    RMH_ENTER(c);
    extrema_dropped(c);
    if (c->ng > 0 && (!c->gh_min || !c->gh_max)) { return fail(RMH_ERR_STATE, "ghost extrema not set"); }
+   if (const char *why = ghosts_in_flight(c)) { return fail(RMH_ERR_STATE, why); }
    const int wide = (((uintptr_t)u_min | (uintptr_t)u_max) & 15) == 0; // 16-byte stores
    if (c->dim == 2)
    {
@@ -930,10 +941,6 @@ int rmh_fct_product(rmh_ctx *c, const double *us, const double *m, const double 
    return timer_end(c, 3, ep);
 }
 
-// Ghost data (neighbour traces, ghost element extrema) is valid between rmh_exchange_end and the next rmh_exchange_begin,
-// and only if no rmh_exchange_minmax_* has put another field's extrema there since.  Only element ranges that reach a ghost
-// reader are held to that: the interior range of a split stage is launched while the exchange is in flight.
-static const char *ghosts_not_ready(const rmh_ctx *c, int e_begin); // (defined behind rmh_comm.hpp, which has struct Exchange)
 
 static int limit_fused_impl(rmh_ctx *c, const double *u, const double *du_ho, const double *du_lo, double dt, double *du,
                             const double *x_base, double a, double b, double dt_rk, double *y_out)
@@ -1292,6 +1299,13 @@ int rmh_set_mass_completion(rmh_ctx *c, int jacobi_step, int constant_mode)
 } // extern "C"
 
 #include "rmh_comm.hpp"
+
+static const char *ghosts_in_flight(const rmh_ctx *c)
+{
+   if (c->ng <= 0) { return nullptr; }
+   if (c->xch && c->xch->gen_begin != c->xch->gen_end) { return "the exchange of u is still in flight (rmh_exchange_end first): this call reads ghost data"; }
+   return nullptr;
+}
 
 static const char *ghosts_not_ready(const rmh_ctx *c, int e_begin)
 {

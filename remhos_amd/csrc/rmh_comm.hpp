@@ -600,7 +600,7 @@ int rmh_exchange_end(rmh_ctx *c)
    if (!x) { return fail(RMH_ERR_STATE, "rmh_exchange_end: no exchange plan"); }
    if (x->gen_begin != x->gen_end + 1) { return fail(RMH_ERR_STATE, "rmh_exchange_end without rmh_exchange_begin"); }
    RMH_ENTER(c);
-   if (x->peers.empty()) { x->gen_end++; return RMH_OK; }
+   if (x->peers.empty()) { x->gen_end++; c->gh_foreign = false; return RMH_OK; }
    bool any_local = false;
    for (PeerPlan &p : x->peers)
    {

@@ -47,7 +47,8 @@ def test_bench_gpus_n_on_one_gpu(n, partition):
     assert line["mass_check"]["pass"] is True, line["mass_check"]
     detail = json.load(open(os.path.join(ROOT, f"bench_detail_n{n}.json")))
     legs = detail["mass_check"]["legs"]
-    assert set(legs) == {"strong", "weak"} and all(v["identical"] for v in legs.values()), legs
+    # (the fields are bit-identical -- tests/test_gpu_exchange.py; the printed mass is a sum over blocks: equal up to its last bit)
+    assert set(legs) == {"strong", "weak"} and all(abs(v["mass_rel_dev"]) <= 5e-16 for v in legs.values()), legs
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["avg_launch_ms"] > 0
     # every rank keeps its own log
     logs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "bench_rank*.log")))

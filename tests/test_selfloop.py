@@ -198,7 +198,16 @@ def test_state_checks_of_the_exchange_and_the_split_stage(emulib):
     c.stage_fused_range(u, dt, z, nh, ne, False)
     with _pytest.raises(RuntimeError, match="in flight"):
         c.stage_fused_range(u, dt, z, 0, nh, True)
+    # (round 6, advisor: the granular ghost readers too -- rmh_ho_apply reads the neighbour traces, rmh_bounds the ghost extrema)
+    with _pytest.raises(RuntimeError, match="in flight"):
+        c.ho_apply(u, z)
+    xi_lo, xi_hi = torch.zeros_like(u), torch.zeros_like(u)
+    with _pytest.raises(RuntimeError, match="in flight"):
+        c.bounds(xe_min, xe_max, xi_lo, xi_hi)
     c.exchange_end()
+    c.ho_apply(u, z)  # valid ghosts: accepted; and rmh_bounds takes ANOTHER field's extrema from the ghost slots by design
+    c.exchange_minmax(xe_min, xe_max)
+    c.bounds(xe_min, xe_max, xi_lo, xi_hi)
     c.exchange_begin(u)
     c.stage_fused_range(u, dt, z, nh, ne, False)
     c.exchange_end()
