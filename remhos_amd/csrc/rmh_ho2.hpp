@@ -339,6 +339,17 @@ __device__ inline tabp_t<P> tab_view()
 #endif
    return t;
 }
+// the same view typed in the constant address space for any order (p <= 3 experiments: phases whose tables do not fit the scalar
+// registers beside the kernel's long-lived scalars -- y-leg: 3 x 24 doubles -- spill those to VGPR lanes, v_writelane / v_readlane)
+template <int P>
+__device__ inline tabp_const tab_view_c()
+{
+   tabp_const t = (tabp_const)c_tab[P];
+#if defined(__HIP_DEVICE_COMPILE__)
+   asm volatile("" : "+s"(t));
+#endif
+   return t;
+}
 #define RMH_TAB() tab_view<P>()
 #define RMH_TABK() (P >= RMH_VIEW_MINP ? tab_view<P>() : gtb)
 
@@ -1358,11 +1369,16 @@ tabp gt = gtb;
       for (int ix = 0; ix < D; ix++) { uu[ix] = src[ix]; }
       double *dst = RMH_W(eb) + oU1 + i2;
       split_outputs<SPL, Q>(wv, [&](auto qlo, auto qhi) {
-tabp gt = gtb;
+#ifndef RMH_PENCIL_VIEW3
+#define RMH_PENCIL_VIEW3 (P == 3) // (B and G, 2 x 24 doubles: 13 v_writelane + 12 v_readlane per wavefront otherwise; see the y-leg)
+#endif
+         constexpr bool PV3 = RMH_PENCIL_VIEW3 && P < RMH_VIEW_MINP;
+         std::conditional_t<PV3, tabp_const, tabp> gt = (std::conditional_t<PV3, tabp_const, tabp>)gtb;
+         if constexpr (PV3) { gt = tab_view_c<P>(); }
 #pragma unroll
          for (int q = qlo; q < qhi; q++)
          {
-            if (((q) - (qlo)) % G2D == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
+            if constexpr (!PV3) { if (((q) - (qlo)) % G2D == 0) { gt = RMH_TABK(); } } // (one view per group of outputs: GD)
             double ub = 0.0, ug = 0.0;
 #pragma unroll
             for (int ix = 0; ix < D; ix++)
@@ -1880,11 +1896,21 @@ tabp gt = gtb;
          // [r][qx][iy + D*iz]; in place: [r][qx + Q*iy][iz], the first D entries of the line just read
          double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz;
          constexpr int dstr = C::INPLACE_Y ? Q * D : 1;
-tabp gt = gtb;
+         // p = 3 (round 6): the three tables of this leg -- 3 x 24 doubles = 144 scalar registers -- do not fit beside the kernel's
+         // long-lived scalars, which the compiler parked in VGPR lanes around the phase (22 v_writelane + 22 v_readlane per
+         // wavefront: VALU instructions in an issue-bound phase).  One opaque view per tensor keeps 48 table registers live at a
+         // time: no scalar spills left in the kernel (with the x-pencils below: 2786 -> 2708 static VALU instructions, p = 3
+         // +1.2 %, lo 4 at p = 3 +1.9 %, p = 2 +-0: only p = 3; bit-identical)
+#ifndef RMH_YLEG_VIEW3
+#define RMH_YLEG_VIEW3 (P == 3)
+#endif
+         constexpr bool YV3 = RMH_YLEG_VIEW3 && P < RMH_VIEW_MINP;
+         std::conditional_t<YV3, tabp_const, tabp> gt = (std::conditional_t<YV3, tabp_const, tabp>)gtb;
+         if constexpr (YV3) { gt = tab_view_c<P>(); } // (one view per tensor)
 #pragma unroll
          for (int iy = 0; iy < D; iy++)
          {
-            if (((iy) - (0)) % GQ == 0) { gt = RMH_TABK(); } // (one view per group of outputs: GD)
+            if constexpr (!YV3) { if (((iy) - (0)) % GQ == 0) { gt = RMH_TABK(); } } // (one view per group of outputs: GD)
             double acc = 0.0;
 #pragma unroll
             for (int jy = 0; jy < Q; jy++)
