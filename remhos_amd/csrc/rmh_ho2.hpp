@@ -101,7 +101,18 @@ struct K2Cfg : TabLayout<P>
    static constexpr int NR = 3;
    // INPLACE_Y: the y-leg writes its D outputs over the first D of the Q inputs of its own line (R2 inside R3)
    static constexpr bool INPLACE_Y = RMH_INPLACE_Y || LO4;
-   static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * Q2 * D, PF = INPLACE_Y ? NR * Q2 * D : oR2 + NR * Q * D2;
+   // R3 = [r][qy][qx][iz]: QYS = stride of qy, R3S = tensor stride.  In place (R2 inside R3) the dof threads of the x-leg read
+   // R2[(jx, iy, iz)] with their lanes iy QYS doubles apart: Q D = 24 doubles = 48 dwords at p = 3 puts iy = 0, 2 and iy = 1, 3
+   // into the same banks -- 2-way conflicts on all 18 reads of a dof (tools/pmc_variants.sh, round 6: 6.4e7 of the lo 4 stage's
+   // 2.15e8 SQ_LDS_BANK_CONFLICT per launch sat in that leg).  Multi-element workgroups pad the line by RMH_RYPAD doubles; the
+   // work region has the room (PA > PF).
+   // (where Q D is a multiple of 8 doubles -- p = 3, p = 1; p = 2 has 15: its three iy already fall into different banks)
+#ifndef RMH_RYPAD
+#define RMH_RYPAD 1
+#endif
+   static constexpr int RYPAD = (INPLACE_Y && NB > 1 && (Q * D) % 8 == 0) ? RMH_RYPAD : 0;
+   static constexpr int QYS = Q * D + RYPAD, R3S = Q * QYS;
+   static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * R3S, PF = INPLACE_Y ? NR * R3S : oR2 + NR * Q * D2;
    // JS: plane stride of the intermediates of the back-transform (phase J) -- D^2 + D at p = 3, where 16 lines of an
    // element otherwise start in 4 LDS banks
 #ifndef RMH_JPAD
@@ -1846,9 +1857,9 @@ tabp gt = gtb;
 #pragma unroll
          for (int iz = 0; iz < D; iz++)
          {
-            R3[(0 * Q2 + cc) * D + iz] = r0[iz];
-            R3[(1 * Q2 + cc) * D + iz] = r1[iz];
-            R3[(2 * Q2 + cc) * D + iz] = r2[iz];
+            R3[0 * C::R3S + qy * C::QYS + qx * D + iz] = r0[iz];
+            R3[1 * C::R3S + qy * C::QYS + qx * D + iz] = r1[iz];
+            R3[2 * C::R3S + qy * C::QYS + qx * D + iz] = r2[iz];
          }
       }
       // (read here, not with the other rows of qy: it is first used by the mass apply and would only occupy registers
@@ -1881,21 +1892,21 @@ tabp gt = gtb;
 #pragma unroll
          for (int r = rlo; r < rhi; r++)
          {
-            const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
+            const double *R3 = RMH_W(eb) + oR3 + r * C::R3S + q * D + iz;
 #pragma unroll
-            for (int jy = 0; jy < Q; jy++) { inall[PRE ? r : 0][jy] = R3[Q * jy * D]; }
+            for (int jy = 0; jy < Q; jy++) { inall[PRE ? r : 0][jy] = R3[jy * C::QYS]; }
          }
       }
 #pragma unroll
       for (int r = rlo; r < rhi; r++)
       {
-         const double *R3 = RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz;
+         const double *R3 = RMH_W(eb) + oR3 + r * C::R3S + q * D + iz;
          double in[Q];
 #pragma unroll
-         for (int jy = 0; jy < Q; jy++) { in[jy] = PRE ? inall[PRE ? r : 0][jy] : R3[Q * jy * D]; }
+         for (int jy = 0; jy < Q; jy++) { in[jy] = PRE ? inall[PRE ? r : 0][jy] : R3[jy * C::QYS]; }
          // [r][qx][iy + D*iz]; in place: [r][qx + Q*iy][iz], the first D entries of the line just read
-         double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + (r * Q2 + q) * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz;
-         constexpr int dstr = C::INPLACE_Y ? Q * D : 1;
+         double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + r * C::R3S + q * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz;
+         constexpr int dstr = C::INPLACE_Y ? C::QYS : 1;
          // p = 3 (round 6): the three tables of this leg -- 3 x 24 doubles = 144 scalar registers -- do not fit beside the kernel's
          // long-lived scalars, which the compiler parked in VGPR lanes around the phase (22 v_writelane + 22 v_readlane per
          // wavefront: VALU instructions in an issue-bound phase).  One opaque view per tensor keeps 48 table registers live at a
@@ -1972,7 +1983,7 @@ tabp gt = gtb;
    constexpr bool PX = NB == 1 && C::INPLACE_Y && !LO4 && !(RMH_CBG_REG);
    if (PX)
    {
-      constexpr int rs2 = Q2 * D;
+      constexpr int rs2 = C::R3S;
       for (int k = ptid; k < D2; k += PNT)
       {
          const int iy = k / D, iz = k % D;
@@ -1998,7 +2009,7 @@ tabp gt = gtb;
 #pragma unroll
             for (int r = rlo; r < rhi; r++)
             {
-               double *line = RMH_W(0) + oR2 + r * rs2 + Q * iy * D + iz;
+               double *line = RMH_W(0) + oR2 + r * rs2 + iy * C::QYS + iz;
 #pragma unroll
                for (int jx = 0; jx < Q; jx++) { inx[PRE ? r : 0][jx] = line[jx * D]; }
                if (!PRE) { xleg_outputs(r, line, inx[0]); }
@@ -2006,7 +2017,7 @@ tabp gt = gtb;
             if (PRE)
             {
 #pragma unroll
-               for (int r = rlo; r < rhi; r++) { xleg_outputs(r, RMH_W(0) + oR2 + r * rs2 + Q * iy * D + iz, inx[PRE ? r : 0]); }
+               for (int r = rlo; r < rhi; r++) { xleg_outputs(r, RMH_W(0) + oR2 + r * rs2 + iy * C::QYS + iz, inx[PRE ? r : 0]); }
             }
          });
       }
@@ -2038,10 +2049,10 @@ tabp gt = gtb;
          double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
          if (PX)
          {
-            const int o2 = (ix + Q * idx[1]) * D + idx[2];
-            a0 = R2[0 * (Q2 * D) + o2];
-            a1 = R2[1 * (Q2 * D) + o2];
-            a2 = R2[2 * (Q2 * D) + o2];
+            const int o2 = ix * D + idx[1] * C::QYS + idx[2];
+            a0 = R2[0 * C::R3S + o2];
+            a1 = R2[1 * C::R3S + o2];
+            a2 = R2[2 * C::R3S + o2];
          }
 #pragma unroll
          for (int jx = 0; jx < (PX ? 0 : Q); jx++)
@@ -2050,8 +2061,8 @@ tabp gt = gtb;
             if (CBG_REG) { cBg[CBG_REG ? r : 0][jx] = bgx; }
             const double bx = stab[oB + jx * D + ix];
             // R2[r][jx][iy + D*iz] -- in place it sits at [r][jx + Q*iy][iz] of R3
-            const int o2 = C::INPLACE_Y ? (jx + Q * idx[1]) * D + idx[2] : jx * D2 + i2;
-            constexpr int rs2 = C::INPLACE_Y ? Q2 * D : Q * D2;
+            const int o2 = C::INPLACE_Y ? jx * D + idx[1] * C::QYS + idx[2] : jx * D2 + i2;
+            constexpr int rs2 = C::INPLACE_Y ? C::R3S : Q * D2;
             const double r0x = R2[0 * rs2 + o2];
             a0 += bgx * r0x;
             if (XB) { a3 += bx * r0x; } // the RD solver's z, Bernstein-tested along x (y and z follow below)
