@@ -112,7 +112,15 @@ struct K2Cfg : TabLayout<P>
 #endif
    static constexpr int RYPAD = (INPLACE_Y && NB > 1 && (Q * D) % 8 == 0) ? RMH_RYPAD : 0;
    static constexpr int QYS = Q * D + RYPAD, R3S = Q * QYS;
-   static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * R3S, PF = INPLACE_Y ? NR * R3S : oR2 + NR * Q * D2;
+   // R2 = [r][jx][iy + D iz] (not in place): R2S = stride of jx.  The y-leg's tasks (jx, iz) store their D outputs 8 iz + 2 R2S jx
+   // dwords apart: with R2S = D^2 = 16 doubles (p = 3) the four jx of a 16-lane group fall into the same banks -- 4-way conflicts
+   // on every store of the leg (round 4's attribution: the y-leg held a fifth of the p = 3 stage's bank conflicts).  One double
+   // of padding per jx spreads them over all banks; the x-leg reads jx R2S + i2 with consecutive i2 either way.
+#ifndef RMH_R2PAD
+#define RMH_R2PAD 1
+#endif
+   static constexpr int R2S = D2 + ((!INPLACE_Y && NB > 1 && D2 % 16 == 0) ? RMH_R2PAD : 0);
+   static constexpr int oR3 = 0, oR2 = INPLACE_Y ? 0 : NR * R3S, PF = INPLACE_Y ? NR * R3S : oR2 + NR * Q * R2S;
    // JS: plane stride of the intermediates of the back-transform (phase J) -- D^2 + D at p = 3, where 16 lines of an
    // element otherwise start in 4 LDS banks
 #ifndef RMH_JPAD
@@ -1870,6 +1878,12 @@ tabp gt = gtb;
    __syncthreads();
 
    RMH_STAMP(3);
+#if defined(RMH_NOP_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+   // diagnostic build only (tools/experiments/r06_jobs/nop_probe.sh): RMH_NOP_PROBE extra VALU issue slots per wavefront in an
+   // issue-bound phase -- how much a stage kernel's time responds to its VALU instruction count, order by order
+#pragma unroll
+   for (int i_ = 0; i_ < RMH_NOP_PROBE; i_++) { asm volatile("v_nop"); }
+#endif
    // ---- phase F: y-leg of the three test contractions (R2 overlays U1) ---------------------------------
    // (split workgroups: the three tensors are divided between the wavefronts -- r = 0, 1 / r = 2 -- not the outputs of
    // a line: in place, a line's outputs overwrite its own inputs)
@@ -1905,7 +1919,7 @@ tabp gt = gtb;
 #pragma unroll
          for (int jy = 0; jy < Q; jy++) { in[jy] = PRE ? inall[PRE ? r : 0][jy] : R3[jy * C::QYS]; }
          // [r][qx][iy + D*iz]; in place: [r][qx + Q*iy][iz], the first D entries of the line just read
-         double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + r * C::R3S + q * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * D2 + D * iz;
+         double *dst = C::INPLACE_Y ? RMH_W(eb) + oR3 + r * C::R3S + q * D + iz : RMH_W(eb) + oR2 + (r * Q + q) * C::R2S + D * iz;
          constexpr int dstr = C::INPLACE_Y ? C::QYS : 1;
          // p = 3 (round 6): the three tables of this leg -- 3 x 24 doubles = 144 scalar registers -- do not fit beside the kernel's
          // long-lived scalars, which the compiler parked in VGPR lanes around the phase (22 v_writelane + 22 v_readlane per
@@ -2061,8 +2075,8 @@ tabp gt = gtb;
             if (CBG_REG) { cBg[CBG_REG ? r : 0][jx] = bgx; }
             const double bx = stab[oB + jx * D + ix];
             // R2[r][jx][iy + D*iz] -- in place it sits at [r][jx + Q*iy][iz] of R3
-            const int o2 = C::INPLACE_Y ? jx * D + idx[1] * C::QYS + idx[2] : jx * D2 + i2;
-            constexpr int rs2 = C::INPLACE_Y ? C::R3S : Q * D2;
+            const int o2 = C::INPLACE_Y ? jx * D + idx[1] * C::QYS + idx[2] : jx * C::R2S + i2;
+            constexpr int rs2 = C::INPLACE_Y ? C::R3S : Q * C::R2S;
             const double r0x = R2[0 * rs2 + o2];
             a0 += bgx * r0x;
             if (XB) { a3 += bx * r0x; } // the RD solver's z, Bernstein-tested along x (y and z follow below)
