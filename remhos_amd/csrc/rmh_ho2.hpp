@@ -1167,6 +1167,11 @@ tabp gt = gtb;
          });
       }
    };
+#if defined(RMH_NOP_PROBE_A) && defined(__HIP_DEVICE_COMPILE__)
+   // (diagnostic build only: the same probe in the load phase, see RMH_NOP_PROBE)
+#pragma unroll
+   for (int i_ = 0; i_ < RMH_NOP_PROBE_A; i_++) { asm volatile("v_nop"); }
+#endif
    if (tid < 4 * NB) { s_acc[tid] = 0.0; } // reduction ring starts zeroed
    // ("any element still active" flags of the PCG loop: cleared here, in front of the first barrier -- the wavefronts reach
    // the prelude of the mass solve, where the first flag is raised, without a common barrier in between when their element
@@ -2698,17 +2703,32 @@ tabp gt = gtb;
          if (L.bounds_type == 0)
          {
             // box {lo, hi} per direction: low layer {-1, 0} -> entries (0, 1), inside {0} -> (1, 1), high layer
-            // {0, +1} -> (1, 2); the eight corners of the box are read unconditionally (duplicates are harmless)
-            const int sx = s3 % 3, sy = (s3 / 3) % 3, sz = s3 / 9;
-            const int x0 = (sx == 0) ? 0 : 1, x1 = (sx == 2) ? 2 : 1;
-            const int y0 = (sy == 0) ? 0 : 1, y1 = (sy == 2) ? 2 : 1;
-            const int z0 = (sz == 0) ? 0 : 1, z1 = (sz == 2) ? 2 : 1;
-#pragma unroll
-            for (int c = 0; c < 8; c++)
+            // {0, +1} -> (1, 2); the eight corners of the box are read unconditionally (duplicates are harmless).  Their
+            // byte offsets come packed from the table (TabLayoutQ::oBoxQ) instead of from ~45 integer instructions
+            if constexpr (C::ITAB)
             {
-               const int q = ((c & 1) ? x1 : x0) + 3 * ((c & 2) ? y1 : y0) + 9 * ((c & 4) ? z1 : z0);
-               lo = fmin(lo, smin[q]);
-               hi = fmax(hi, smax[q]);
+               const unsigned long long pk = (unsigned long long)__double_as_longlong(stab[C::oBoxQ + s3]);
+#pragma unroll
+               for (int c = 0; c < 8; c++)
+               {
+                  const int qb = (int)((pk >> (8 * c)) & 0xffu);
+                  lo = fmin(lo, *(const double *)((const char *)smin + qb));
+                  hi = fmax(hi, *(const double *)((const char *)smax + qb));
+               }
+            }
+            else
+            {
+               const int sx = s3 % 3, sy = (s3 / 3) % 3, sz = s3 / 9;
+               const int x0 = (sx == 0) ? 0 : 1, x1 = (sx == 2) ? 2 : 1;
+               const int y0 = (sy == 0) ? 0 : 1, y1 = (sy == 2) ? 2 : 1;
+               const int z0 = (sz == 0) ? 0 : 1, z1 = (sz == 2) ? 2 : 1;
+#pragma unroll
+               for (int c = 0; c < 8; c++)
+               {
+                  const int q = ((c & 1) ? x1 : x0) + 3 * ((c & 2) ? y1 : y0) + 9 * ((c & 4) ? z1 : z0);
+                  lo = fmin(lo, smin[q]);
+                  hi = fmax(hi, smax[q]);
+               }
             }
          }
          else
@@ -2832,8 +2852,13 @@ tabp gt = gtb;
          if (t < NB * D3)
          {
             const int eb = t / D3, i = t % D3;
-            const int bx = i % D, by = (i / D) % D, bz = i / D2;
-            const int s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
+            int s3; // class of the dof (low layer / inside / high layer per direction)
+            if constexpr (C::ITAB) { s3 = ((const unsigned char *)(stab + C::oCls))[i]; }
+            else
+            {
+               const int bx = i % D, by = (i / D) % D, bz = i / D2;
+               s3 = (bx == 0 ? 0 : (bx == P ? 2 : 1)) + 3 * (by == 0 ? 0 : (by == P ? 2 : 1)) + 9 * (bz == 0 ? 0 : (bz == P ? 2 : 1));
+            }
             const double lo = RMH_W(eb)[C::oLim + s3], hi = RMH_W(eb)[C::oLim + 27 + s3];
             const double ubar = UNI ? ubar_uni : fdiv(mass[r], vol[r]);
             if (!BOTH) { dlo[r] = fdiv_by(ubar - uu[r], L.dt, r_dt); } // MassBasedAvg; with RD dlo is already there

@@ -13,6 +13,7 @@
 //     basis Bernstein <-> Gauss-Legendre nodal.
 #pragma once
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace rmh
@@ -35,7 +36,18 @@ struct TabLayoutQ
    static constexpr int oBgE = N;           // BgE[side*D+k] GL nodal basis at xi = 0 / 1
    static constexpr int oLcu = oBgE + 2 * D; // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
    static constexpr int oCf = oLcu + 3 * D; // Cf[i*D+k] = C[k][i]: GL-tested -> Bernstein-tested moments (phi^B_i = sum_k C[k][i] l_k)
-   static constexpr int N2 = oCf + D * D;   // extended table (what the kernels copy to LDS)
+   // Integer tables of the fused limiter (dim = 3), packed into doubles so that they travel with the LDS copy -- index arithmetic a
+   // dof thread otherwise repeats per round (divisions by D, compare / select chains: ~15-25 VALU instructions each) becomes
+   // one LDS byte read:
+   //   BoxQ[s3]  the 8 corners of dof class s3's box in the 3 x 3 x 3 stencil (remhos_tools.cpp:432-495: offsets {-1, 0} on a low
+   //             layer, {0} inside, {0, +1} on a high layer, per direction), as byte offsets 8 q of the stencil entries -- 8 bytes
+   //   Cls[i]    the class s3 = cx + 3 cy + 9 cz of dof i (c = 0 low face layer, 1 interior, 2 high face layer) -- one byte per dof
+   // (not at p = 5: the 432 bytes they add to the stage kernel's 15 152 B of LDS cost it the tenth workgroup per CU --
+   // 26.8 k -> 25.7 k MDOFs*stage/s; p = 3 +0.4 %, p = 4 +1.1 %, p = 6 +1.2 %)
+   static constexpr bool ITAB = (P != 5);
+   static constexpr int oBoxQ = oCf + D * D;
+   static constexpr int oCls = oBoxQ + (ITAB ? 27 : 0);
+   static constexpr int N2 = oCls + (ITAB ? (D * D * D + 7) / 8 : 0); // extended table (what the kernels copy to LDS)
    // Transposed copies for the contractions that form ONE output per table COLUMN (y-leg of the test tensors, y-back leg of the
    // mass apply, q1-contraction of the face rows: sum over q of T[q*D+k] x[q] for fixed k).  With the q-major table each output
    // gathers Q separate entries through scalar loads -- 2 x 4 s_load_dwordx2 and two exposed waits per output at p = 5; from
@@ -217,6 +229,30 @@ inline std::vector<double> make_tables_q()
    for (int i = 0; i < D; i++)
    {
       for (int k = 0; k < D; k++) { tab[T::oCi + i * D + k] = C[i * D + k]; }
+   }
+   if (T::ITAB)
+   {
+      unsigned char box[27][8], cls[((D * D * D + 7) / 8) * 8] = {};
+      for (int s3 = 0; s3 < 27; s3++)
+      {
+         const int sc[3] = {s3 % 3, (s3 / 3) % 3, s3 / 9};
+         int lo[3], hi[3];
+         for (int c = 0; c < 3; c++) { lo[c] = (sc[c] == 0) ? 0 : 1; hi[c] = (sc[c] == 2) ? 2 : 1; }
+         for (int c = 0; c < 8; c++)
+         {
+            const int q = ((c & 1) ? hi[0] : lo[0]) + 3 * ((c & 2) ? hi[1] : lo[1]) + 9 * ((c & 4) ? hi[2] : lo[2]);
+            box[s3][c] = (unsigned char)(8 * q);
+         }
+         std::memcpy(&tab[T::oBoxQ + s3], box[s3], 8);
+      }
+      for (int i = 0; i < D * D * D; i++)
+      {
+         const int b[3] = {i % D, (i / D) % D, i / (D * D)};
+         int s3 = 0, w = 1;
+         for (int c = 0; c < 3; c++, w *= 3) { s3 += w * (b[c] == 0 ? 0 : (b[c] == P ? 2 : 1)); }
+         cls[i] = (unsigned char)s3;
+      }
+      std::memcpy(&tab[T::oCls], cls, sizeof(cls));
    }
    for (int q = 0; q < Q; q++)
    {
