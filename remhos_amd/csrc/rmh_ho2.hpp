@@ -167,7 +167,7 @@ struct K2Cfg : TabLayout<P>
    // split columns (p = 6, see ho_kernel2 phase C): w detJ of the columns that three lanes share lives in LDS, [column][qz]
    static constexpr bool CSPL = NT == 128 && NB == 1 && Q2 > 64 && Q % 3 == 0 && 3 * (Q2 - 64) <= 64 && 6 * Q <= 64;
    static constexpr int WDL = CSPL ? (Q2 - 64) * Q : 0;
-   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2 + PART + STI + WDL;
+   static constexpr int LDS_DOUBLES = NB * EL + 4 * NB + 8 + T::N2S + PART + STI + WDL;
    // LDS allocation granule: a 54 096-byte kernel ran two workgroups per CU, a 52 560-byte one three (measured:
    // 6.3 k vs 8.6 k MDOFs*stage/s); 2 KiB granules are consistent with that
    static constexpr int LDS_BYTES = (8 * LDS_DOUBLES + 2047) / 2048 * 2048;
@@ -524,7 +524,7 @@ __device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double
       // the sum is fixed by the dof -> (thread, round) map, which does not depend on where the element is)
       constexpr int NW = C::NT / 64;
       static_assert(C::NB != 1 || 4 * NW <= C::PART, "partial-sum ring does not fit");
-      double *slot = s_acc3 + 4 * C::NB + 8 + C::N2 + ring * NW;
+      double *slot = s_acc3 + 4 * C::NB + 8 + C::N2S + ring * NW;
       double x = 0.0;
 #pragma unroll
       for (int r = 0; r < C::DR; r++) { x += (tid + r * C::NT < C::D3) ? v[r] : 0.0; }
@@ -564,7 +564,7 @@ __device__ inline void batch_dot(const int tid, const double (&v)[C::DR], double
          if (t < C::NB * C::D3) { (lds + (t / C::D3) * C::EL)[C::oSB + t % C::D3] = v[r]; }
       }
       __syncthreads();
-      double *part = s_acc3 + 4 * C::NB + 8 + C::N2; // [NB][CH], behind the table copy
+      double *part = s_acc3 + 4 * C::NB + 8 + C::N2S; // [NB][CH], behind the table copy
       constexpr int CH = C::DOT_CH;
       if (C::D3 >= 64)
       {
@@ -669,8 +669,8 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
    {
       // (see batch_dot: both sums behind one barrier)
       constexpr int NW = C::NT / 64;
-      double *slotv = s_acc3 + 4 * C::NB + 8 + C::N2 + ring * NW;
-      double *slotw = s_acc3 + 4 * C::NB + 8 + C::N2 + ((ring + 1) % 4) * NW;
+      double *slotv = s_acc3 + 4 * C::NB + 8 + C::N2S + ring * NW;
+      double *slotw = s_acc3 + 4 * C::NB + 8 + C::N2S + ((ring + 1) % 4) * NW;
       double x = 0.0, y = 0.0;
 #pragma unroll
       for (int r = 0; r < C::DR; r++)
@@ -776,7 +776,7 @@ __device__ inline void batch_dot_keep2(const int tid, const double (&v)[C::DR], 
    else if (C::NB == 1)
    {
       constexpr int NW = C::NT / 64;
-      double *slot = s_acc3 + 4 * C::NB + 8 + C::N2;
+      double *slot = s_acc3 + 4 * C::NB + 8 + C::N2S;
       double *sv = slot + ring * NW, *sw = slot + ((ring + 1) % 4) * NW, *sz = slot + ((ring + 2) % 4) * NW;
       double x = 0.0, y = 0.0, q = 0.0;
 #pragma unroll
@@ -1019,8 +1019,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    double *s_acc = lds + NB * C::EL;   // [3][NB] ring of reduction buffers (+ NB spare)
    int *s_flag = (int *)(s_acc + 4 * NB); // [4] "any element still active" flags (ring of 2 used)
    double *stab = s_acc + 4 * NB + 8;  // table copy for lane-dependent indexing
-   int *s_sti = (int *)(stab + C::N2 + C::PART); // [NB][27] stencil indices (fused stage)
-   double *s_wdl = stab + C::N2 + C::PART + C::STI; // [Q2 - 64][Q] w detJ of the split columns (p = 6)
+   int *s_sti = (int *)(stab + C::N2S + C::PART); // [NB][27] stencil indices (fused stage)
+   double *s_wdl = stab + C::N2S + C::PART + C::STI; // [Q2 - 64][Q] w detJ of the split columns (p = 6)
 
    const int tid0 = threadIdx.x;
    static_assert(C::N3 <= RMH_TAB_STRIDE, "constant table too small");
@@ -1192,10 +1192,10 @@ tabp gt = gtb;
    load_batch<C, FUSED>(a, e0, tid, nbi, sti, gx0, gv, gu);
    // table copy for lane-dependent indexing: loaded behind the element data, stored with it (a copy loop at the top of
    // the kernel put a full memory round trip in front of the first element load)
-   constexpr int NLT = (C::N2 + NT - 1) / NT;
+   constexpr int NLT = (C::N2S + NT - 1) / NT;
    double gtab[NLT];
 #pragma unroll
-   for (int j = 0; j < NLT; j++) { gtab[j] = a.tab[min(tid + j * NT, C::N2 - 1)]; }
+   for (int j = 0; j < NLT; j++) { gtab[j] = a.tab[min(tid + j * NT, C::N2S - 1)]; }
    // RD solver: sub-mesh start positions and node velocities, in flight with everything else (a load-and-store loop
    // in front of the first barrier exposed five memory round trips: 18 % of the lo 4 workgroup's cycles)
    constexpr int NLSUB = LO4 ? (NB * 3 * D3 + NT - 1) / NT : 1;
@@ -1303,7 +1303,7 @@ tabp gt = gtb;
       if (k < NB * D3) { RMH_W(k / D3)[oU + k % D3] = gu[j]; }
    }
 #pragma unroll
-   for (int j = 0; j < NLT; j++) { if (tid + j * NT < C::N2) { stab[tid + j * NT] = gtab[j]; } }
+   for (int j = 0; j < NLT; j++) { if (tid + j * NT < C::N2S) { stab[tid + j * NT] = gtab[j]; } }
    if (FUSED)
    {
       // (in a register the index would be spilled through the column phase, and a pending scratch reload makes
@@ -2989,7 +2989,7 @@ tabp gt = gtb;
          else
          {
             // (the two ring slots the last element sums did NOT use: slower threads may still be reading those)
-            double *slo_ = s_acc + 4 * NB + 8 + C::N2 + ring * NW, *shi_ = s_acc + 4 * NB + 8 + C::N2 + ((ring + 1) % 4) * NW;
+            double *slo_ = s_acc + 4 * NB + 8 + C::N2S + ring * NW, *shi_ = s_acc + 4 * NB + 8 + C::N2S + ((ring + 1) % 4) * NW;
             if ((tid & 63) == 63) { slo_[tid >> 6] = lo; shi_[tid >> 6] = hi; }
             __syncthreads();
             if (tid == 0 && e0 < L.e_end)
@@ -3016,7 +3016,7 @@ tabp gt = gtb;
          {
             // one wavefront per 64-dof chunk, then the chunks of an element
             constexpr int CH = C::DOT_CH;
-            double *part = s_acc + 4 * NB + 8 + C::N2; // [NB][CH][2]
+            double *part = s_acc + 4 * NB + 8 + C::N2S; // [NB][CH][2]
             const int lane = tid & 63, wave = tid >> 6;
             for (int k = wave; k < NB * CH; k += NT / 64)
             {

@@ -31,23 +31,28 @@ struct TabLayoutQ
    static constexpr int oW = odL + Q * 3;   // w[q]       quadrature weights
    static constexpr int oBg = oW + Q;       // Bg[q*D+k]  GL nodal basis at quadrature points
    static constexpr int oBg2 = oBg + Q * D; // Bg2 = Bg^2 (Jacobi diagonal)
-   static constexpr int oCi = oBg2 + Q * D; // Ci[i*D+k]  inverse of C[k][i] = Bernstein_i(gl node k)
-   static constexpr int N = oCi + D * D;
-   static constexpr int oBgE = N;           // BgE[side*D+k] GL nodal basis at xi = 0 / 1
-   static constexpr int oLcu = oBgE + 2 * D; // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
-   static constexpr int oCf = oLcu + 3 * D; // Cf[i*D+k] = C[k][i]: GL-tested -> Bernstein-tested moments (phi^B_i = sum_k C[k][i] l_k)
+   static constexpr int oBgE = oBg2 + Q * D; // BgE[side*D+k] GL nodal basis at xi = 0 / 1
    // Integer tables of the fused limiter (dim = 3), packed into doubles so that they travel with the LDS copy -- index arithmetic a
    // dof thread otherwise repeats per round (divisions by D, compare / select chains: ~15-25 VALU instructions each) becomes
    // one LDS byte read:
    //   BoxQ[s3]  the 8 corners of dof class s3's box in the 3 x 3 x 3 stencil (remhos_tools.cpp:432-495: offsets {-1, 0} on a low
    //             layer, {0} inside, {0, +1} on a high layer, per direction), as byte offsets 8 q of the stencil entries -- 8 bytes
    //   Cls[i]    the class s3 = cx + 3 cy + 9 cz of dof i (c = 0 low face layer, 1 interior, 2 high face layer) -- one byte per dof
-   // (not at p = 5: the 432 bytes they add to the stage kernel's 15 152 B of LDS cost it the tenth workgroup per CU --
-   // 26.8 k -> 25.7 k MDOFs*stage/s; p = 3 +0.4 %, p = 4 +1.1 %, p = 6 +1.2 %)
-   static constexpr bool ITAB = (P != 5);
-   static constexpr int oBoxQ = oCf + D * D;
+   // (p = 3 +0.4 %, p = 4 +1.1 %, p = 6 +1.2 %; RMH_ITAB5: see N2S)
+#ifndef RMH_ITAB5
+#define RMH_ITAB5 1
+#endif
+   static constexpr bool ITAB = (P != 5) || RMH_ITAB5;
+   static constexpr int oBoxQ = oBgE + 2 * D;
    static constexpr int oCls = oBoxQ + (ITAB ? 27 : 0);
-   static constexpr int N2 = oCls + (ITAB ? (D * D * D + 7) / 8 : 0); // extended table (what the kernels copy to LDS)
+   // N2S: what the stage kernels (ho_kernel2) copy to LDS -- the entries they index by LANE.  The change-of-basis tables and the
+   // closed-uniform Lagrange rows behind it are only read through scalar loads there (round 6: out of the copy -- at p = 5 the
+   // 720 bytes are the difference between 10 and 11 resident workgroups per CU).
+   static constexpr int N2S = oCls + (ITAB ? (D * D * D + 7) / 8 : 0);
+   static constexpr int oCi = N2S;            // Ci[i*D+k]  inverse of C[k][i] = Bernstein_i(gl node k)
+   static constexpr int oLcu = oCi + D * D;   // Lcu[i*3+a]  mesh Lagrange basis at the closed-uniform points i/p
+   static constexpr int oCf = oLcu + 3 * D;   // Cf[i*D+k] = C[k][i]: GL-tested -> Bernstein-tested moments (phi^B_i = sum_k C[k][i] l_k)
+   static constexpr int N2 = oCf + D * D;     // extended table (what the other kernels copy to LDS)
    // Transposed copies for the contractions that form ONE output per table COLUMN (y-leg of the test tensors, y-back leg of the
    // mass apply, q1-contraction of the face rows: sum over q of T[q*D+k] x[q] for fixed k).  With the q-major table each output
    // gathers Q separate entries through scalar loads -- 2 x 4 s_load_dwordx2 and two exposed waits per output at p = 5; from
