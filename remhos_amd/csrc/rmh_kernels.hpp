@@ -152,8 +152,10 @@ __device__ inline double block_max(double v, double *s_red)
 // geometry from the 27 nodes x0 + t v like the stage kernel (rmh_ho2.hpp), without u.  Called a few times per run.
 // ---------------------------------------------------------------------------------------
 template <int P>
+// The nodes arrive in the form the context keeps on the device -- hierarchical along the directions of the bit mask `hier`
+// ((n0, n1 - n0, n2 - n0), see RMH_HIER in rmh_ho2.hpp; 0: nodal) -- and are put back into nodal form in LDS first.
 __global__ void __launch_bounds__(KCfg<P>::NT) lumped_mass_kernel(const double *x0, const double *vel, const double *gtab,
-                                                                  double t, int move, double *m)
+                                                                  double t, int move, int hier, double *m)
 {
    using C = KCfg<P>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT;
@@ -171,6 +173,17 @@ __global__ void __launch_bounds__(KCfg<P>::NT) lumped_mass_kernel(const double *
       sX[i] = move ? x + t * vel[(size_t)e * 81 + i] : x;
    }
    __syncthreads();
+   for (int dir = 2; dir >= 0; dir--) // (the host took the differences along x, then y, then z: undone in the reverse order)
+   {
+      if (!((hier >> dir) & 1)) { continue; }
+      const int st = dir == 0 ? 1 : (dir == 1 ? 3 : 9);
+      for (int i = tid; i < 81; i += NT)
+      {
+         const int a = ((i % 27) / st) % 3;
+         if (a > 0) { sX[i] += sX[i - a * st]; } // (entries with a = 0 are only read in this pass)
+      }
+      __syncthreads();
+   }
    // x-contraction of the nodes: sT1[((comp*2 + kind)*Q + qx)*9 + ay + 3*az], kind 0: L.X, 1: dL.X
    for (int k = tid; k < 6 * Q * 9; k += NT)
    {

@@ -54,7 +54,9 @@ def perturbed(u):
 # reports through check_rel; the session's worst per order is written to gpurun_out/rel_measured.json, the numbers of record are in
 # DESIGN.md section 4).  What this slack cannot hide is held tight elsewhere: K u through the oracle's dense M (5e-14), bounds
 # bit-exact, the limiter on the device's own du_HO (1e-12: tests/test_gpu_parity.py::test_limiter_tight).
-REL = {1: 1e-12, 2: 1e-12, 3: 5e-10, 4: 5e-9, 5: 1e-7, 6: 5e-7}
+# measured worst over the 415 tests of the -m gpu suite (round 6, gpurun_out/rel_measured.json): p = 1 3.6e-14, p = 2 2.5e-13, p = 3 6.5e-12
+# (golden stage_remap_p3_lo5_pa), p = 4 7.2e-11, p = 5 2.6e-9, p = 6 1.28e-7 (sweeps, lo 4 on the deformed cube01 mesh)
+REL = {1: 1e-12, 2: 1e-12, 3: 2e-11, 4: 2.5e-10, 5: 1e-8, 6: 4e-7}
 REL_MEASURED = {}  # order -> (worst error seen this session, where)
 
 
