@@ -2479,8 +2479,13 @@ tabp gt = gtb;
       }
       if (any) { raise_flag(&s_flag[0]); } // visible after the first barrier of the loop
    }
-   for (int it = 0; it < a.max_iter; it++)
-   {
+   // One PCG iteration; false: the loop is left.  The FIRST iteration is peeled (RMH_PCG_PEEL): under the -pa rule the bench meshes
+   // need one iteration at p = 3 -- as straight-line code it carries none of the register copies of a loop's back edge (the
+   // "tail" of the loop held 20 v_mov_b64 + 9 v_mov_b32 per trip, the exit trip included).
+#ifndef RMH_PCG_PEEL
+#define RMH_PCG_PEEL (NB > 1)
+#endif
+   auto pcg_iteration = [&](const int it) -> bool {
       RMH_STAMP(9);
       // Ad = M_g d
 #pragma unroll
@@ -2491,7 +2496,7 @@ tabp gt = gtb;
       }
       if (tid == 0) { s_flag[(it + 1) & 1] = 0; }
       __syncthreads();
-      if (!s_flag[it & 1]) { break; } // no element of the batch is active any more
+      if (!s_flag[it & 1]) { return false; } // no element of the batch is active any more
       RMH_STAMP(10);
       for (int k = ptid; k < NB * D2; k += PNT)
       {
@@ -2628,7 +2633,7 @@ tabp gt = gtb;
       {
 #pragma unroll
          for (int r = 0; r < DR; r++) { its[r] += act[r] ? 1 : 0; }
-         break;
+         return false;
       }
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // betanom = r.z
       RMH_STAMP(15);
@@ -2648,6 +2653,18 @@ tabp gt = gtb;
          any = any || act[r];
       }
       if (any) { raise_flag(&s_flag[(it + 1) & 1]); } // read after the first barrier of the next iteration
+      return true;
+   };
+   if (RMH_PCG_PEEL)
+   {
+      if (a.max_iter > 0 && pcg_iteration(0))
+      {
+         for (int it = 1; it < a.max_iter; it++) { if (!pcg_iteration(it)) { break; } }
+      }
+   }
+   else
+   {
+      for (int it = 0; it < a.max_iter; it++) { if (!pcg_iteration(it)) { break; } }
    }
 
    RMH_STAMP(6);
