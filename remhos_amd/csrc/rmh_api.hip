@@ -151,6 +151,15 @@ int ensure_face_table(rmh_ctx *c)
                       (const double *)c->d_vel, (const double *)c->d_tab, c->exec_mode == 1 ? 1 : 0,
                       (const int *)c->d_face_rows, c->d_fgeo);
    RMH_HIP(hipGetLastError());
+   // One node representation on the device (round 6).  The set-up kernels take the NODAL values -- the face speed table has to be
+   // the same bits on both sides of a shared face and for every partition of the mesh, and n0 + (n1 - n0) is not n1.  This was the
+   // last of them (the lo 4 sub-mesh is set up in rmh_create): the nodal arrays are released, what stays resident is the
+   // hierarchical form the stage kernels read (-1.15 GB at -rs 5); rmh_compute_lumped_mass restores nodal values in LDS.  (Once
+   // per context, at its first HO / stage launch: one stream synchronisation.)
+   RMH_HIP(hipStreamSynchronize(c->stream));
+   RMH_HIP(hipFree(c->d_x0));
+   RMH_HIP(hipFree(c->d_vel));
+   c->d_x0 = c->d_vel = nullptr;
    return 0;
 }
 
@@ -494,16 +503,6 @@ int create_device_state(rmh_ctx *c, const rmh_layout *L)
       RMH_HIP(hipGetLastError());
       RMH_HIP(hipDeviceSynchronize());
    }
-   // One node representation on the device (round 6).  The set-up kernels take the NODAL values -- the face speed table has to be
-   // the same bits on both sides of a shared face and for every partition of the mesh, and n0 + (n1 - n0) is not n1 -- so the
-   // table is made here, not at the first stage launch, and the nodal arrays are released: what stays resident is the
-   // hierarchical form the stage kernels read (-1.15 GB at -rs 5); rmh_compute_lumped_mass restores nodal values in LDS.
-   RMH_DISPATCH(c, rc = ensure_face_table<P>(c));
-   if (rc) { return rc; }
-   RMH_HIP(hipDeviceSynchronize());
-   RMH_HIP(hipFree(c->d_x0));
-   RMH_HIP(hipFree(c->d_vel));
-   c->d_x0 = c->d_vel = nullptr;
    RMH_HIP(hipMalloc((void **)&c->d_m, ne * c->ndof * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_xe_min, ne * sizeof(double)));
    RMH_HIP(hipMalloc((void **)&c->d_xe_max, ne * sizeof(double)));

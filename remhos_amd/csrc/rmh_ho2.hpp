@@ -1189,6 +1189,19 @@ tabp gt = gtb;
       const int feb = FMJ ? (fr % (NB * Q)) / Q : fr / (6 * Q), ff = FMJ ? fr / (NB * Q) : (fr % (6 * Q)) / Q;
       fri[jp] = a.face_rows[(size_t)min(e0 + feb, a.e_end - 1) * 6 + ff];
    }
+   // trace table entries of this thread's face-layer entries (TabLayoutQ::oTr): independent loads, issued in front of the
+   // neighbour indices they will be combined with
+#ifndef RMH_TRACE_TABLE
+#define RMH_TRACE_TABLE 1
+#endif
+   constexpr bool TRT = RMH_TRACE_TABLE;
+   unsigned trpk[NLN];
+#pragma unroll
+   for (int j = 0; j < NLN; j++)
+   {
+      trpk[j] = 0u;
+      if (TRT) { trpk[j] = ((const unsigned *)(a.tab + C::oTr))[min(tid + j * NT, NB * 6 * D2 - 1) % (6 * D2)]; }
+   }
    load_batch<C, FUSED>(a, e0, tid, nbi, sti, gx0, gv, gu);
    // table copy for lane-dependent indexing: loaded behind the element data, stored with it (a copy loop at the top of
    // the kernel put a full memory round trip in front of the first element load)
@@ -1243,17 +1256,31 @@ tabp gt = gtb;
       const int k = min(tid + j * NT, NB * 6 * D2 - 1);
       {
          const int r6 = k % (6 * D2);
-         const int f = r6 / D2, r = r6 % D2;
-         const int i1 = r % D, i2 = r / D;
-         const int c = f >> 1, side = f & 1;
-         const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
-         tr_own[j] = (k / (6 * D2)) * C::EL + oU + (side ? P * strc : 0) + i1 * str1 + i2 * str2;
+         int own_off, nbr_off, r;
+         if (TRT)
+         {
+            // (own face dof | opposite-layer dof of the neighbour | index in the layer: from the trace table)
+            own_off = (int)(trpk[j] & 1023u);
+            nbr_off = (int)((trpk[j] >> 10) & 1023u);
+            r = (int)(trpk[j] >> 20);
+         }
+         else
+         {
+            const int f = r6 / D2;
+            r = r6 % D2;
+            const int i1 = r % D, i2 = r / D;
+            const int c = f >> 1, side = f & 1;
+            const int strc = axis_stride<D>(c), str1 = axis_stride<D>(axis_next(c)), str2 = axis_stride<D>(axis_next2(c));
+            own_off = (side ? P * strc : 0) + i1 * str1 + i2 * str2;
+            nbr_off = (side ? 0 : P) * strc + i1 * str1 + i2 * str2;
+         }
+         tr_own[j] = (k / (6 * D2)) * C::EL + oU + own_off;
          tr_dst[j] = (k / (6 * D2)) * C::EL + oNb + r6;
          const int nb = max(nbi[j], 0);
          const double *un = (nb < a.ne_owned) ? a.u + (size_t)nb * D3 : a.u_ghost + (size_t)(nb - a.ne_owned) * a.gh_ustride;
          // the neighbour's opposite face layer (compact ghost records hold exactly that layer, ordered like this face:
          // rmh_exchange_setup)
-         const int off = (a.gh_compact && nb >= a.ne_owned) ? r : (side ? 0 : P) * strc + i1 * str1 + i2 * str2;
+         const int off = (a.gh_compact && nb >= a.ne_owned) ? r : nbr_off;
          const double v = un[off];
          gn[j] = nbi[j] >= 0 ? v : 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
       }
@@ -1276,8 +1303,11 @@ tabp gt = gtb;
          // the face rows multiply them by zero; straight-line loads either way: a.move is uniform over the launch)
          // (+3.8 % for transport at p = 3, remap +-0; not at p >= 4, where the extra scalar arithmetic of the 21-27 loads costs remap 0.4-0.7 %)
          const int mv = (a.move || P >= 4) ? 1 : 0;
+         // (three base pointers, compile-time offsets: with the index (k - (1 - mv) (k % 3)) Q formed per load, 12 of the 18 loads of a
+         // row carried a 64-bit address add of their own)
+         const double *fgk[3] = {fg, fg - (1 - mv) * Q, fg - 2 * (1 - mv) * Q};
 #pragma unroll
-         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fg[(k - (1 - mv) * (k % 3)) * Q]; }
+         for (int k = 0; k < 3 * Q; k++) { fgc[jp][k] = fgk[k % 3][k * Q]; }
       }
    }
    // diagnostic: the largest iteration count so far, read here -- behind the element loads, a uniform load whose

@@ -33,7 +33,7 @@ struct KCfg : TabLayout<P>
 // 1-D tables of every order in constant memory: compile-time indexed reads become scalar loads
 // (s_load) everywhere, including after barriers where the compiler no longer treats loads from
 // ordinary global memory as invariant.  Filled by rmh_create (identical for all contexts).
-constexpr int RMH_TAB_STRIDE = 720; // (>= TabLayout<6>::N3 = 707)
+constexpr int RMH_TAB_STRIDE = 864; // (>= TabLayout<6>::N3 = 854)
 __constant__ double c_tab[7][RMH_TAB_STRIDE];
 
 struct HoArgs

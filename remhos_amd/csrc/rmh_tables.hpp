@@ -60,7 +60,12 @@ struct TabLayoutQ
    static constexpr int oBgT = N2;            // BgT[k*Q+q]  = Bg[q*D+k]
    static constexpr int oBT = oBgT + D * Q;   // BT[i*Q+q]   = B[q*D+i]
    static constexpr int oBg2T = oBT + D * Q;  // Bg2T[k*Q+q] = Bg2[q*D+k]
-   static constexpr int N3 = oBg2T + D * Q;   // everything in constant memory / the global copy
+   // Trace table (dim = 3; global copy only, read per LANE in the load phase): for entry r6 = f D^2 + i1 + D i2 of an element's six
+   // face layers, packed into 32 bits: the own face dof's offset in the element | << 10 the offset of the same dof in the face
+   // neighbour's OPPOSITE layer | << 20 the dof's index in the layer.  What the load phase otherwise takes apart per entry -- face,
+   // side, axis strides, two mixed-radix offsets: ~25 integer instructions, three entries per lane.
+   static constexpr int oTr = oBg2T + D * Q;   // 6 D^2 ints = 3 D^2 doubles
+   static constexpr int N3 = oTr + 3 * D * D;  // everything in constant memory / the global copy
 };
 // dim = 3: Q = p + 3 (order 2p + 2*3 - 1); dim = 2: Q = p + 2 (order 2p + 2*2 - 1) -- SURVEY A.2
 template <int P>
@@ -258,6 +263,19 @@ inline std::vector<double> make_tables_q()
          cls[i] = (unsigned char)s3;
       }
       std::memcpy(&tab[T::oCls], cls, sizeof(cls));
+   }
+   {
+      std::vector<unsigned> tr(6 * D * D + 1, 0u);
+      const int st[3] = {1, D, D * D};
+      for (int r6 = 0; r6 < 6 * D * D; r6++)
+      {
+         const int f = r6 / (D * D), r = r6 % (D * D), i1 = r % D, i2 = r / D, c = f >> 1, side = f & 1;
+         const int strc = st[c], str1 = st[(c + 1) % 3], str2 = st[(c + 2) % 3];
+         const unsigned own = (unsigned)((side ? P * strc : 0) + i1 * str1 + i2 * str2);
+         const unsigned nbr = (unsigned)((side ? 0 : P) * strc + i1 * str1 + i2 * str2);
+         tr[r6] = own | nbr << 10 | (unsigned)r << 20;
+      }
+      std::memcpy(&tab[T::oTr], tr.data(), sizeof(unsigned) * 6 * D * D);
    }
    for (int q = 0; q < Q; q++)
    {
