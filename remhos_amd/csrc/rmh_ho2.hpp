@@ -328,6 +328,40 @@ __device__ inline double wave_sum(double v)
    return v;
 }
 
+// Two wavefront sums for the price of one (one-element workgroups, round 6): the half-wave swap puts the lower halves of both values
+// into lanes 0..31 and the upper halves into lanes 32..63, one addition folds the halves, and the five DPP steps of a 32-lane sum
+// reduce both at once: the total of a is valid in lane 31, that of b in lane 63.  17 instead of 36 cross-lane / add instructions.
+// (A fixed order, independent of where the element is -- but not wave_sum's: lane i and lane i + 32 meet first.)
+// Measured (A/B in one process, round 6): p = 6 (two wavefronts per element) +0.5 %, lo 4 at p = 6 +0.55 %, p = 4 +-0,
+// p = 5 -0.3 % -> on where an element spans more than one wavefront.
+#ifndef RMH_PACKED_SUMS
+#define RMH_PACKED_SUMS (NW > 1)
+#endif
+__device__ inline double wave_sum2(double a, double b)
+{
+   swap32(a, b);
+   double x = a + b;
+   x = dpp_add_all<0xB1>(x);
+   x = dpp_add_all<0x4E>(x);
+   x = dpp_add_all<0x141>(x);
+   x = dpp_add_all<0x140>(x);
+   x = dpp_add<0x142, 0xA>(x);
+   return x;
+}
+// the same for a minimum and a maximum (carried as the minimum of the negated values): min(a) in lane 31, -max(b) in lane 63
+__device__ inline double wave_min_negmax(double a, double b)
+{
+   double nb = -b;
+   swap32(a, nb);
+   double x = fmin(a, nb);
+   x = dpp_minmax<0xB1, 0xF, true>(x);
+   x = dpp_minmax<0x4E, 0xF, true>(x);
+   x = dpp_minmax<0x141, 0xF, true>(x);
+   x = dpp_minmax<0x140, 0xF, true>(x);
+   x = dpp_minmax<0x142, 0xA, true>(x);
+   return x;
+}
+
 // A fresh view of the constant table of order P.  Entries read through one view cannot be merged with (or
 // hoisted next to) reads through another.  At p >= 5 the compiler otherwise keeps every table entry of the
 // kernel live in scalar registers from its first use to its last and spills them to VGPR lanes (p = 6: more
@@ -679,11 +713,19 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
          x += in ? v[r] : 0.0;
          y += in ? w[r] : 0.0;
       }
-      x = wave_sum(x);
-      y = wave_sum(y);
+      if (RMH_PACKED_SUMS)
+      {
+         x = wave_sum2(x, y); // (total of v in lane 31, of w in lane 63)
+         y = x;
+      }
+      else
+      {
+         x = wave_sum(x);
+         y = wave_sum(y);
+      }
       if (NW == 1)
       {
-         const double tv1 = wave_bcast<63>(x), tw1 = wave_bcast<63>(y); // (one wavefront: see batch_dot)
+         const double tv1 = wave_bcast<(RMH_PACKED_SUMS ? 31 : 63)>(x), tw1 = wave_bcast<63>(y); // (one wavefront: see batch_dot)
 #pragma unroll
          for (int r = 0; r < C::DR; r++)
          {
@@ -693,7 +735,12 @@ __device__ inline void batch_dot2(const int tid, const double (&v)[C::DR], const
          }
          return;
       }
-      if ((tid & 63) == 63) { slotv[tid >> 6] = x; slotw[tid >> 6] = y; }
+      if (RMH_PACKED_SUMS)
+      {
+         if ((tid & 63) == 31) { slotv[tid >> 6] = x; }
+         if ((tid & 63) == 63) { slotw[tid >> 6] = y; }
+      }
+      else if ((tid & 63) == 63) { slotv[tid >> 6] = x; slotw[tid >> 6] = y; }
       __syncthreads();
       double totv = slotv[0], totw = slotw[0];
 #pragma unroll
@@ -787,19 +834,38 @@ __device__ inline void batch_dot_keep2(const int tid, const double (&v)[C::DR], 
          y += in ? w[r] : 0.0;
          q += in ? z[r] : 0.0;
       }
-      x = wave_sum(x);
-      y = wave_sum(y);
-      q = wave_sum(q);
+      if (RMH_PACKED_SUMS)
+      {
+         y = wave_sum2(y, q); // (the two kept sums share a reduction: w in lane 31, z in lane 63)
+         q = y;
+         x = wave_sum(x);
+      }
+      else
+      {
+         x = wave_sum(x);
+         y = wave_sum(y);
+         q = wave_sum(q);
+      }
       if (NW == 1)
       {
          // (one wavefront: see batch_dot; lane 63 holds the totals and parks the two kept ones -- their readers are behind barriers)
-         if (tid == 63) { lds[C::oKeep] = y; lds[C::oKeep + 1] = q; }
+         if (RMH_PACKED_SUMS)
+         {
+            if (tid == 31) { lds[C::oKeep] = y; }
+            if (tid == 63) { lds[C::oKeep + 1] = q; }
+         }
+         else if (tid == 63) { lds[C::oKeep] = y; lds[C::oKeep + 1] = q; }
          const double tv1 = wave_bcast<63>(x);
 #pragma unroll
          for (int r = 0; r < C::DR; r++) { outv[r] = (tid + r * C::NT < C::D3) ? tv1 : 0.0; }
          return;
       }
-      if ((tid & 63) == 63) { sv[tid >> 6] = x; sw[tid >> 6] = y; sz[tid >> 6] = q; }
+      if (RMH_PACKED_SUMS)
+      {
+         if ((tid & 63) == 31) { sw[tid >> 6] = y; }
+         if ((tid & 63) == 63) { sv[tid >> 6] = x; sz[tid >> 6] = q; }
+      }
+      else if ((tid & 63) == 63) { sv[tid >> 6] = x; sw[tid >> 6] = y; sz[tid >> 6] = q; }
       __syncthreads();
       double totv = sv[0];
 #pragma unroll
@@ -1393,14 +1459,24 @@ tabp gt = gtb;
          my_min = fmin(my_min, in ? gu[j] : INFINITY);
          my_max = fmax(my_max, in ? gu[j] : -INFINITY);
       }
-      my_min = wave_minmax<true>(my_min);
-      my_max = wave_minmax<false>(my_max);
-      if ((tid & 63) == 63)
+      constexpr int NW = NT / 64;
+      double *part = s_acc + 4 * NB + 2; // (8 doubles are reserved for the flags, the first two hold them)
+      static_assert(NB != 1 || NT / 64 <= 3, "spare doubles behind the flags");
+      if (RMH_PACKED_SUMS)
       {
-         double *part = s_acc + 4 * NB + 2; // (8 doubles are reserved for the flags, the first two hold them)
-         static_assert(NB != 1 || NT / 64 <= 3, "spare doubles behind the flags");
-         part[2 * (tid >> 6)] = my_min;
-         part[2 * (tid >> 6) + 1] = my_max;
+         const double mm = wave_min_negmax(my_min, my_max);
+         if ((tid & 63) == 31) { part[2 * (tid >> 6)] = mm; }
+         if ((tid & 63) == 63) { part[2 * (tid >> 6) + 1] = -mm; }
+      }
+      else
+      {
+         my_min = wave_minmax<true>(my_min);
+         my_max = wave_minmax<false>(my_max);
+         if ((tid & 63) == 63)
+         {
+            part[2 * (tid >> 6)] = my_min;
+            part[2 * (tid >> 6) + 1] = my_max;
+         }
       }
    }
    else if (!FUSED && !LO4 && tid < NB)
@@ -2284,14 +2360,26 @@ tabp gt = gtb;
             sp += fmax(0., f);
             sn += fmin(0., f);
          }
-         lo = wave_minmax<true>(lo);
-         hi = wave_minmax<false>(hi);
-         sp = wave_sum(sp);
-         sn = wave_sum(sn);
-         if ((tid & 63) == 63)
+         constexpr int NW = NT / 64;
+         if (RMH_PACKED_SUMS)
          {
+            // (two packed reductions instead of four: lane 31 holds the minimum and the sum of fluct^+, lane 63 -max and the sum of fluct^-)
+            const double mm = wave_min_negmax(lo, hi), ss = wave_sum2(sp, sn);
             double *el = RMH_W(0) + oM1 + 4 * (tid >> 6);
-            el[0] = lo; el[1] = hi; el[2] = sp; el[3] = sn;
+            if ((tid & 63) == 31) { el[0] = mm; el[2] = ss; }
+            if ((tid & 63) == 63) { el[1] = -mm; el[3] = ss; }
+         }
+         else
+         {
+            lo = wave_minmax<true>(lo);
+            hi = wave_minmax<false>(hi);
+            sp = wave_sum(sp);
+            sn = wave_sum(sn);
+            if ((tid & 63) == 63)
+            {
+               double *el = RMH_W(0) + oM1 + 4 * (tid >> 6);
+               el[0] = lo; el[1] = hi; el[2] = sp; el[3] = sn;
+            }
          }
       }
       else if (tid < NB)
@@ -3023,11 +3111,25 @@ tabp gt = gtb;
             lo = fmin(lo, in ? ynew[r] : INFINITY);
             hi = fmax(hi, in ? ynew[r] : -INFINITY);
          }
-         lo = wave_minmax<true>(lo);
-         hi = wave_minmax<false>(hi);
+         if (RMH_PACKED_SUMS)
+         {
+            const double x = wave_min_negmax(lo, hi); // (min in lane 31, -max in lane 63)
+            lo = x;
+            hi = -x;
+         }
+         else
+         {
+            lo = wave_minmax<true>(lo);
+            hi = wave_minmax<false>(hi);
+         }
          if (NW == 1)
          {
-            if (tid == 63 && e0 < L.e_end)
+            if (RMH_PACKED_SUMS)
+            {
+               if (tid == 31 && e0 < L.e_end) { L.xe_min_out[e0] = lo; }
+               if (tid == 63 && e0 < L.e_end) { L.xe_max_out[e0] = hi; }
+            }
+            else if (tid == 63 && e0 < L.e_end)
             {
                L.xe_min_out[e0] = lo;
                L.xe_max_out[e0] = hi;
@@ -3037,7 +3139,12 @@ tabp gt = gtb;
          {
             // (the two ring slots the last element sums did NOT use: slower threads may still be reading those)
             double *slo_ = s_acc + 4 * NB + 8 + C::N2S + ring * NW, *shi_ = s_acc + 4 * NB + 8 + C::N2S + ((ring + 1) % 4) * NW;
-            if ((tid & 63) == 63) { slo_[tid >> 6] = lo; shi_[tid >> 6] = hi; }
+            if (RMH_PACKED_SUMS)
+            {
+               if ((tid & 63) == 31) { slo_[tid >> 6] = lo; }
+               if ((tid & 63) == 63) { shi_[tid >> 6] = hi; }
+            }
+            else if ((tid & 63) == 63) { slo_[tid >> 6] = lo; shi_[tid >> 6] = hi; }
             __syncthreads();
             if (tid == 0 && e0 < L.e_end)
             {
