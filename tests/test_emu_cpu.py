@@ -377,7 +377,7 @@ def test_extrema_tokens(lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("mesh,p,rs,chunks", [("periodic-cube", 4, 0, ((1, 0), (3, 0), (2, 1))), ("cube01_hex", 3, 1, ((1, 0),))])
+@pytest.mark.parametrize("mesh,p,rs,chunks", [("periodic-cube", 4, 0, ((3, 0), (2, 1))), ("cube01_hex", 3, 1, ((1, 0),))])
 def test_xcd_chunk_order_is_a_permutation_of_the_batches(lib, mesh, p, rs, chunks, monkeypatch):
     """The XCD-aware batch order of the stage kernel (ho_kernel2: blockIdx.x -> batch; HoArgs::xcd_chunk, chunks of a lattice
     layer -- or of 2^weave layers woven batch by batch, xcd_weave -- dealt round-robin to the 8 XCDs, the rest in contiguous eighths):
