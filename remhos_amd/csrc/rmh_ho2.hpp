@@ -54,6 +54,11 @@ namespace rmh
 #define RMH_INPLACE_Y (P >= 4)
 #endif
 
+// hierarchical directions of the Q2 mesh nodes (bit mask; explained where the kernel uses it, below)
+#ifndef RMH_HIER
+#define RMH_HIER 5
+#endif
+
 template <int P, bool LO4 = false, bool BOTH = false>
 struct K2Cfg : TabLayout<P>
 {
@@ -75,7 +80,7 @@ struct K2Cfg : TabLayout<P>
    static constexpr int DR = (NB * D3 + NT - 1) / NT; // dof rounds per thread
    // per-element LDS block (doubles): a work region W whose contents change with the phase, and
    // the face buffer.
-   //   phases A-C : [X(t),V nodes 162 | u D3 | neighbour traces 6 D2 | U1 2 Q S2]
+   //   phases A-C : [X(t),V nodes 162 (or their x-contractions, XPK) | u D3 | neighbour traces 6 D2 | U1 2 Q S2]
    //   phases C-G : [R3 3 Q2 D | R2 3 Q D2]
    //   PCG, J     : [sA D3 | M1 / R2' Q S2 | R3' Q2 D | sB D3]
    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -93,7 +98,20 @@ struct K2Cfg : TabLayout<P>
 #define RMH_S2PAD ((D2 & 1) ? 2 : 1)
 #endif
    static constexpr int S2 = D2 + (RMH_S2PAD); // padded row stride of U1 / M1: odd
-   static constexpr int oXV = 0, oU = 162, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
+   // X-CONTRACTED MESH NODES (round 6).  The Q columns of a plane qx all contract the 27 nodes of X(t) and V along x with the same
+   // three 1-D basis values: 162 of the 270 FP64 operations a column spends on the nodes, done Q times over.  With XPK != 0 the
+   // thread that LOADS a node line (comp, ay, az) -- three nodes of x0 and of v -- contracts it for all Q planes on its way to
+   // LDS (phase A: 6 Q FMAs per line, in the shadow of the memory round trip), and the column threads read the values of their qx:
+   //   XPK = 2: [line][xl | vl][qx] + the raw hierarchical nodes x1, x2 of every line (the x-derivative xd = dL1 x1 + dL2 x2 stays
+   //            with the column: 2 Q 27 + 54 doubles instead of 162 -- what the p = 3 work region has room for in phases A-C);
+   //   XPK = 3: [line][xl | vl | xd][qx], no raw nodes (3 Q 27 doubles: p = 6, where the registers, not the LDS, cap the occupancy).
+   // Same operations in the same order as in the column: bit-identical.  Needs the hierarchical x form (RMH_HIER & 1).
+#ifndef RMH_XPK
+#define RMH_XPK ((RMH_HIER & 1) ? ((P == 3 && !LO4) ? 2 : ((P == 6) ? 3 : 0)) : 0)
+#endif
+   static constexpr int XPK = RMH_XPK;
+   static constexpr int XVN = XPK == 0 ? 162 : ((XPK == 2 ? 2 * 27 * Q + 54 : 3 * 27 * Q) + 1) / 2 * 2; // (even: u stays 16-byte aligned)
+   static constexpr int oXV = 0, oXR = 2 * 27 * Q, oU = XVN, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
    // volume rhs by the 1-D change of test basis Cf along y and z (phi^B_i = sum_k C[k][i] l_k; the x-leg of phase G
@@ -309,9 +327,7 @@ __device__ inline double wave_bcast(double v)
 // order).  y as well would save 36 more, but that form of the y-leg makes the compiler spill at every order but 4 (p = 6: 44
 // -> 484 B/lane of scratch, 20.7 k -> 12.7 k MDOFs*stage/s).  Same polynomial, evaluated from differences: results differ from
 // the nodal evaluation by round-off.
-#ifndef RMH_HIER
-#define RMH_HIER 5
-#endif
+// (RMH_HIER itself is defined in front of K2Cfg, whose layout depends on it)
 #ifndef RMH_WAVE_DOT
 #define RMH_WAVE_DOT 1
 #endif
@@ -1033,13 +1049,32 @@ __device__ inline void load_batch(const HoArgs &a, const int e0, const int tid, 
       sti[j] = -1;
       if (FUSED) { sti[j] = a.stencil27[(size_t)min(e0 + k / 27, a.e_end - 1) * 27 + k % 27]; }
    }
-#pragma unroll
-   for (int j = 0; j < NLX; j++)
+   if constexpr (C::XPK != 0)
    {
-      const int k = min(tid + j * NT, NB * 81 - 1);
-      const int e = min(e0 + k / 81, a.e_end - 1);
-      gx0[j] = a.x0[(size_t)e * 81 + k % 81];
-      gv[j] = a.vel[(size_t)e * 81 + k % 81];
+      // (node LINES: the three nodes of (comp, ay, az) go to one thread, which contracts them along x before they reach LDS)
+#pragma unroll
+      for (int j = 0; j < NLX / 3; j++)
+      {
+         const int k = min(tid + j * NT, NB * 27 - 1);
+         const size_t base = (size_t)min(e0 + k / 27, a.e_end - 1) * 81 + 3 * (k % 27);
+#pragma unroll
+         for (int i = 0; i < 3; i++)
+         {
+            gx0[3 * j + i] = a.x0[base + i];
+            gv[3 * j + i] = a.vel[base + i];
+         }
+      }
+   }
+   else
+   {
+#pragma unroll
+      for (int j = 0; j < NLX; j++)
+      {
+         const int k = min(tid + j * NT, NB * 81 - 1);
+         const int e = min(e0 + k / 81, a.e_end - 1);
+         gx0[j] = a.x0[(size_t)e * 81 + k % 81];
+         gv[j] = a.vel[(size_t)e * 81 + k % 81];
+      }
    }
 #pragma unroll
    for (int j = 0; j < NLU; j++)
@@ -1095,7 +1130,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 
    // ---- phase A: loads ----------------------------------------------------------------------
    // (one batch of NB elements per workgroup)
-   constexpr int NLX = (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
+   constexpr int NLX = C::XPK != 0 ? 3 * ((NB * 27 + NT - 1) / NT) : (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
    constexpr int NLS = (NB * 27 + NT - 1) / NT;
    const int nblk = (a.e_end - a.e_begin + NB - 1) / NB;
    int nbi[NLN], sti[NLS];
@@ -1381,15 +1416,50 @@ tabp gt = gtb;
    // (a stale value only costs a redundant atomicMax)
    cg_known = HAS_HO ? *a.cg_iters : 0;
    if (SUBL) { load_submesh(); }
-#pragma unroll
-   for (int j = 0; j < NLX; j++)
+   if constexpr (C::XPK != 0)
    {
-      const int k = tid + j * NT;
-      if (k < NB * 81)
+      tabp gt = RMH_TAB();
+#pragma unroll
+      for (int j = 0; j < NLX / 3; j++)
       {
-         const int eb = k / 81, i = k % 81;
-         RMH_W(eb)[oXV + 81 + i] = gv[j];
-         RMH_W(eb)[oXV + i] = a.move ? gx0[j] + a.t * gv[j] : gx0[j];
+         const int k = tid + j * NT;
+         if (k < NB * 27)
+         {
+            const int eb = k / 27, l = k % 27;
+            const double x0n = a.move ? gx0[3 * j] + a.t * gv[3 * j] : gx0[3 * j];
+            const double x1n = a.move ? gx0[3 * j + 1] + a.t * gv[3 * j + 1] : gx0[3 * j + 1];
+            const double x2n = a.move ? gx0[3 * j + 2] + a.t * gv[3 * j + 2] : gx0[3 * j + 2];
+            const double v0n = gv[3 * j], v1n = gv[3 * j + 1], v2n = gv[3 * j + 2];
+            double *XP = RMH_W(eb) + oXV + l * (C::XPK * Q);
+#pragma unroll
+            for (int qx = 0; qx < Q; qx++)
+            {
+               // (the column's own expressions, see column_pass)
+               const double L1 = gt[oL + qx * 3 + 1], L2 = gt[oL + qx * 3 + 2];
+               XP[qx] = x0n + L1 * x1n + L2 * x2n;
+               XP[Q + qx] = v0n + L1 * v1n + L2 * v2n;
+               if (C::XPK == 3) { XP[2 * Q + qx] = gt[odL + qx * 3 + 1] * x1n + gt[odL + qx * 3 + 2] * x2n; }
+            }
+            if (C::XPK == 2)
+            {
+               RMH_W(eb)[C::oXR + 2 * l] = x1n;
+               RMH_W(eb)[C::oXR + 2 * l + 1] = x2n;
+            }
+         }
+      }
+   }
+   else
+   {
+#pragma unroll
+      for (int j = 0; j < NLX; j++)
+      {
+         const int k = tid + j * NT;
+         if (k < NB * 81)
+         {
+            const int eb = k / 81, i = k % 81;
+            RMH_W(eb)[oXV + 81 + i] = gv[j];
+            RMH_W(eb)[oXV + i] = a.move ? gx0[j] + a.t * gv[j] : gx0[j];
+         }
       }
    }
 #pragma unroll
@@ -1784,6 +1854,7 @@ tabp gt = gtb;
          // pass 1: geometry.  x- and y-contractions of the 27 nodes of X(t) and V for this column
          // (broadcast LDS reads: all columns of an element read the same node)
          const double *XN = RMH_W(ceb) + oXV;
+         const double *XPq = OPQ ? lds + opaque_lds_offset((int)(RMH_W(ceb) - lds) + oXV + qx) : XN + qx; // (XPK: the values of plane qx)
          double A[3][4][3];
 #pragma unroll
          for (int comp = 0; comp < 3; comp++)
@@ -1795,13 +1866,27 @@ tabp gt = gtb;
 #pragma unroll
                for (int ay = 0; ay < 3; ay++)
                {
+                  double xl, xd, vl;
+                  if constexpr (C::XPK != 0)
+                  {
+                     // (contracted along x by the thread that loaded the line, phase A; K2Cfg::XPK)
+                     constexpr int XK = C::XPK;
+                     const int l = comp * 9 + ay + 3 * az;
+                     xl = XPq[l * (XK * Q)];
+                     vl = XPq[l * (XK * Q) + Q];
+                     if (XK == 3) { xd = XPq[l * (XK * Q) + 2 * Q]; }
+                     else { xd = dLx[1] * XN[C::oXR + 2 * l] + dLx[2] * XN[C::oXR + 2 * l + 1]; }
+                  }
+                  else
+                  {
                   const double *xr = XN + comp * 27 + 3 * (ay + 3 * az);
                   const double x0n = xr[0], x1n = xr[1], x2n = xr[2];
                   const double v0n = xr[81], v1n = xr[82], v2n = xr[83];
                   // (hierarchical nodes, RMH_HIER: basis (1, L1, L2), derivative (0, dL1, dL2), along x and along y)
-                  const double xl = HX ? x0n + Lx[1] * x1n + Lx[2] * x2n : Lx[0] * x0n + Lx[1] * x1n + Lx[2] * x2n;
-                  const double xd = HX ? dLx[1] * x1n + dLx[2] * x2n : dLx[0] * x0n + dLx[1] * x1n + dLx[2] * x2n;
-                  const double vl = HX ? v0n + Lx[1] * v1n + Lx[2] * v2n : Lx[0] * v0n + Lx[1] * v1n + Lx[2] * v2n;
+                  xl = HX ? x0n + Lx[1] * x1n + Lx[2] * x2n : Lx[0] * x0n + Lx[1] * x1n + Lx[2] * x2n;
+                  xd = HX ? dLx[1] * x1n + dLx[2] * x2n : dLx[0] * x0n + dLx[1] * x1n + dLx[2] * x2n;
+                  vl = HX ? v0n + Lx[1] * v1n + Lx[2] * v2n : Lx[0] * v0n + Lx[1] * v1n + Lx[2] * v2n;
+                  }
                   if (HY && ay == 0) { a0 = xd; a2 = xl; a3 = vl; }
                   else
                   {
