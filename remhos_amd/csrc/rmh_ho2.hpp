@@ -106,8 +106,12 @@ struct K2Cfg : TabLayout<P>
    //            with the column: 2 Q 27 + 54 doubles instead of 162 -- what the p = 3 work region has room for in phases A-C);
    //   XPK = 3: [line][xl | vl | xd][qx], no raw nodes (3 Q 27 doubles: p = 6, where the registers, not the LDS, cap the occupancy).
    // Same operations in the same order as in the column: bit-identical.  Needs the hierarchical x form (RMH_HIER & 1).
+   // Measured (tools/kbench.py, one box): p = 3 21 768 -> 22 335 / 22 445 (+2.6 ... 3.1 %), p = 6 25 440 -> 25 867 (+1.7 %); static FP64
+   // instructions of the column phase 796 -> 688 (p = 3), 2006 -> 1682 (p = 6, both column forms), its LDS reads 108 -> 80 / 357 -> 273.
+   // Not elsewhere: the lo 4 kernels of p = 6 +-0 (their LDS grows by two granules), those of p = 3 have no room; p = 4, 5 with
+   // only vl precomputed beside the raw nodes of X (all their LDS admits): p = 4 +0.2 %, p = 5 -5 % (the tenth workgroup per CU).
 #ifndef RMH_XPK
-#define RMH_XPK ((RMH_HIER & 1) ? ((P == 3 && !LO4) ? 2 : ((P == 6) ? 3 : 0)) : 0)
+#define RMH_XPK ((RMH_HIER & 1) ? ((P == 3 && !LO4) ? 2 : ((P == 6 && !LO4) ? 3 : 0)) : 0)
 #endif
    static constexpr int XPK = RMH_XPK;
    static constexpr int XVN = XPK == 0 ? 162 : ((XPK == 2 ? 2 * 27 * Q + 54 : 3 * 27 * Q) + 1) / 2 * 2; // (even: u stays 16-byte aligned)
