@@ -1031,7 +1031,7 @@ __global__ void face_geom_kernel(const double *x0, const double *vel, const doub
 
 // Primary global loads of one element batch (phase A): face-neighbour indices, stencil indices (fused stage), Q2
 // nodes of x0 and v, u.
-template <class C, bool FUSED, int NLN, int NLS, int NLX, int NLU>
+template <class C, bool FUSED, bool ULN, int NLN, int NLS, int NLX, int NLU>
 __device__ inline void load_batch(const HoArgs &a, const int e0, const int tid, int (&nbi)[NLN], int (&sti)[NLS], double (&gx0)[NLX],
                                   double (&gv)[NLX], double (&gu)[NLU])
 {
@@ -1080,12 +1080,31 @@ __device__ inline void load_batch(const HoArgs &a, const int e0, const int tid, 
          gv[j] = a.vel[(size_t)e * 81 + k % 81];
       }
    }
-#pragma unroll
-   for (int j = 0; j < NLU; j++)
+   if constexpr (ULN)
    {
-      const int k = min(tid + j * NT, NB * D3 - 1);
-      const int e = min(e0 + k / D3, a.e_end - 1);
-      gu[j] = a.u[(size_t)e * D3 + k % D3];
+      // (u LINES: the D values of a line (iy, iz) go to the thread that contracts them along x on their way to LDS, ho_kernel2 phase A;
+      // tasks and threads as in the pencil phases -- split workgroups: both wavefronts load the line, each forms half the outputs)
+      constexpr bool SPL = NT == 128 && NB == 1;
+      constexpr int PNT = SPL ? 64 : NT, D = C::D;
+      const int ptid = SPL ? (tid & 63) : tid;
+#pragma unroll
+      for (int j = 0; j < NLU / D; j++)
+      {
+         const int k = min(ptid + j * PNT, NB * D2 - 1);
+         const double *line = a.u + (size_t)min(e0 + k / D2, a.e_end - 1) * D3 + D * (k % D2);
+#pragma unroll
+         for (int ix = 0; ix < D; ix++) { gu[j * D + ix] = line[ix]; }
+      }
+   }
+   else
+   {
+#pragma unroll
+      for (int j = 0; j < NLU; j++)
+      {
+         const int k = min(tid + j * NT, NB * D3 - 1);
+         const int e = min(e0 + k / D3, a.e_end - 1);
+         gu[j] = a.u[(size_t)e * D3 + k % D3];
+      }
    }
 }
 
@@ -1134,7 +1153,18 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
 
    // ---- phase A: loads ----------------------------------------------------------------------
    // (one batch of NB elements per workgroup)
-   constexpr int NLX = C::XPK != 0 ? 3 * ((NB * 27 + NT - 1) / NT) : (NB * 81 + NT - 1) / NT, NLU = (NB * D3 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
+   constexpr int NLX = C::XPK != 0 ? 3 * ((NB * 27 + NT - 1) / NT) : (NB * 81 + NT - 1) / NT, NLN = (NB * 6 * D2 + NT - 1) / NT;
+   // U LINES AND JUMPS IN THE LOAD PHASE (round 6, whole-stage kernel of lo 5): the thread that loads a line of u contracts it along x for
+   // all Q planes (U1) and the thread that loads a neighbour's trace value also loads the own face value (an L2 hit: this workgroup
+   // reads the element anyway) and stores the jump -- the x-pencil phase of u, the trace step and their barrier are gone, u itself
+   // never reaches LDS.  The same operations in the same order: bit-identical.  (The stall-dominated pencil and trace phases were 8 %
+   // of a p = 3 workgroup's cycles, profiles/r06_phase_cycles.txt.)
+   // Measured (one box, tools/kbench.py): p = 3 +0.5 ... 0.6 %, p = 5 +0.3 %, p = 4 +0.2 %, p = 6 +0.1 %, p = 2 -0.4 % (not there).
+#ifndef RMH_ULN
+#define RMH_ULN (P >= 3)
+#endif
+   constexpr bool ULN = FUSED && !LO4 && (RMH_ULN);
+   constexpr int NLU = ULN ? D * ((NB * D2 + (NT == 128 && NB == 1 ? 64 : NT) - 1) / (NT == 128 && NB == 1 ? 64 : NT)) : (NB * D3 + NT - 1) / NT;
    constexpr int NLS = (NB * 27 + NT - 1) / NT;
    const int nblk = (a.e_end - a.e_begin + NB - 1) / NB;
    int nbi[NLN], sti[NLS];
@@ -1307,7 +1337,7 @@ tabp gt = gtb;
       trpk[j] = 0u;
       if (TRT) { trpk[j] = ((const unsigned *)(a.tab + C::oTr))[min(tid + j * NT, NB * 6 * D2 - 1) % (6 * D2)]; }
    }
-   load_batch<C, FUSED>(a, e0, tid, nbi, sti, gx0, gv, gu);
+   load_batch<C, FUSED, ULN>(a, e0, tid, nbi, sti, gx0, gv, gu);
    // table copy for lane-dependent indexing: loaded behind the element data, stored with it (a copy loop at the top of
    // the kernel put a full memory round trip in front of the first element load)
    constexpr int NLT = (C::N2S + NT - 1) / NT;
@@ -1350,7 +1380,7 @@ tabp gt = gtb;
          for (int comp = 0; comp < 3; comp++) { gvm[j][comp] = a.rd_subcell ? vmid[comp * C::NS] : 0.0; }
       }
    }
-   double gn[NLN];
+   double gn[NLN], go[ULN ? NLN : 1];
    // LDS offsets of the own face dof and of the jump slot of this thread's trace entries: the trace step of phase B took them apart
    // again (entry -> element, face, face dof, strides: ~30 integer instructions per entry; kept: p = 4, 5, 6 +0.9 ... +1.2 %, p = 3 +0.7 %)
    int tr_own[NLN], tr_dst[NLN];
@@ -1388,6 +1418,7 @@ tabp gt = gtb;
          const int off = (a.gh_compact && nb >= a.ne_owned) ? r : nbr_off;
          const double v = un[off];
          gn[j] = nbi[j] >= 0 ? v : 0.0; // boundary: u_nbr = 0 (no inflow data enters the HO path)
+         if (ULN) { go[ULN ? j : 0] = a.u[(size_t)min(e0 + k / (6 * D2), a.e_end - 1) * D3 + own_off]; }
       }
    }
    // face speed coefficients of this thread's face rows (youngest loads: first used after the second barrier)
@@ -1466,11 +1497,52 @@ tabp gt = gtb;
          }
       }
    }
-#pragma unroll
-   for (int j = 0; j < NLU; j++)
+   if constexpr (ULN)
    {
-      const int k = tid + j * NT;
-      if (k < NB * D3) { RMH_W(k / D3)[oU + k % D3] = gu[j]; }
+      // U1[eb][(kind*Q + qx)*S2 + i2], kind 0: B.u, 1: G.u, from the line in registers (the pencil phase's own expressions)
+#pragma unroll
+      for (int j = 0; j < NLU / D; j++)
+      {
+         const int k = ptid + j * PNT;
+         if (k < NB * D2)
+         {
+            double *dst = RMH_W(k / D2) + oU1 + k % D2;
+            split_outputs<SPL, Q>(wv, [&](auto qlo, auto qhi) {
+               constexpr bool PV3 = (P == 3) && P < RMH_VIEW_MINP;
+               std::conditional_t<PV3, tabp_const, tabp> gt = (std::conditional_t<PV3, tabp_const, tabp>)gtb;
+               if constexpr (PV3) { gt = tab_view_c<P>(); }
+#pragma unroll
+               for (int q = qlo; q < qhi; q++)
+               {
+                  if constexpr (!PV3) { if (((q) - (qlo)) % G2D == 0) { gt = RMH_TABK(); } }
+                  double ub = 0.0, ug = 0.0;
+#pragma unroll
+                  for (int ix = 0; ix < D; ix++)
+                  {
+                     ub += gt[oB + q * D + ix] * gu[j * D + ix];
+                     ug += gt[oG + q * D + ix] * gu[j * D + ix];
+                  }
+                  dst[(0 * Q + q) * S2] = ub;
+                  dst[(1 * Q + q) * S2] = ug;
+               }
+            });
+         }
+      }
+      // the jumps u_nbr - u_own at the face dofs (see the trace step of phase B)
+#pragma unroll
+      for (int j = 0; j < NLN; j++)
+      {
+         if (tid + j * NT < NB * 6 * D2) { lds[tr_dst[j]] = gn[j] - go[ULN ? j : 0]; }
+      }
+   }
+   else
+   {
+#pragma unroll
+      for (int j = 0; j < NLU; j++)
+      {
+         const int k = tid + j * NT;
+         if (k < NB * D3) { RMH_W(k / D3)[oU + k % D3] = gu[j]; }
+      }
    }
 #pragma unroll
    for (int j = 0; j < NLT; j++) { if (tid + j * NT < C::N2S) { stab[tid + j * NT] = gtab[j]; } }
@@ -1564,7 +1636,7 @@ tabp gt = gtb;
    }
    // U1[eb][(kind*Q + qx)*S2 + i2], kind 0: B.u, 1: G.u; pencil tasks (eb, i2)
    static_assert(!SPL || NB * D2 <= 64, "split phases: one task per lane");
-   for (int k = ptid; k < NB * D2; k += PNT)
+   for (int k = ptid; k < (ULN ? 0 : NB * D2); k += PNT)
    {
       const int eb = k / D2, i2 = k % D2;
       const double *src = RMH_W(eb) + oU + D * i2;
@@ -1679,16 +1751,19 @@ tabp gt = gtb;
    // What is stored is the JUMP u_nbr - u_own at the face dof: the Q face rows of a face each formed the same D^2
    // differences from two LDS reads apiece (p = 6: 98 reads and 49 subtractions per row, on the wavefront that is the
    // longer pole of the workgroup); now one read and one subtraction per trace value here, D^2 reads per row there.
-#pragma unroll
-   for (int j = 0; j < NLN; j++)
+   if constexpr (!ULN)
    {
-      const int k = tid + j * NT;
-      if (k < NB * 6 * D2)
+#pragma unroll
+      for (int j = 0; j < NLN; j++)
       {
-         lds[tr_dst[j]] = gn[j] - lds[tr_own[j]];
+         const int k = tid + j * NT;
+         if (k < NB * 6 * D2)
+         {
+            lds[tr_dst[j]] = gn[j] - lds[tr_own[j]];
+         }
       }
+      __syncthreads();
    }
-   __syncthreads();
    RMH_STAMP(25);
    const double t_move = (a.move || P >= 4) ? a.t : 0.0; // (static mesh: the face speed is its value at t = 0; p >= 4 reads the zero coefficients)
    // face rows: thread (eb, f, q1) integrates the quadrature row {(q1, q2)} of face f:
