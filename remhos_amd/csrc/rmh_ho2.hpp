@@ -102,9 +102,9 @@ struct K2Cfg : TabLayout<P>
    // three 1-D basis values: 162 of the 270 FP64 operations a column spends on the nodes, done Q times over.  With XPK != 0 the
    // thread that LOADS a node line (comp, ay, az) -- three nodes of x0 and of v -- contracts it for all Q planes on its way to
    // LDS (phase A: 6 Q FMAs per line, in the shadow of the memory round trip), and the column threads read the values of their qx:
-   //   XPK = 2: [line][xl | vl][qx] + the raw hierarchical nodes x1, x2 of every line (the x-derivative xd = dL1 x1 + dL2 x2 stays
+   //   XPK = 2: [xl | vl][qx][line] + the raw hierarchical nodes x1, x2 of every line (the x-derivative xd = dL1 x1 + dL2 x2 stays
    //            with the column: 2 Q 27 + 54 doubles instead of 162 -- what the p = 3 work region has room for in phases A-C);
-   //   XPK = 3: [line][xl | vl | xd][qx], no raw nodes (3 Q 27 doubles: p = 6, where the registers, not the LDS, cap the occupancy).
+   //   XPK = 3: [xl | vl | xd][qx][line], no raw nodes (3 Q 27 doubles: p = 6, where the registers, not the LDS, cap the occupancy).
    // Same operations in the same order as in the column: bit-identical.  Needs the hierarchical x form (RMH_HIER & 1).
    // Measured (tools/kbench.py, one box): p = 3 21 768 -> 22 335 / 22 445 (+2.6 ... 3.1 %), p = 6 25 440 -> 25 867 (+1.7 %); static FP64
    // instructions of the column phase 796 -> 688 (p = 3), 2006 -> 1682 (p = 6, both column forms), its LDS reads 108 -> 80 / 357 -> 273.
@@ -1465,15 +1465,17 @@ tabp gt = gtb;
             const double x1n = a.move ? gx0[3 * j + 1] + a.t * gv[3 * j + 1] : gx0[3 * j + 1];
             const double x2n = a.move ? gx0[3 * j + 2] + a.t * gv[3 * j + 2] : gx0[3 * j + 2];
             const double v0n = gv[3 * j], v1n = gv[3 * j + 1], v2n = gv[3 * j + 2];
-            double *XP = RMH_W(eb) + oXV + l * (C::XPK * Q);
+            // ([kind][qx][line]: the 27 line threads of an element store side by side, the columns read their plane 27 doubles apart --
+            // banks 54 dwords apart; [line][kind][qx] had 3-way conflicts on every store: SQ_LDS_BANK_CONFLICT 8.0e7 -> 1.29e8 at p = 3)
+            double *XP = RMH_W(eb) + oXV + l;
 #pragma unroll
             for (int qx = 0; qx < Q; qx++)
             {
                // (the column's own expressions, see column_pass)
                const double L1 = gt[oL + qx * 3 + 1], L2 = gt[oL + qx * 3 + 2];
-               XP[qx] = x0n + L1 * x1n + L2 * x2n;
-               XP[Q + qx] = v0n + L1 * v1n + L2 * v2n;
-               if (C::XPK == 3) { XP[2 * Q + qx] = gt[odL + qx * 3 + 1] * x1n + gt[odL + qx * 3 + 2] * x2n; }
+               XP[qx * 27] = x0n + L1 * x1n + L2 * x2n;
+               XP[(Q + qx) * 27] = v0n + L1 * v1n + L2 * v2n;
+               if (C::XPK == 3) { XP[(2 * Q + qx) * 27] = gt[odL + qx * 3 + 1] * x1n + gt[odL + qx * 3 + 2] * x2n; }
             }
             if (C::XPK == 2)
             {
@@ -1933,7 +1935,7 @@ tabp gt = gtb;
          // pass 1: geometry.  x- and y-contractions of the 27 nodes of X(t) and V for this column
          // (broadcast LDS reads: all columns of an element read the same node)
          const double *XN = RMH_W(ceb) + oXV;
-         const double *XPq = OPQ ? lds + opaque_lds_offset((int)(RMH_W(ceb) - lds) + oXV + qx) : XN + qx; // (XPK: the values of plane qx)
+         const double *XPq = OPQ ? lds + opaque_lds_offset((int)(RMH_W(ceb) - lds) + oXV + qx * 27) : XN + qx * 27; // (XPK: the values of plane qx)
          double A[3][4][3];
 #pragma unroll
          for (int comp = 0; comp < 3; comp++)
@@ -1951,9 +1953,9 @@ tabp gt = gtb;
                      // (contracted along x by the thread that loaded the line, phase A; K2Cfg::XPK)
                      constexpr int XK = C::XPK;
                      const int l = comp * 9 + ay + 3 * az;
-                     xl = XPq[l * (XK * Q)];
-                     vl = XPq[l * (XK * Q) + Q];
-                     if (XK == 3) { xd = XPq[l * (XK * Q) + 2 * Q]; }
+                     xl = XPq[l];
+                     vl = XPq[Q * 27 + l];
+                     if (XK == 3) { xd = XPq[2 * Q * 27 + l]; }
                      else { xd = dLx[1] * XN[C::oXR + 2 * l] + dLx[2] * XN[C::oXR + 2 * l + 1]; }
                   }
                   else
