@@ -2922,14 +2922,16 @@ tabp gt = gtb;
       batch_dot<C>(tid, tmp, red, lds, s_acc, ring); // betanom = r.z
       RMH_STAMP(15);
       bool any = false;
-      const double be_uni = UNI ? fdiv(red[0], nom[0]) : 0.0;
+      // (the new direction only where the element goes on: a converged element -- under the -pa rule every element of the bench meshes
+      // after its first iteration -- skips the quotient, a nine-instruction chain per round; its d is not read again)
+      double be_uni = 0.0;
+      if (UNI && act[0] && red[0] > tol[0]) { be_uni = fdiv(red[0], nom[0]); }
 #pragma unroll
       for (int r = 0; r < DR; r++)
       {
-         const double z = rg[r] * dg[r];
          if (act[r])
          {
-            dd[r] = z + (UNI ? be_uni : fdiv(red[r], nom[r])) * dd[r];
+            if (red[r] > tol[r]) { dd[r] = rg[r] * dg[r] + (UNI ? be_uni : fdiv(red[r], nom[r])) * dd[r]; }
             nom[r] = red[r];
             its[r]++;
          }
