@@ -1160,6 +1160,8 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // never reaches LDS.  The same operations in the same order: bit-identical.  (The stall-dominated pencil and trace phases were 8 %
    // of a p = 3 workgroup's cycles, profiles/r06_phase_cycles.txt.)
    // Measured (one box, tools/kbench.py): p = 3 +0.5 ... 0.6 %, p = 5 +0.3 %, p = 4 +0.2 %, p = 6 +0.1 %, p = 2 -0.4 % (not there).
+   // The lo 4 stage kernels (u also stored for the subcell pass, the barrier kept for the sub-mesh nodes): p = 3 +-0, p = 6 -0.15 %,
+   // p = 4 +0.1 %, p = 5 +0.5 % -- not there.
 #ifndef RMH_ULN
 #define RMH_ULN (P >= 3)
 #endif
