@@ -98,3 +98,14 @@ def test_compact_line_never_exceeds_the_limit(capsys):
     for k in ("metric", "value", "unit", "n_gpus", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert "cutting it to the contract's fields" in capsys.readouterr().err
+
+
+def test_committed_traffic_entries_belong_to_the_committed_kernel_sources():
+    """bench.py reports `roofline.traffic` / `dram_frac` / `of_bound` only from PMC entries measured on the kernel sources it runs
+    (profiles/traffic_ho_kernel.json is keyed by their hash): a kernel change without a re-measured profile would silently drop them."""
+    have = bench.kernel_source_hash()
+    entries = json.load(open(os.path.join(os.path.dirname(HERE), "profiles", "traffic_ho_kernel.json")))
+    stage = {k: v for k, v in entries.items() if isinstance(v, dict) and "kernel_src_sha" in v and "-stage" in k}
+    assert stage, "no stage entries"
+    for k, v in stage.items():
+        assert v["kernel_src_sha"] == have, (k, v["kernel_src_sha"], have)
