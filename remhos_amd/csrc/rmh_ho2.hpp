@@ -54,12 +54,17 @@ namespace rmh
 #define RMH_INPLACE_Y (P >= 4)
 #endif
 
+// the lo 5 stage kernel forms the x-contraction of u and the face jumps in its load phase (ho_kernel2, ULN): u itself is not in LDS
+#ifndef RMH_ULN
+#define RMH_ULN (P >= 3)
+#endif
 // hierarchical directions of the Q2 mesh nodes (bit mask; explained where the kernel uses it, below)
 #ifndef RMH_HIER
 #define RMH_HIER 5
 #endif
 
-template <int P, bool LO4 = false, bool BOTH = false>
+// (NOU: no u slot in the work region -- the whole-stage kernel of lo 5 where RMH_ULN holds, see K2For)
+template <int P, bool LO4 = false, bool BOTH = false, bool NOU = false>
 struct K2Cfg : TabLayout<P>
 {
    using T = TabLayout<P>;
@@ -108,14 +113,19 @@ struct K2Cfg : TabLayout<P>
    // Same operations in the same order as in the column: bit-identical.  Needs the hierarchical x form (RMH_HIER & 1).
    // Measured (tools/kbench.py, one box): p = 3 21 768 -> 22 335 / 22 445 (+2.6 ... 3.1 %), p = 6 25 440 -> 25 867 (+1.7 %); static FP64
    // instructions of the column phase 796 -> 688 (p = 3), 2006 -> 1682 (p = 6, both column forms), its LDS reads 108 -> 80 / 357 -> 273.
-   // Not elsewhere: the lo 4 kernels of p = 6 +-0 (their LDS grows by two granules), those of p = 3 have no room; p = 4, 5 with
-   // only vl precomputed beside the raw nodes of X (all their LDS admits): p = 4 +0.2 %, p = 5 -5 % (the tenth workgroup per CU).
+   // p = 4: XPK = 2 (HO kernel) / 3 (stage kernel, whose u slot is free: K2For) -- 12.6 KB per one-wavefront workgroup, still twelve per CU
+   // (the LDS is allocated in finer granules than K2Cfg::LDS_BYTES assumes): cube01_hex -rs 5 23 500 -> 23 900 (XPK = 2) -> 24 090 (+2.5 %).
+   // Not elsewhere: the lo 4 kernels of p = 6 +-0 (their LDS grows by two granules), those of p = 3 have no room; p = 5 with only vl
+   // precomputed (all its LDS admits): -5 % (the tenth workgroup per CU; p = 4 with vl alone: +0.2 %).
 #ifndef RMH_XPK
-#define RMH_XPK ((RMH_HIER & 1) ? ((P == 3 && !LO4) ? 2 : ((P == 6 && !LO4) ? 3 : 0)) : 0)
+#ifndef RMH_XPK4
+#define RMH_XPK4 (NOU ? 3 : 2)
+#endif
+#define RMH_XPK ((RMH_HIER & 1) ? ((P == 3 && !LO4) ? 2 : ((P == 6 && !LO4) ? 3 : ((P == 4 && !LO4) ? RMH_XPK4 : 0))) : 0)
 #endif
    static constexpr int XPK = RMH_XPK;
    static constexpr int XVN = XPK == 0 ? 162 : ((XPK == 2 ? 2 * 27 * Q + 54 : 3 * 27 * Q) + 1) / 2 * 2; // (even: u stays 16-byte aligned)
-   static constexpr int oXV = 0, oXR = 2 * 27 * Q, oU = XVN, oNb = oU + D3, oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
+   static constexpr int oXV = 0, oXR = 2 * 27 * Q, oU = XVN, oNb = oU + (NOU ? 0 : D3), oU1 = oNb + 6 * D2, PA = oU1 + 2 * Q * S2;
    // test tensors: r = 0 rhs (GL basis; Bernstein in the RD-only kernel), 1 lumped mass, 2 Jacobi diagonal.
    // When HO and RD run in the same kernel, z = K_vol u in the Bernstein basis is obtained from the GL-tested
    // volume rhs by the 1-D change of test basis Cf along y and z (phi^B_i = sum_k C[k][i] l_k; the x-leg of phase G
@@ -214,7 +224,9 @@ struct K2Cfg : TabLayout<P>
    // ignored as long as the compiler sees the 32 KB of static LDS -- it clamps the request to what the LDS admits, rounded down;
    // with the work region as dynamic LDS the bound is honoured (168 VGPRs, 68 B/lane of scratch, five resident workgroups per CU)
    // and the stage is 11 % SLOWER: 12.36 k -> 10.98 k MDOFs*stage/s.  It stays at 2, profiles/r05_lo4_split.txt.)
-   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0));
+   // (p = 4 with the x-contracted node lines: 12.6 KB per workgroup; the 2 KiB model above says 11 workgroups per CU, the hardware runs 12 --
+   // LDS is allocated in finer granules: measured, cube01_hex -rs 5 +2.5 % with the bound kept at three wavefronts per SIMD)
+   static constexpr int WAVES_PER_SIMD = (P == 6 && !LO4) ? RMH_WAVES6 : ((P == 5 && !LO4) ? RMH_WAVES5 : ((P == 4 && !LO4) ? 3 : (WAVES_PER_SIMD0 > 8 ? 8 : WAVES_PER_SIMD0)));
 };
 
 // v + (v of the lane selected by the DPP control), lanes outside row_mask add 0
@@ -1118,10 +1130,19 @@ __device__ inline void load_batch(const HoArgs &a, const int e0, const int tid, 
 //                 z = K_vol u, lumped upwind face fluxes, sub-mesh motion and subcell fluctuations, nodal
 //                 weights, du_LO; also writes the lumped mass and the element extrema (like the reference's
 //                 RD solver does, remhos_lo.cpp:1702-1716).  No mass solve.
+// the layout of ho_kernel2<P, MODE>.  The u slot is dropped where the room buys something: p = 4, whose one-wavefront workgroups then hold all
+// three x-contractions of the node lines (XPK = 3 instead of 2: 23.5 -> 24.1 k instead of 23.9 k on cube01_hex -rs 5); p = 3, 5 +-0 (nothing to
+// put there), p = 6 -0.3 % (the offsets behind the slot change parity).
+#ifndef RMH_NOU
+#define RMH_NOU (P == 4)
+#endif
+template <int P, int MODE>
+using K2For = K2Cfg<P, (MODE >= 2), (MODE == 3), (MODE == 1 && (RMH_ULN) && (RMH_NOU))>;
+
 template <int P, int MODE>
 // MODE 3        : the whole RK stage for -ho 3 -lo 4 -fct 2: MODE 0 + MODE 2 + overlap bounds + ClipScale + RK
 //                 update in one kernel (geometry, face data and u-contractions shared by HO and RD).
-__global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2Cfg<P, (MODE >= 2), (MODE == 3)>::WAVES_PER_SIMD)) ho_kernel2(HoArgs a)
+__global__ void __launch_bounds__((K2For<P, MODE>::NT), (K2For<P, MODE>::WAVES_PER_SIMD)) ho_kernel2(HoArgs a)
 {
    constexpr bool FUSED = MODE == 1 || MODE == 3; // limiter + RK update at the end
    constexpr bool LO4 = MODE >= 2;                // subcell residual distribution pieces
@@ -1132,7 +1153,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    if (threadIdx.x < 32) { s_stamp[threadIdx.x] = 0; }
    unsigned long long stamp_prev_ = clock64();
 #endif
-   using C = K2Cfg<P, (MODE >= 2), (MODE == 3)>;
+   using C = K2For<P, MODE>;
    constexpr int D = C::D, Q = C::Q, D2 = C::D2, D3 = C::D3, Q2 = C::Q2, NT = C::NT, NB = C::NB, DR = C::DR;
    constexpr int S2 = C::S2;
    constexpr int oXV = C::oXV, oU = C::oU, oNb = C::oNb, oU1 = C::oU1, oR3 = C::oR3, oR2 = C::oR2, oSA = C::oSA,
@@ -1162,9 +1183,7 @@ __global__ void __launch_bounds__((K2Cfg<P, (MODE >= 2), (MODE == 3)>::NT), (K2C
    // Measured (one box, tools/kbench.py): p = 3 +0.5 ... 0.6 %, p = 5 +0.3 %, p = 4 +0.2 %, p = 6 +0.1 %, p = 2 -0.4 % (not there).
    // The lo 4 stage kernels (u also stored for the subcell pass, the barrier kept for the sub-mesh nodes): p = 3 +-0, p = 6 -0.15 %,
    // p = 4 +0.1 %, p = 5 +0.5 % -- not there.
-#ifndef RMH_ULN
-#define RMH_ULN (P >= 3)
-#endif
+   // (RMH_ULN is defined in front of K2Cfg: the stage kernel's layout drops the u slot with it)
    constexpr bool ULN = FUSED && !LO4 && (RMH_ULN);
    constexpr int NLU = ULN ? D * ((NB * D2 + (NT == 128 && NB == 1 ? 64 : NT) - 1) / (NT == 128 && NB == 1 ? 64 : NT)) : (NB * D3 + NT - 1) / NT;
    constexpr int NLS = (NB * 27 + NT - 1) / NT;
