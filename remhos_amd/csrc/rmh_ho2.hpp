@@ -110,6 +110,9 @@ struct K2Cfg : TabLayout<P>
    //   XPK = 2: [xl | vl][qx][line] + the raw hierarchical nodes x1, x2 of every line (the x-derivative xd = dL1 x1 + dL2 x2 stays
    //            with the column: 2 Q 27 + 54 doubles instead of 162 -- what the p = 3 work region has room for in phases A-C);
    //   XPK = 3: [xl | vl | xd][qx][line], no raw nodes (3 Q 27 doubles: p = 6, where the registers, not the LDS, cap the occupancy).
+   //   (p = 3, xd of the components 0 and 1 as well -- 18 of the 27 lines fit the stage kernel's freed u slot without a byte more LDS, 36 more
+   //   FP64 operations off a column: the compiler then spills in the column pass, 168 VGPRs + 28 B/lane of scratch, 22.2 -> 21.7 k; with
+   //   scheduling fences 144 B/lane.  Not kept.)
    // Same operations in the same order as in the column: bit-identical.  Needs the hierarchical x form (RMH_HIER & 1).
    // Measured (tools/kbench.py, one box): p = 3 21 768 -> 22 335 / 22 445 (+2.6 ... 3.1 %), p = 6 25 440 -> 25 867 (+1.7 %); static FP64
    // instructions of the column phase 796 -> 688 (p = 3), 2006 -> 1682 (p = 6, both column forms), its LDS reads 108 -> 80 / 357 -> 273.
