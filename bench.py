@@ -692,7 +692,7 @@ def measure(args, lib, order, rs, world, rank, dev, dist, backend, with_counters
 
 def granular_block(args, lib, world, rank, dev, dist, backend):
     """The reference's own call sequence at the plug-in boundary (remhos.cpp:1692, 1815-1831): CalcHOSolution, CalcLOSolution,
-    ComputeElementsMinMax + ComputeBounds, CalcFCTSolution as separate kernels, the RK vector updates by the caller (torch) --
+    ComputeElementsMinMax + ComputeBounds, CalcFCTSolution as separate kernels, the RK vector updates by the caller (y.Add: torch; add(a, x, b, y, z): rmhd_axpby) --
     what a binding that only replaces the three solver classes gets -- and the HO kernel + fused limiter.
     The limiter-side kernels stream every E-vector once: each is priced against its algorithmic HBM bytes (8 B x dofs x
     vectors read and written, + the stencil table), timed alone with HIP events on the context's stream."""

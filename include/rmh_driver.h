@@ -154,6 +154,13 @@ int rmhd_run_partitioned(const rmhd_config *cfg, const char *comm_id_file, int d
  * 0 on success.  Exported so that the protocol can be exercised without a GPU (tests/test_id_file.py). */
 int rmhd_id_file_exchange(const char *path, int writer, char id[128]);
 
+/* z = a x + b y on n doubles of device memory, one pass, on `stream` (a hipStream_t; NULL = the default stream): the vector
+ * combination the reference's time integrators make between two Mult calls -- MFEM's add(a, x, b, y, z) in RK3SSPSolver::Step (the
+ * solver remhos.cpp:490 selects for -s 3) and in remhos_solvers.cpp:134, 194 (add(x, c dt, dx, x_new)) -- i.e. remhos::add of
+ * include/remhos_amd/solvers.hpp for callers that hold raw pointers (the Python stepper's granular call sequence; z may alias x or y).
+ * 0 on success. */
+int rmhd_axpby(double a, const double *x, double b, const double *y, double *z, long long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "librmh_host.so")
 DRIVER_SYMBOLS = [
     "rmhd_case_create", "rmhd_case_destroy", "rmhd_last_error", "rmhd_case_get_info", "rmhd_case_x0",
     "rmhd_case_vel", "rmhd_case_u0", "rmhd_case_s0", "rmhd_case_subcell_vel", "rmhd_case_face_nbr", "rmhd_case_stencil27",
-    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_case_save", "rmhd_run", "rmhd_run_state", "rmhd_run_rank", "rmhd_run_partitioned", "rmhd_id_file_exchange",
+    "rmhd_case_owned_gid", "rmhd_case_ghost_gid", "rmhd_case_peer", "rmhd_case_save", "rmhd_run", "rmhd_run_state", "rmhd_run_rank", "rmhd_run_partitioned", "rmhd_id_file_exchange", "rmhd_axpby",
 ]
 
 
@@ -83,6 +83,9 @@ def bind_driver(lib: C.CDLL) -> C.CDLL:
     lib.rmhd_last_error.restype = C.c_char_p
     lib.rmhd_case_get_info.argtypes = [p, C.POINTER(RmhdCaseInfo)]
     lib.rmhd_case_save.argtypes = [p, C.c_double, p, C.c_char_p, C.c_char_p]
+    if hasattr(lib, "rmhd_axpby"):  # (device library only: librmh_host.so has no kernels)
+        lib.rmhd_axpby.argtypes = [C.c_double, p, C.c_double, p, p, C.c_longlong, p]
+        lib.rmhd_axpby.restype = C.c_int
     for name in ("x0", "vel", "u0", "s0", "subcell_vel", "face_nbr", "stencil27", "owned_gid", "ghost_gid"):
         f = getattr(lib, "rmhd_case_" + name)
         f.argtypes = [p]

@@ -1046,6 +1046,15 @@ bool read_or_write_id(const char *path, bool writer, char id[128])
 }
 } // namespace
 
+extern "C" int rmhd_axpby(double a, const double *x, double b, const double *y, double *z, long long n, void *stream)
+{
+   if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!x || !y || !z))) { g_driver_error = "rmhd_axpby: bad argument"; return -1; }
+   if (n == 0) { return 0; }
+   hipLaunchKernelGGL(remhos::axpby_kernel, dim3(remhos::grid_for((int)n)), dim3(256), 0, (hipStream_t)stream, a, x, b, y, z, (int)n);
+   if (hipGetLastError() != hipSuccess) { g_driver_error = "rmhd_axpby: launch failed"; return -1; }
+   return 0;
+}
+
 extern "C" int rmhd_id_file_exchange(const char *path, int writer, char id[128])
 {
    if (!path || !path[0] || !id) { g_driver_error = "rmhd_id_file_exchange: null argument"; return -1; }

@@ -18,6 +18,11 @@ from .capi import Context
 class Stepper:
     def __init__(self, lib, case, device="cuda:0", dist=None, fused=True, one_kernel=True, overlap=True):
         self.case = case
+        self.lib = lib
+        if hasattr(lib, "rmhd_axpby") and not lib.rmhd_axpby.argtypes:  # (a library handle that did not go through case.bind_driver)
+            import ctypes as _C
+            lib.rmhd_axpby.argtypes = [_C.c_double, _C.c_void_p, _C.c_double, _C.c_void_p, _C.c_void_p, _C.c_longlong, _C.c_void_p]
+            lib.rmhd_axpby.restype = _C.c_int
         self.overlap = overlap  # one-kernel stage: interior elements overlap the halo exchange
         self.dev = torch.device(device)
         # validation aid (tools/two_ranks_one_gpu.py): a backend that is not stream-aware needs the pack kernel finished
@@ -229,12 +234,18 @@ class Stepper:
         if x_base is None and b == 1.0:
             torch.add(u, du, alpha=dt, out=out)
         else:
+            # RK3SSPSolver::Step: y.Add(dt, k); add(a, x, b, y, z) -- two vector operations, as in the reference's integrator
             torch.add(u, du, alpha=dt, out=du)
-            du.mul_(b)
-            if x_base is None:
-                out.copy_(du)
+            if x_base is not None and hasattr(self.lib, "rmhd_axpby"):
+                stream = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
+                if self.lib.rmhd_axpby(a, x_base.data_ptr(), b, du.data_ptr(), out.data_ptr(), du.numel(), stream) != 0:
+                    raise RuntimeError("rmhd_axpby: " + self.lib.rmhd_last_error().decode())
             else:
-                torch.add(du, x_base, alpha=a, out=out)
+                du.mul_(b)
+                if x_base is None:
+                    out.copy_(du)
+                else:
+                    torch.add(du, x_base, alpha=a, out=out)
         return 0
 
     def step(self, dt):

@@ -45,7 +45,7 @@ def test_rmh_driver_h_symbols(built):
         assert getattr(lib, n) is not None
     host = ctypes.CDLL(os.path.join(ROOT, "remhos_amd", "librmh_host.so"))
     for n in names:
-        if n not in ("rmhd_run", "rmhd_run_state", "rmhd_run_rank", "rmhd_run_partitioned", "rmhd_id_file_exchange"):  # (the time loops need the GPU library)
+        if n not in ("rmhd_run", "rmhd_run_state", "rmhd_run_rank", "rmhd_run_partitioned", "rmhd_id_file_exchange", "rmhd_axpby"):  # (the time loops and the vector kernel need the GPU library)
             assert getattr(host, n) is not None
 
 
